@@ -1,0 +1,113 @@
+// Fused plane-sweep warp + feature correlation (forward) for gfx950.
+//
+// One launch produces the whole [B,D,H,W] cost volume for all M measurement frames: the per-plane homography,
+// the bilinear gather of the measurement features, the channel reduction and the mean over measurement frames
+// are fused, so the volume is written exactly once and no warped temporary ever exists in HBM.
+// Semantics: /root/reference/dvmvs/utils.py:45-107 (see oracle/dvmvs_oracle.py for the CPU restatement).
+#include "plane_sweep.h"
+
+namespace dvmvs {
+
+// ----------------------------------------------------------------------------------------------------------------
+// Generic kernel: any C, dot or SAD, arithmetic in the reference's order (interpolate, then reduce channels).
+// Workgroup = 64 consecutive pixels x 4 plane sub-groups; each thread owns one pixel and PPT consecutive planes,
+// so a wave's tap loads for one channel hit a few consecutive cache lines of the NCHW measurement map.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int kGenericPlaneGroups = 4;
+
+template <bool DOT, int PPT>
+__global__ __launch_bounds__(kWave* kGenericPlaneGroups) void cost_volume_generic_kernel(CostVolumeArgs a) {
+  constexpr int kPlanesPerBlock = kGenericPlaneGroups * PPT;
+  __shared__ float s_H[DVMVS_MAX_MEASUREMENTS * 9];
+  __shared__ float s_kt[DVMVS_MAX_MEASUREMENTS * 3];
+  __shared__ float s_ktd[DVMVS_MAX_MEASUREMENTS * kPlanesPerBlock * 3];
+
+  const int b = blockIdx.z;
+  const int d_block = blockIdx.y * kPlanesPerBlock;
+  const int tid = threadIdx.y * kWave + threadIdx.x;
+  sweep_setup(a, b, d_block, kPlanesPerBlock, tid, kWave * kGenericPlaneGroups, s_H, s_kt, s_ktd);
+
+  const int HW = a.H * a.W;
+  const int pix = blockIdx.x * kWave + threadIdx.x;
+  if (pix >= HW) return;
+  const int y = pix / a.W;
+  const int x = pix - y * a.W;
+  const float xf = static_cast<float>(x), yf = static_cast<float>(y);
+  const int dl0 = threadIdx.y * PPT;
+
+  const float* ref = a.image1 + static_cast<size_t>(b) * a.C * HW + pix;
+  float fused[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) fused[j] = 0.0f;
+
+  for (int m = 0; m < a.M; ++m) {
+    int off[PPT][4];
+    float wgt[PPT][4];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      float ix, iy;
+      sweep_position(s_H + m * 9, s_ktd + (m * kPlanesPerBlock + dl0 + j) * 3, xf, yf, a.W, a.H, &ix, &iy);
+      const BilinearTaps t = make_taps(ix, iy, a.W, a.H);
+      const int xa = t.in_x0 ? t.x0 : 0, xb = t.in_x1 ? t.x0 + 1 : 0;
+      const int ya = t.in_y0 ? t.y0 : 0, yb = t.in_y1 ? t.y0 + 1 : 0;
+      off[j][0] = ya * a.W + xa;
+      off[j][1] = ya * a.W + xb;
+      off[j][2] = yb * a.W + xa;
+      off[j][3] = yb * a.W + xb;
+      wgt[j][0] = (t.in_x0 && t.in_y0) ? t.w_nw : 0.0f;
+      wgt[j][1] = (t.in_x1 && t.in_y0) ? t.w_ne : 0.0f;
+      wgt[j][2] = (t.in_x0 && t.in_y1) ? t.w_sw : 0.0f;
+      wgt[j][3] = (t.in_x1 && t.in_y1) ? t.w_se : 0.0f;
+    }
+    float acc[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) acc[j] = 0.0f;
+    const float* meas = a.image2[m] + static_cast<size_t>(b) * a.C * HW;
+    for (int c = 0; c < a.C; ++c) {
+      const float r = ref[static_cast<size_t>(c) * HW];
+      const float* plane = meas + static_cast<size_t>(c) * HW;
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) {
+        float s = plane[off[j][0]] * wgt[j][0];
+        s += plane[off[j][1]] * wgt[j][1];
+        s += plane[off[j][2]] * wgt[j][2];
+        s += plane[off[j][3]] * wgt[j][3];
+        if (DOT) acc[j] += r * s;
+        else acc[j] += fabsf(r - s);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) fused[j] += DOT ? acc[j] / static_cast<float>(a.C) : acc[j];
+  }
+
+  float* out = a.out + (static_cast<size_t>(b) * a.D + d_block + dl0) * HW + pix;
+#pragma unroll
+  for (int j = 0; j < PPT; ++j)
+    if (d_block + dl0 + j < a.D) out[static_cast<size_t>(j) * HW] = fused[j] / static_cast<float>(a.M);
+}
+
+int launch_cost_volume_generic(const CostVolumeArgs& a, bool dot, hipStream_t stream) {
+  constexpr int PPT = 4;
+  const int HW = a.H * a.W;
+  dim3 block(kWave, kGenericPlaneGroups);
+  dim3 grid((HW + kWave - 1) / kWave, (a.D + kGenericPlaneGroups * PPT - 1) / (kGenericPlaneGroups * PPT), a.B);
+  if (dot) hipLaunchKernelGGL((cost_volume_generic_kernel<true, PPT>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((cost_volume_generic_kernel<false, PPT>), grid, block, 0, stream, a);
+  return launch_status();
+}
+
+}  // namespace dvmvs
+
+extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, const float* pose1,
+                                     const float* const* pose2s, const float* K, float* cost_volume,
+                                     int B, int M, int C, int H, int W, int D,
+                                     double min_depth, double max_depth, int dot_product, int variant,
+                                     dvmvs_stream_t stream) {
+  using namespace dvmvs;
+  if (variant < 0 || variant > 2) return DVMVS_EINVAL;
+  if (variant == 2 && !dot_product) return DVMVS_EUNSUPPORTED;
+  CostVolumeArgs a;
+  const int rc = fill_sweep_args(&a, image1, image2s, pose1, pose2s, K, cost_volume, B, M, C, H, W, D, min_depth, max_depth, true);
+  if (rc != 0) return rc;
+  return launch_cost_volume_generic(a, dot_product != 0, static_cast<hipStream_t>(stream));
+}

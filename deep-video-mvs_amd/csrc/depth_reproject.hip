@@ -1,0 +1,88 @@
+// Forward splat of the previous depth map into the current half-resolution view (z-buffer, farthest wins), gfx950.
+//
+// The reference sorts all points by relu(z) descending, projects, rounds, and keeps the first point per target
+// pixel through a host round trip (argsort + gather + ij.cpu().numpy() -> np.unique -> .cuda() + index_put_):
+// /root/reference/dvmvs/utils.py:110-154.  "First after a descending sort" is "maximum relu(z) among the points
+// that land on the pixel", and relu(z) >= 0, so its IEEE bit pattern orders like an unsigned integer: one
+// atomicMax per source pixel reproduces the result exactly, in any execution order, with no sort and no sync.
+#include "dvmvs_device.h"
+
+namespace dvmvs {
+
+constexpr float kReprojEps = 1e-8f;
+
+__global__ __launch_bounds__(256) void depth_splat_kernel(const float* __restrict__ ref_pose, const float* __restrict__ meas_pose,
+                                                          const float* __restrict__ prev_depth, const float* __restrict__ full_K,
+                                                          const float* __restrict__ half_K, unsigned int* __restrict__ out_bits,
+                                                          int B, int Hf, int Wf) {
+#pragma clang fp contract(off)
+  __shared__ float s_T[16];
+  const int b = blockIdx.y;
+  if (threadIdx.x == 0) {
+    double T[16];
+    relative_pose_f64(ref_pose + b * 16, meas_pose + b * 16, T);  // inverse(reference_pose) * measurement_pose
+    for (int i = 0; i < 16; ++i) s_T[i] = static_cast<float>(T[i]);
+  }
+  __syncthreads();
+  const int HWf = Hf * Wf;
+  const int hw = Wf / 2, hh = Hf / 2;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= HWf) return;
+  const int y = pix / Wf, x = pix - y * Wf;
+  const float* Kf = full_K + b * 9;
+  const float* Kh = half_K + b * 9;
+  const float d = prev_depth[static_cast<size_t>(b) * HWf + pix];
+  // kornia.depth_to_3d with the full-resolution intrinsics
+  const float px = ((static_cast<float>(x) - Kf[2]) / Kf[0]) * d;
+  const float py = ((static_cast<float>(y) - Kf[5]) / Kf[4]) * d;
+  const float pz = d;
+  float q[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) q[r] = ((s_T[r * 4 + 0] * px + s_T[r * 4 + 1] * py) + s_T[r * 4 + 2] * pz) + s_T[r * 4 + 3];
+  const float sw = fabsf(q[3]) > kReprojEps ? 1.0f / q[3] : 1.0f;
+  const float X = sw * q[0], Y = sw * q[1], Z = sw * q[2];
+  const float z_store = fmaxf(Z, 0.0f);                       // value written: relu(z)        (utils.py:129)
+  const float sz = fabsf(Z) > kReprojEps ? 1.0f / Z : 1.0f;   // projection uses the raw z    (utils.py:134-136)
+  const float u = rintf((X * sz) * Kh[0] + Kh[2]);            // torch.round = half-to-even
+  const float v = rintf((Y * sz) * Kh[4] + Kh[5]);
+  if (!(u >= 0.0f && v >= 0.0f && u < static_cast<float>(hw) && v < static_cast<float>(hh))) return;  // also drops NaN
+  if (!(z_store > 0.0f)) return;                               // 0 (or NaN) never beats the zero-initialised buffer
+  atomicMax(out_bits + static_cast<size_t>(b) * hh * hw + static_cast<int>(v) * hw + static_cast<int>(u), __float_as_uint(z_store));
+}
+
+// F.interpolate(scale_factor=1/f, mode="nearest") for an integer factor: picks rows / columns 0, f, 2f, ...
+__global__ void nearest_decimate_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int f) {
+  const int Ho = H / f, Wo = W / f;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Ho * Wo) return;
+  const int xo = i % Wo, yo = (i / Wo) % Ho, b = i / (Wo * Ho);
+  out[i] = in[(static_cast<size_t>(b) * H + yo * f) * W + xo * f];
+}
+
+}  // namespace dvmvs
+
+extern "C" int dvmvs_depth_reproject_fwd(const float* reference_pose, const float* measurement_pose,
+                                         const float* previous_depth, const float* full_K, const float* half_K,
+                                         float* out, float* out_lowres, int lowres_factor,
+                                         int B, int full_height, int full_width, dvmvs_stream_t stream) {
+  using namespace dvmvs;
+  if (!reference_pose || !measurement_pose || !previous_depth || !full_K || !half_K || !out) return DVMVS_EINVAL;
+  if (B <= 0 || full_height < 2 || full_width < 2 || B > 65535) return DVMVS_EINVAL;
+  if (out_lowres && lowres_factor <= 0) return DVMVS_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int hh = full_height / 2, hw = full_width / 2;
+  DVMVS_RETURN_IF_HIP(hipMemsetAsync(out, 0, sizeof(float) * static_cast<size_t>(B) * hh * hw, s));
+  const int HWf = full_height * full_width;
+  hipLaunchKernelGGL(depth_splat_kernel, dim3((HWf + 255) / 256, B), dim3(256), 0, s, reference_pose, measurement_pose,
+                     previous_depth, full_K, half_K, reinterpret_cast<unsigned int*>(out), B, full_height, full_width);
+  int rc = launch_status();
+  if (rc != 0) return rc;
+  if (out_lowres) {
+    const int n = B * (hh / lowres_factor) * (hw / lowres_factor);
+    if (n > 0) {
+      hipLaunchKernelGGL(nearest_decimate_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, out_lowres, B, hh, hw, lowres_factor);
+      rc = launch_status();
+    }
+  }
+  return rc;
+}

@@ -1,0 +1,102 @@
+// Plane-sweep geometry shared by the forward and backward cost-volume kernels (gfx950).
+// Semantics: /root/reference/dvmvs/utils.py:51-73.
+#pragma once
+
+#include "dvmvs_device.h"
+
+namespace dvmvs {
+
+struct CostVolumeArgs {
+  const float* image1;
+  const float* image2[DVMVS_MAX_MEASUREMENTS];
+  const float* pose1;
+  const float* pose2[DVMVS_MAX_MEASUREMENTS];
+  const float* K;
+  float* out;
+  int B, M, C, H, W, D;
+  double inv_depth_base, inv_depth_step;
+};
+
+// Per-(batch, measurement) sweep constants, evaluated once per workgroup into LDS.
+//   Hm = K R K^-1 (row-major 3x3), kt = K t   with [R|t] = inverse(pose2) * pose1     (utils.py:51-56)
+__device__ inline void sweep_matrices(const float* pose1, const float* pose2, const float* K, float* Hm, float* kt) {
+  double E[16];
+  relative_pose_f64(pose2, pose1, E);
+  double Kd[9], Kinv[9], R[9], KR[9], KRKinv[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Kd[i] = static_cast<double>(K[i]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) R[r * 3 + c] = E[r * 4 + c];
+  inverse3(Kd, Kinv);
+  matmul3(Kd, R, KR);
+  matmul3(KR, Kinv, KRKinv);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Hm[i] = static_cast<float>(KRKinv[i]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    kt[r] = static_cast<float>(Kd[r * 3 + 0] * E[0 * 4 + 3] + Kd[r * 3 + 1] * E[1 * 4 + 3] + Kd[r * 3 + 2] * E[2 * 4 + 3]);
+}
+
+// depth of sweep plane d as the reference's python-double expression, rounded to fp32 where it meets the tensor
+__device__ inline float plane_depth(double inv_base, double inv_step, int d) {
+  return static_cast<float>(1.0 / (inv_base + static_cast<double>(d) * inv_step));
+}
+
+// Fills s_H[M][9], s_kt[M][3] and s_ktd[M][planes][3] (= kt / depth_d for d in [d_begin, d_begin+planes)).
+__device__ inline void sweep_setup(const CostVolumeArgs& a, int b, int d_begin, int planes, int tid, int nthreads,
+                                   float* s_H, float* s_kt, float* s_ktd) {
+  if (tid < a.M) sweep_matrices(a.pose1 + b * 16, a.pose2[tid] + b * 16, a.K + b * 9, s_H + tid * 9, s_kt + tid * 3);
+  __syncthreads();
+  for (int i = tid; i < a.M * planes * 3; i += nthreads) {
+    const int k = i % 3;
+    const int dl = (i / 3) % planes;
+    const int m = i / (3 * planes);
+    const int d = d_begin + dl;
+    s_ktd[i] = (d < a.D) ? s_kt[m * 3 + k] / plane_depth(a.inv_depth_base, a.inv_depth_step, d) : 0.0f;
+  }
+  __syncthreads();
+}
+
+// Sample position of reference pixel (x, y) on one plane of one measurement frame, in measurement-image pixels.
+// Op order follows utils.py:68-73 and ATen's align_corners un-normalisation.
+__device__ inline void sweep_position(const float* Hm, const float* ktd, float xf, float yf, int W, int H, float* ix, float* iy) {
+  const float X = fmaf(Hm[2], 1.0f, fmaf(Hm[1], yf, Hm[0] * xf)) + ktd[0];
+  const float Y = fmaf(Hm[5], 1.0f, fmaf(Hm[4], yf, Hm[3] * xf)) + ktd[1];
+  const float Z = fmaf(Hm[8], 1.0f, fmaf(Hm[7], yf, Hm[6] * xf)) + ktd[2];
+  const float denom = Z + 1e-8f;
+  const float u = X / denom;
+  const float v = Y / denom;
+  const float wn = static_cast<float>(W) * 0.5f;
+  const float hn = static_cast<float>(H) * 0.5f;
+  *ix = unnormalize_ac((u - wn) / wn, W);
+  *iy = unnormalize_ac((v - hn) / hn, H);
+}
+
+// Validates the shared arguments of the forward / backward entry points and fills the kernel argument block.
+inline int fill_sweep_args(CostVolumeArgs* a, const float* image1, const float* const* image2s, const float* pose1,
+                           const float* const* pose2s, const float* K, float* out, int B, int M, int C, int H, int W, int D,
+                           double min_depth, double max_depth, bool need_out) {
+  if (!image1 || !image2s || !pose1 || !pose2s || !K || (need_out && !out)) return DVMVS_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || D <= 0 || M <= 0) return DVMVS_EINVAL;
+  if (M > DVMVS_MAX_MEASUREMENTS || D > DVMVS_MAX_DEPTH_LEVELS || B > 65535) return DVMVS_EUNSUPPORTED;
+  if (static_cast<long long>(C) * H * W >= (1LL << 31)) return DVMVS_EUNSUPPORTED;
+  if (!(min_depth > 0.0) || !(max_depth > 0.0)) return DVMVS_EINVAL;
+  a->image1 = image1;
+  a->pose1 = pose1;
+  a->K = K;
+  a->out = out;
+  for (int m = 0; m < DVMVS_MAX_MEASUREMENTS; ++m) {
+    if (m < M && (!image2s[m] || !pose2s[m])) return DVMVS_EINVAL;
+    a->image2[m] = m < M ? image2s[m] : nullptr;
+    a->pose2[m] = m < M ? pose2s[m] : nullptr;
+  }
+  a->B = B; a->M = M; a->C = C; a->H = H; a->W = W; a->D = D;
+  // utils.py:59-60, python doubles
+  a->inv_depth_base = 1.0 / max_depth;
+  a->inv_depth_step = D > 1 ? (1.0 / min_depth - 1.0 / max_depth) / (D - 1) : 0.0;
+  return 0;
+}
+
+}  // namespace dvmvs

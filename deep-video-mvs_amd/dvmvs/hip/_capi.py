@@ -1,0 +1,83 @@
+"""ctypes binding of ``libdvmvs_hip.so`` (the C ABI declared in ``include/dvmvs_hip.h``).
+
+The library is the only implementation of the hot path: there is no CPU or eager-PyTorch fallback.  If it has not
+been built (``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C deep-video-mvs_amd/csrc``) every op
+raises ``RuntimeError`` on first use.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("DVMVS_HIP_LIB", os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libdvmvs_hip.so")))
+
+ABI_VERSION = 1
+MAX_MEASUREMENTS = 8
+MAX_DEPTH_LEVELS = 256
+
+_c_fp = ctypes.c_void_p          # device pointer to float
+_c_fpp = ctypes.POINTER(ctypes.c_void_p)  # host array of device pointers
+_c_int = ctypes.c_int
+_c_dbl = ctypes.c_double
+_c_stream = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol the header declares (checked by tests/test_capi_symbols.py)
+SIGNATURES = {
+    "dvmvs_abi_version": (_c_int, []),
+    "dvmvs_build_arch": (ctypes.c_char_p, []),
+    "dvmvs_error_string": (ctypes.c_char_p, [_c_int]),
+    "dvmvs_cost_volume_fwd": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fpp, _c_fp, _c_fp,
+                                       _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                       _c_dbl, _c_dbl, _c_int, _c_int, _c_stream]),
+    "dvmvs_cost_volume_bwd": (_c_int, [_c_fp, _c_fp, _c_fpp, _c_fp, _c_fpp, _c_fp, _c_fp, _c_fpp,
+                                       _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                       _c_dbl, _c_dbl, _c_stream]),
+    "dvmvs_hidden_warp_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "dvmvs_hidden_warp_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "dvmvs_relative_pose": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_stream]),
+    "dvmvs_lstm_gates_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "dvmvs_lstm_gates_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "dvmvs_depth_reproject_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int,
+                                           _c_int, _c_int, _c_int, _c_stream]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Loads the shared library once; raises RuntimeError (never falls back) when it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"dvmvs HIP library not found at {LIB_PATH}. Build it with `make -C deep-video-mvs_amd/csrc` "
+                f"(or __graft_entry__.build()). The plane-sweep ops have no CPU / eager fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library mismatch: let it propagate loudly
+            fn.restype = restype
+            fn.argtypes = argtypes
+        got = handle.dvmvs_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"libdvmvs_hip.so ABI {got} does not match the Python binding ({ABI_VERSION}); rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().dvmvs_error_string(code).decode()
+        raise RuntimeError(f"{what} failed with code {code}: {msg}")
+
+
+def pointer_array(ptrs):
+    """Host array of device pointers (``const float* const*`` in the header)."""
+    arr = (ctypes.c_void_p * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr

@@ -1,0 +1,297 @@
+"""``torch.library`` custom ops over the C ABI of ``libdvmvs_hip.so``.
+
+Each op is a thin shim: check device/dtype, make inputs contiguous, allocate the output with torch, pass raw device
+pointers and the current HIP stream to the ``extern "C"`` launcher.  No op synchronises or touches the host, so a
+whole frame can be captured into a hipGraph (``torch.cuda.graph``).  Tensors that are not on the GPU are rejected:
+the CPU restatement lives in ``oracle/`` and is test infrastructure only.
+"""
+from typing import List, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from dvmvs.hip import _capi
+
+__all__ = ["cost_volume", "hidden_warp", "relative_pose", "lstm_gates", "depth_reproject", "depth_reproject_lowres"]
+
+
+def _no_cpu(op):
+    raise RuntimeError(f"dvmvs::{op} only runs as a HIP kernel on an MI355X; move the tensors to the GPU. "
+                       f"There is deliberately no CPU fallback (the CPU oracle under oracle/ is for tests).")
+
+
+def _dev_f32(name, *tensors):
+    for t in tensors:
+        if t.device.type != "cuda":
+            _no_cpu(name)
+        if t.dtype != torch.float32:
+            raise TypeError(f"dvmvs::{name}: expected float32 tensors, got {t.dtype}")
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return t.data_ptr()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fused plane-sweep cost volume
+# ----------------------------------------------------------------------------------------------------------------------
+@torch.library.custom_op("dvmvs::cost_volume", mutates_args=(), device_types="cuda")
+def cost_volume(image1: Tensor, image2s: Sequence[Tensor], pose1: Tensor, pose2s: Sequence[Tensor], K: Tensor,
+                min_depth: float, max_depth: float, n_depth_levels: int, dot_product: bool, variant: int) -> Tensor:
+    _dev_f32("cost_volume", image1, pose1, K, *image2s, *pose2s)
+    M = len(image2s)
+    if M == 0 or M != len(pose2s):
+        raise ValueError("dvmvs::cost_volume: need as many measurement poses as measurement feature maps (>= 1)")
+    B, C, H, W = image1.shape
+    image1 = image1.contiguous()
+    image2s = [t.contiguous() for t in image2s]
+    pose1 = pose1.contiguous()
+    pose2s = [t.contiguous() for t in pose2s]
+    K = K.contiguous()
+    for t in image2s:
+        if t.shape != image1.shape:
+            raise ValueError(f"dvmvs::cost_volume: measurement features {tuple(t.shape)} != reference {tuple(image1.shape)}")
+    out = torch.empty((B, n_depth_levels, H, W), dtype=torch.float32, device=image1.device)
+    with torch.cuda.device(image1.device):
+        rc = _capi.lib().dvmvs_cost_volume_fwd(
+            _ptr(image1), _capi.pointer_array([_ptr(t) for t in image2s]), _ptr(pose1),
+            _capi.pointer_array([_ptr(t) for t in pose2s]), _ptr(K), _ptr(out),
+            B, M, C, H, W, n_depth_levels, float(min_depth), float(max_depth), int(bool(dot_product)), int(variant),
+            _stream(image1))
+    _capi.check(rc, "dvmvs_cost_volume_fwd")
+    return out
+
+
+@cost_volume.register_fake
+def _(image1, image2s, pose1, pose2s, K, min_depth, max_depth, n_depth_levels, dot_product, variant):
+    B, C, H, W = image1.shape
+    return image1.new_empty((B, n_depth_levels, H, W))
+
+
+@cost_volume.register_kernel("cpu")
+def _(image1, image2s, pose1, pose2s, K, min_depth, max_depth, n_depth_levels, dot_product, variant):
+    _no_cpu("cost_volume")
+
+
+def _cost_volume_setup(ctx, inputs, output):
+    image1, image2s, pose1, pose2s, K, min_depth, max_depth, n_depth_levels, dot_product, variant = inputs
+    if not dot_product and (image1.requires_grad or any(t.requires_grad for t in image2s)):
+        raise NotImplementedError("dvmvs::cost_volume: gradients are implemented for dot_product=True only")
+    ctx.M = len(image2s)
+    ctx.depth_range = (min_depth, max_depth, n_depth_levels)
+    ctx.save_for_backward(image1, pose1, K, *image2s, *pose2s)
+
+
+def _cost_volume_backward(ctx, grad):
+    saved = ctx.saved_tensors
+    M = ctx.M
+    image1, pose1, K = saved[0], saved[1], saved[2]
+    image2s, pose2s = list(saved[3:3 + M]), list(saved[3 + M:3 + 2 * M])
+    min_depth, max_depth, D = ctx.depth_range
+    grad = grad.contiguous()
+    B, C, H, W = image1.shape
+    image1c = image1.contiguous()
+    image2c = [t.contiguous() for t in image2s]
+    pose2c = [t.contiguous() for t in pose2s]
+    g1 = torch.empty_like(image1c)
+    need2 = ctx.needs_input_grad[1]
+    g2 = [torch.zeros_like(t) for t in image2c] if need2 else []
+    with torch.cuda.device(image1.device):
+        rc = _capi.lib().dvmvs_cost_volume_bwd(
+            _ptr(grad), _ptr(image1c), _capi.pointer_array([_ptr(t) for t in image2c]), _ptr(pose1.contiguous()),
+            _capi.pointer_array([_ptr(t) for t in pose2c]), _ptr(K.contiguous()), _ptr(g1),
+            _capi.pointer_array([_ptr(t) for t in g2] if need2 else [None] * M),
+            B, M, C, H, W, D, float(min_depth), float(max_depth), _stream(image1))
+    _capi.check(rc, "dvmvs_cost_volume_bwd")
+    return g1, (g2 if need2 else None), None, None, None, None, None, None, None, None
+
+
+torch.library.register_autograd("dvmvs::cost_volume", _cost_volume_backward, setup_context=_cost_volume_setup)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# hidden-state warp
+# ----------------------------------------------------------------------------------------------------------------------
+@torch.library.custom_op("dvmvs::hidden_warp", mutates_args=(), device_types="cuda")
+def hidden_warp(image_src: Tensor, depth_dst: Tensor, src_trans_dst: Tensor, camera_matrix: Tensor,
+                zero_invalid: bool) -> Tensor:
+    _dev_f32("hidden_warp", image_src, depth_dst, src_trans_dst, camera_matrix)
+    B, C, H, W = image_src.shape
+    image_src, depth_dst = image_src.contiguous(), depth_dst.contiguous()
+    src_trans_dst, camera_matrix = src_trans_dst.contiguous(), camera_matrix.contiguous()
+    out = torch.empty_like(image_src)
+    with torch.cuda.device(image_src.device):
+        rc = _capi.lib().dvmvs_hidden_warp_fwd(_ptr(image_src), _ptr(depth_dst), _ptr(src_trans_dst), _ptr(camera_matrix),
+                                               _ptr(out), B, C, H, W, int(bool(zero_invalid)), _stream(image_src))
+    _capi.check(rc, "dvmvs_hidden_warp_fwd")
+    return out
+
+
+@hidden_warp.register_fake
+def _(image_src, depth_dst, src_trans_dst, camera_matrix, zero_invalid):
+    return torch.empty_like(image_src)
+
+
+@hidden_warp.register_kernel("cpu")
+def _(image_src, depth_dst, src_trans_dst, camera_matrix, zero_invalid):
+    _no_cpu("hidden_warp")
+
+
+def _hidden_warp_setup(ctx, inputs, output):
+    image_src, depth_dst, src_trans_dst, camera_matrix, _ = inputs
+    ctx.shape = tuple(image_src.shape)
+    ctx.save_for_backward(depth_dst, src_trans_dst, camera_matrix)
+
+
+def _hidden_warp_backward(ctx, grad):
+    depth_dst, src_trans_dst, camera_matrix = ctx.saved_tensors
+    B, C, H, W = ctx.shape
+    grad = grad.contiguous()
+    gsrc = torch.zeros_like(grad)
+    with torch.cuda.device(grad.device):
+        # the validity mask is NOT applied to the gradient, as in the reference (convlstm.py:41 edits .data)
+        rc = _capi.lib().dvmvs_hidden_warp_bwd(_ptr(grad), _ptr(depth_dst.contiguous()), _ptr(src_trans_dst.contiguous()),
+                                               _ptr(camera_matrix.contiguous()), _ptr(gsrc), B, C, H, W, _stream(grad))
+    _capi.check(rc, "dvmvs_hidden_warp_bwd")
+    return gsrc, None, None, None, None
+
+
+torch.library.register_autograd("dvmvs::hidden_warp", _hidden_warp_backward, setup_context=_hidden_warp_setup)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# inverse(a) @ c for 4x4 poses
+# ----------------------------------------------------------------------------------------------------------------------
+@torch.library.custom_op("dvmvs::relative_pose", mutates_args=(), device_types="cuda")
+def relative_pose(a: Tensor, c: Tensor) -> Tensor:
+    _dev_f32("relative_pose", a, c)
+    if a.shape != c.shape or a.shape[-2:] != (4, 4) or a.dim() != 3:
+        raise ValueError(f"dvmvs::relative_pose: expected two [B,4,4] tensors, got {tuple(a.shape)} and {tuple(c.shape)}")
+    a, c = a.contiguous(), c.contiguous()
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        rc = _capi.lib().dvmvs_relative_pose(_ptr(a), _ptr(c), _ptr(out), a.shape[0], _stream(a))
+    _capi.check(rc, "dvmvs_relative_pose")
+    return out
+
+
+@relative_pose.register_fake
+def _(a, c):
+    return torch.empty_like(a)
+
+
+@relative_pose.register_kernel("cpu")
+def _(a, c):
+    _no_cpu("relative_pose")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ConvLSTM gate fusion
+# ----------------------------------------------------------------------------------------------------------------------
+@torch.library.custom_op("dvmvs::lstm_gates", mutates_args=(), device_types="cuda")
+def lstm_gates(combined_conv: Tensor, c_cur: Tensor) -> Tuple[Tensor, Tensor]:
+    _dev_f32("lstm_gates", combined_conv, c_cur)
+    B, hidden, H, W = c_cur.shape
+    if combined_conv.shape != (B, 4 * hidden, H, W):
+        raise ValueError(f"dvmvs::lstm_gates: conv output {tuple(combined_conv.shape)} does not match state {tuple(c_cur.shape)}")
+    combined_conv, c_cur = combined_conv.contiguous(), c_cur.contiguous()
+    h_next, c_next = torch.empty_like(c_cur), torch.empty_like(c_cur)
+    with torch.cuda.device(c_cur.device):
+        rc = _capi.lib().dvmvs_lstm_gates_fwd(_ptr(combined_conv), _ptr(c_cur), _ptr(h_next), _ptr(c_next), B, hidden, H, W,
+                                              _stream(c_cur))
+    _capi.check(rc, "dvmvs_lstm_gates_fwd")
+    return h_next, c_next
+
+
+@lstm_gates.register_fake
+def _(combined_conv, c_cur):
+    return torch.empty_like(c_cur), torch.empty_like(c_cur)
+
+
+@lstm_gates.register_kernel("cpu")
+def _(combined_conv, c_cur):
+    _no_cpu("lstm_gates")
+
+
+def _lstm_gates_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _lstm_gates_backward(ctx, grad_h, grad_c):
+    combined_conv, c_cur = ctx.saved_tensors
+    B, hidden, H, W = c_cur.shape
+    cc, cs = combined_conv.contiguous(), c_cur.contiguous()
+    gh = grad_h.contiguous() if grad_h is not None else None
+    gc = grad_c.contiguous() if grad_c is not None else None
+    grad_cc, grad_cs = torch.empty_like(cc), torch.empty_like(cs)
+    with torch.cuda.device(cs.device):
+        rc = _capi.lib().dvmvs_lstm_gates_bwd(_ptr(gh) if gh is not None else None, _ptr(gc) if gc is not None else None,
+                                              _ptr(cc), _ptr(cs), _ptr(grad_cc), _ptr(grad_cs), B, hidden, H, W, _stream(cs))
+    _capi.check(rc, "dvmvs_lstm_gates_bwd")
+    return grad_cc, grad_cs
+
+
+torch.library.register_autograd("dvmvs::lstm_gates", _lstm_gates_backward, setup_context=_lstm_gates_setup)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# depth re-projection (forward splat)
+# ----------------------------------------------------------------------------------------------------------------------
+def _reproject(name, reference_pose, measurement_pose, previous_depth, full_K, half_K, factor):
+    _dev_f32(name, reference_pose, measurement_pose, previous_depth, full_K, half_K)
+    B, one, Hf, Wf = previous_depth.shape
+    if one != 1:
+        raise ValueError(f"dvmvs::{name}: previous depth must be [B,1,H,W], got {tuple(previous_depth.shape)}")
+    args = [t.contiguous() for t in (reference_pose, measurement_pose, previous_depth, full_K, half_K)]
+    out = torch.empty((B, 1, Hf // 2, Wf // 2), dtype=torch.float32, device=previous_depth.device)
+    low = None
+    if factor > 0:
+        low = torch.empty((B, 1, (Hf // 2) // factor, (Wf // 2) // factor), dtype=torch.float32, device=previous_depth.device)
+    with torch.cuda.device(previous_depth.device):
+        rc = _capi.lib().dvmvs_depth_reproject_fwd(*[_ptr(t) for t in args], _ptr(out), _ptr(low) if low is not None else None,
+                                                   int(factor), B, Hf, Wf, _stream(previous_depth))
+    _capi.check(rc, "dvmvs_depth_reproject_fwd")
+    return out, low
+
+
+@torch.library.custom_op("dvmvs::depth_reproject", mutates_args=(), device_types="cuda")
+def depth_reproject(reference_pose: Tensor, measurement_pose: Tensor, previous_depth: Tensor, full_K: Tensor,
+                    half_K: Tensor) -> Tensor:
+    return _reproject("depth_reproject", reference_pose, measurement_pose, previous_depth, full_K, half_K, 0)[0]
+
+
+@depth_reproject.register_fake
+def _(reference_pose, measurement_pose, previous_depth, full_K, half_K):
+    B, _, Hf, Wf = previous_depth.shape
+    return previous_depth.new_empty((B, 1, Hf // 2, Wf // 2))
+
+
+@depth_reproject.register_kernel("cpu")
+def _(reference_pose, measurement_pose, previous_depth, full_K, half_K):
+    _no_cpu("depth_reproject")
+
+
+@torch.library.custom_op("dvmvs::depth_reproject_lowres", mutates_args=(), device_types="cuda")
+def depth_reproject_lowres(reference_pose: Tensor, measurement_pose: Tensor, previous_depth: Tensor, full_K: Tensor,
+                           half_K: Tensor, factor: int) -> Tuple[Tensor, Tensor]:
+    """Splat plus the nearest /factor decimation the fusionnet call site applies next (one C-ABI call)."""
+    if factor <= 0:
+        raise ValueError("dvmvs::depth_reproject_lowres: factor must be positive")
+    out, low = _reproject("depth_reproject_lowres", reference_pose, measurement_pose, previous_depth, full_K, half_K, factor)
+    return out, low
+
+
+@depth_reproject_lowres.register_fake
+def _(reference_pose, measurement_pose, previous_depth, full_K, half_K, factor):
+    B, _, Hf, Wf = previous_depth.shape
+    return (previous_depth.new_empty((B, 1, Hf // 2, Wf // 2)),
+            previous_depth.new_empty((B, 1, (Hf // 2) // factor, (Wf // 2) // factor)))
+
+
+@depth_reproject_lowres.register_kernel("cpu")
+def _(reference_pose, measurement_pose, previous_depth, full_K, half_K, factor):
+    _no_cpu("depth_reproject_lowres")

@@ -1,0 +1,212 @@
+"""``dvmvs.utils`` -- the reference's geometric hot-path functions, executed by hand-written gfx950 HIP kernels.
+
+Function names, argument order and return shapes are those of /root/reference/dvmvs/utils.py so the reference's
+run-testing / run-training scripts can import this module unchanged.  The bodies are not translations: each of
+the hot functions is one C-ABI call into ``libdvmvs_hip.so`` (see ``include/dvmvs_hip.h``):
+
+===================================================  ==========================================================
+reference function (utils.py)                        what runs here
+===================================================  ==========================================================
+calculate_cost_volume_by_warping  :45-86             dvmvs_cost_volume_fwd, M = 1 (all planes, one launch)
+cost_volume_fusion                :89-107            dvmvs_cost_volume_fwd, all M frames fused, written once
+get_non_differentiable_rectangle_depth_estimation    dvmvs_depth_reproject_fwd (atomic z-buffer; no sort, no
+                                  :110-154           host round trip)
+warp_frame_depth                  :205-258           dvmvs_hidden_warp_fwd
+===================================================  ==========================================================
+
+There is no CPU implementation in this package; CPU tensors raise.  ``cv2``/``kornia``/``path``/``pytorch3d`` are
+not imported.
+"""
+import os
+import zipfile
+
+import numpy as np
+import torch
+
+from dvmvs.hip import ops as _ops
+
+# kernel selector for the cost volume: 0 = automatic, 1 = generic reference-order kernel, 2 = tap-reuse kernel
+COST_VOLUME_VARIANT = int(os.environ.get("DVMVS_COST_VOLUME_VARIANT", "0"))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# geometry
+# ----------------------------------------------------------------------------------------------------------------------
+def pose_distance(reference_pose, measurement_pose):
+    """Combined / rotational / translational distance between two camera-to-world poses (4x4 numpy).
+
+    Keyframe-selection measure of /root/reference/dvmvs/utils.py:17-31.
+    """
+    relative = np.linalg.inv(reference_pose) @ measurement_pose
+    rotation, translation = relative[:3, :3], relative[:3, 3]
+    r_measure = np.sqrt(2 * (1 - min(3.0, float(np.trace(rotation))) / 3))
+    t_measure = np.linalg.norm(translation)
+    return np.sqrt(t_measure ** 2 + r_measure ** 2), r_measure, t_measure
+
+
+def is_pose_available(pose):
+    return bool(np.all(np.isfinite(pose)))
+
+
+def get_warp_grid_for_cost_volume_calculation(width, height, device):
+    """[3, H*W] homogeneous pixel grid (x, y, 1), row-major.
+
+    Kept for call-site compatibility (/root/reference/dvmvs/utils.py:34-42).  The HIP kernel derives pixel
+    coordinates from its thread index, so the tensor is only shape-checked by ``cost_volume_fusion``.
+    """
+    ys, xs = torch.meshgrid(torch.arange(int(height), dtype=torch.float32), torch.arange(int(width), dtype=torch.float32),
+                            indexing="ij")
+    grid = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(int(height) * int(width))], dim=0)
+    return grid.to(device)
+
+
+def _check_warp_grid(warp_grid, height, width):
+    if warp_grid is not None and tuple(warp_grid.shape) != (3, height * width):
+        raise ValueError(f"warp_grid must be [3, {height * width}] for a {width}x{height} feature map, "
+                         f"got {tuple(warp_grid.shape)}")
+
+
+def cost_volume_fusion(image1, image2s, pose1, pose2s, K, warp_grid, min_depth, max_depth, n_depth_levels, device,
+                       dot_product):
+    """Mean plane-sweep cost volume [B,D,H,W] of ``image1`` against every measurement frame in ``image2s``.
+
+    One fused HIP launch for all frames and planes.  ``device`` is accepted for signature compatibility; the
+    computation happens where the tensors live (which must be the GPU).
+    """
+    _check_warp_grid(warp_grid, image1.shape[2], image1.shape[3])
+    return _ops.cost_volume(image1, list(image2s), pose1, list(pose2s), K, float(min_depth), float(max_depth),
+                            int(n_depth_levels), bool(dot_product), COST_VOLUME_VARIANT)
+
+
+def calculate_cost_volume_by_warping(image1, image2, pose1, pose2, K, warp_grid, min_depth, max_depth, n_depth_levels,
+                                     device, dot_product):
+    """Cost volume of a single measurement frame (the M = 1 case of ``cost_volume_fusion``)."""
+    return cost_volume_fusion(image1, [image2], pose1, [pose2], K, warp_grid, min_depth, max_depth, n_depth_levels,
+                              device, dot_product)
+
+
+def get_non_differentiable_rectangle_depth_estimation(reference_pose_torch, measurement_pose_torch, previous_depth_torch,
+                                                      full_K_torch, half_K_torch, original_width, original_height):
+    """Previous depth map splatted into the current view at half resolution, farthest surface wins, holes = 0."""
+    B, _, H, W = previous_depth_torch.shape
+    if (H, W) != (int(original_height), int(original_width)):
+        raise ValueError(f"previous depth is {W}x{H} but original size was given as {original_width}x{original_height}")
+    with torch.no_grad():
+        return _ops.depth_reproject(reference_pose_torch, measurement_pose_torch, previous_depth_torch, full_K_torch,
+                                    half_K_torch)
+
+
+def warp_frame_depth(image_src, depth_dst, src_trans_dst, camera_matrix, normalize_points=False, sampling_mode="bilinear"):
+    """Warp ``image_src`` [B,C,H,W] into the destination view given the destination depth [B,1,H,W]."""
+    for name, t in (("image_src", image_src), ("depth_dst", depth_dst), ("src_trans_dst", src_trans_dst),
+                    ("camera_matrix", camera_matrix)):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"Input {name} type is not a torch.Tensor. Got {type(t)}.")
+    if image_src.dim() != 4:
+        raise ValueError(f"Input image_src must have a shape (B, D, H, W). Got: {image_src.shape}")
+    if depth_dst.dim() != 4 or depth_dst.shape[-3] != 1:
+        raise ValueError(f"Input depth_dst must have a shape (B, 1, H, W). Got: {depth_dst.shape}")
+    if src_trans_dst.dim() != 3 or tuple(src_trans_dst.shape[-2:]) != (4, 4):
+        raise ValueError(f"Input src_trans_dst must have a shape (B, 4, 4). Got: {src_trans_dst.shape}.")
+    if camera_matrix.dim() != 3 or tuple(camera_matrix.shape[-2:]) != (3, 3):
+        raise ValueError(f"Input camera_matrix must have a shape (B, 3, 3). Got: {camera_matrix.shape}.")
+    if normalize_points or sampling_mode != "bilinear":
+        raise NotImplementedError("the HIP hidden-state warp implements normalize_points=False, sampling_mode='bilinear' "
+                                  "(the only configuration the depth networks use)")
+    return _ops.hidden_warp(image_src, depth_dst, src_trans_dst, camera_matrix, False)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# training helpers
+# ----------------------------------------------------------------------------------------------------------------------
+def freeze_batchnorm(module):
+    if isinstance(module, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d)):
+        module.eval()
+        module.weight.requires_grad = False
+        module.bias.requires_grad = False
+
+
+def zip_code(run_directory):
+    """Snapshot the *.py files of the working directory and its parent into ``run_directory/code.zip``."""
+    with zipfile.ZipFile(os.path.join(run_directory, "code.zip"), "w", zipfile.ZIP_DEFLATED) as handle:
+        for folder in ("./", "../"):
+            for name in sorted(os.listdir(folder)):
+                if name.endswith(".py"):
+                    handle.write(os.path.join(folder, name))
+
+
+def _checkpoint_name(prefix, filename, step, loss):
+    return "{}_{}_epoch:{}_l1:{:.4f}_l1-inv:{:.4f}_l1-rel:{:.4f}_huber:{:.4f}".format(prefix, filename, step, *loss[:4])
+
+
+def save_checkpoint(save_path, models, step, loss, filename="checkpoint.pth.tar"):
+    for model in models:
+        torch.save(model["state_dict"], os.path.join(str(save_path), _checkpoint_name(model["name"], filename, step, loss)))
+
+
+def save_optimizer(save_path, optimizer, step, loss, filename="checkpoint.pth.tar"):
+    torch.save(optimizer.state_dict(), os.path.join(str(save_path), _checkpoint_name("optimizer", filename, step, loss)))
+
+
+def print_number_of_trainable_parameters(optimizer):
+    count = sum(p.nelement() for group in optimizer.param_groups for p in group["params"] if p.requires_grad)
+    print("Number of trainable parameters:", f"{count:,d}")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# inference helpers
+# ----------------------------------------------------------------------------------------------------------------------
+def save_results(predictions, groundtruths, system_name, scene_name, save_folder, max_depth=np.inf):
+    from dvmvs.errors import compute_errors
+    if groundtruths is not None:
+        errors = np.array([compute_errors(groundtruths[i], p, max_depth) for i, p in enumerate(predictions)])
+        names = ["abs_error", "abs_relative_error", "abs_inverse_error", "squared_relative_error", "rmse", "ratio_125",
+                 "ratio_125_2", "ratio_125_3"]
+        print("Metrics of {} for scene {}:".format(system_name, scene_name))
+        print(", ".join("{:>25}".format(n) for n in names))
+        print(", ".join("{:25.4f}".format(v) for v in np.nanmean(errors, 0)))
+        np.savez_compressed(os.path.join(str(save_folder), system_name + "_errors_" + scene_name), errors)
+    save_predictions(predictions, system_name, scene_name, save_folder)
+
+
+def save_predictions(predictions, system_name, scene_name, save_folder):
+    np.savez_compressed(os.path.join(str(save_folder), system_name + "_predictions_" + scene_name), np.array(predictions))
+
+
+def visualize_predictions(*args, **kwargs):
+    raise NotImplementedError("interactive visualisation needs OpenCV, which is not part of this stack; "
+                              "set Config.test_visualize = False")
+
+
+class InferenceTimer:
+    """HIP-event timer around the per-frame forward; same statistics as the reference (first ``n_skip`` dropped)."""
+
+    def __init__(self, n_skip=20):
+        self.times = []
+        self.n_skip = n_skip
+        self.forward_pass_start = torch.cuda.Event(enable_timing=True)
+        self.forward_pass_end = torch.cuda.Event(enable_timing=True)
+
+    def record_start_time(self):
+        self.forward_pass_start.record()
+
+    def record_end_time_and_elapsed_time(self):
+        self.forward_pass_end.record()
+        torch.cuda.synchronize()
+        self.times.append(self.forward_pass_start.elapsed_time(self.forward_pass_end))
+
+    def statistics(self):
+        times = np.array(self.times[self.n_skip:])
+        if len(times) == 0:
+            return None
+        return {"n": len(times), "mean": float(times.mean()), "std": float(times.std()), "median": float(np.median(times)),
+                "min": float(times.min()), "max": float(times.max())}
+
+    def print_statistics(self):
+        stats = self.statistics()
+        if stats is None:
+            print("Not enough time measurements are taken!")
+            return
+        print("Number of Forward Passes:", stats["n"])
+        for label, key in (("Mean", "mean"), ("Std", "std"), ("Median", "median"), ("Min", "min"), ("Max", "max")):
+            print(f"--- {label} Inference Time:", stats[key])

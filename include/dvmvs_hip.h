@@ -1,0 +1,140 @@
+/*
+ * dvmvs_hip.h -- C ABI of the MI355X (gfx950) plane-sweep depth kernels.
+ *
+ * The reference (ardaduz/deep-video-mvs) has no FFI layer: its hot path is a set of Python functions over torch
+ * tensors.  This header is the boundary a maintainer binds instead (ctypes stub shown in
+ * INTEGRATION.md).  Each entry point names the reference interface it replaces.
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer to contiguous fp32 data unless the comment says "host array";
+ *   - tensors are NCHW, batch-major, exactly as the reference lays them out;
+ *   - the caller (PyTorch) allocates and owns every buffer including outputs and workspaces;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no entry point synchronises,
+ *     allocates, or keeps global state, so calls are re-entrant and capturable into a hipGraph;
+ *   - return value: 0 on success, a positive hipError_t on a HIP failure, a negative DVMVS_E* on a bad argument.
+ *     Nothing is enqueued when the return value is negative.
+ */
+#ifndef DVMVS_HIP_H
+#define DVMVS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVMVS_ABI_VERSION 1
+#define DVMVS_MAX_MEASUREMENTS 8      /* measurement frames fused per launch */
+#define DVMVS_MAX_DEPTH_LEVELS 256    /* sweep planes per launch */
+
+#define DVMVS_EINVAL (-1)             /* null pointer / non-positive dimension / out-of-range count */
+#define DVMVS_EUNSUPPORTED (-2)       /* shape outside what the kernels were built for */
+
+typedef void* dvmvs_stream_t;         /* hipStream_t */
+
+/* ABI / build identification. */
+int dvmvs_abi_version(void);
+const char* dvmvs_build_arch(void);   /* "gfx950" */
+const char* dvmvs_error_string(int code);
+
+/*
+ * Fused plane-sweep warp + feature correlation over all planes and all measurement frames, written once.
+ * Replaces dvmvs.utils.calculate_cost_volume_by_warping (M == 1) and dvmvs.utils.cost_volume_fusion (M >= 1):
+ *   /root/reference/dvmvs/utils.py:45-86 and :89-107.
+ *
+ *   image1      [B,C,H,W]   reference-frame features
+ *   image2s     host array of M device pointers, each [B,C,H,W] measurement-frame features
+ *   pose1       [B,4,4]     reference camera-to-world pose
+ *   pose2s      host array of M device pointers, each [B,4,4]
+ *   K           [B,3,3]     intrinsics at the feature resolution
+ *   cost_volume [B,D,H,W]   out; plane 0 = max_depth ... plane D-1 = min_depth, uniform in inverse depth
+ *   dot_product 1: sum_c(f1*warp(f2))/C   0: sum_c|f1-warp(f2)|  (utils.py:81-84); result is the mean over M
+ *   variant     0 = pick the fastest kernel for the shape; 1 = force the generic reference-order kernel;
+ *               2 = force the tap-reuse kernel (dot_product only)
+ * The 3x3 homography K R K^-1 and K t of utils.py:51-56 are evaluated on the device from the poses.
+ */
+int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, const float* pose1,
+                          const float* const* pose2s, const float* K, float* cost_volume,
+                          int B, int M, int C, int H, int W, int D,
+                          double min_depth, double max_depth, int dot_product, int variant,
+                          dvmvs_stream_t stream);
+
+/*
+ * Gradient of the fused cost volume (dot_product mode) w.r.t. both feature maps; poses/K carry no gradient
+ * (autograd through utils.py:75-82; the sampling grid is data).
+ *   grad_cost   [B,D,H,W]
+ *   grad_image1 [B,C,H,W]   out (overwritten)
+ *   grad_image2s host array of M device pointers, each [B,C,H,W]; MUST be zero-filled by the caller
+ *               (accumulated with atomics); an entry may be NULL to skip that frame's gradient.
+ */
+int dvmvs_cost_volume_bwd(const float* grad_cost, const float* image1, const float* const* image2s,
+                          const float* pose1, const float* const* pose2s, const float* K,
+                          float* grad_image1, float* const* grad_image2s,
+                          int B, int M, int C, int H, int W, int D,
+                          double min_depth, double max_depth, dvmvs_stream_t stream);
+
+/*
+ * Depth-conditioned inverse warp of the ConvLSTM hidden state.
+ * Replaces dvmvs.utils.warp_frame_depth (/root/reference/dvmvs/utils.py:205-258; normalize_points=False,
+ * bilinear) and, with zero_invalid != 0, the caller's mask h[depth <= 0.01] = 0 (dvmvs/convlstm.py:32-41).
+ *   image_src     [B,C,H,W]
+ *   depth_dst     [B,1,H,W]
+ *   src_trans_dst [B,4,4]
+ *   camera_matrix [B,3,3]
+ *   out           [B,C,H,W]
+ */
+int dvmvs_hidden_warp_fwd(const float* image_src, const float* depth_dst, const float* src_trans_dst,
+                          const float* camera_matrix, float* out, int B, int C, int H, int W,
+                          int zero_invalid, dvmvs_stream_t stream);
+
+/*
+ * Gradient of the hidden-state warp w.r.t. image_src.  As in the reference the validity mask is NOT applied to
+ * the gradient (convlstm.py:41 mutates .data outside autograd).  grad_src [B,C,H,W] MUST be zero-filled.
+ */
+int dvmvs_hidden_warp_bwd(const float* grad_out, const float* depth_dst, const float* src_trans_dst,
+                          const float* camera_matrix, float* grad_src, int B, int C, int H, int W,
+                          dvmvs_stream_t stream);
+
+/*
+ * out[b] = inverse(a[b]) * c[b] for 4x4 matrices (evaluated in fp64, rounded once to fp32).
+ * Replaces torch.bmm(torch.inverse(previous_pose), current_pose): dvmvs/convlstm.py:30, utils.py:51,:121.
+ */
+int dvmvs_relative_pose(const float* a, const float* c, float* out, int B, dvmvs_stream_t stream);
+
+/*
+ * ConvLSTM gate fusion given the 4*hidden-channel convolution output (split order i,f,o,g):
+ *   i,f,o = sigmoid; g = celu(LN_hw(cc_g)); c' = LN_hw(f*c + i*g); h' = o*celu(c').  LN: biased variance,
+ *   eps 1e-5, no affine; celu alpha = 1.
+ * Replaces /root/reference/dvmvs/convlstm.py:45-59.
+ *   combined_conv [B,4*hidden,H,W]   c_cur [B,hidden,H,W]   h_next, c_next [B,hidden,H,W] out
+ */
+int dvmvs_lstm_gates_fwd(const float* combined_conv, const float* c_cur, float* h_next, float* c_next,
+                         int B, int hidden, int H, int W, dvmvs_stream_t stream);
+
+/*
+ * Backward of the gate fusion: recomputes the gates from (combined_conv, c_cur).
+ *   grad_h, grad_c [B,hidden,H,W] (either may be NULL = zero)   grad_cc [B,4*hidden,H,W], grad_c_cur out
+ */
+int dvmvs_lstm_gates_bwd(const float* grad_h, const float* grad_c, const float* combined_conv,
+                         const float* c_cur, float* grad_cc, float* grad_c_cur,
+                         int B, int hidden, int H, int W, dvmvs_stream_t stream);
+
+/*
+ * Forward splat (z-buffer, farthest wins) of the previous full-resolution depth into the current view at half
+ * resolution; untouched pixels are 0.  No host round trip, order-independent (atomic max on the float bits).
+ * Replaces dvmvs.utils.get_non_differentiable_rectangle_depth_estimation (/root/reference/dvmvs/utils.py:110-154).
+ *   reference_pose, measurement_pose [B,4,4]   previous_depth [B,1,Hf,Wf]   full_K, half_K [B,3,3]
+ *   out [B,1,Hf/2,Wf/2]  (zeroed by this call)
+ * If out_lowres != NULL it also receives the nearest-neighbour down-sampling by `lowres_factor` that the call
+ * site applies next (fusionnet/run-testing.py:187-189): [B,1,(Hf/2)/f,(Wf/2)/f].
+ */
+int dvmvs_depth_reproject_fwd(const float* reference_pose, const float* measurement_pose,
+                              const float* previous_depth, const float* full_K, const float* half_K,
+                              float* out, float* out_lowres, int lowres_factor,
+                              int B, int full_height, int full_width, dvmvs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVMVS_HIP_H */

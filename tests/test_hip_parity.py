@@ -1,0 +1,354 @@
+"""GPU parity tests: every HIP op, called through the C ABI (ctypes -> libdvmvs_hip.so), against the CPU oracle on the
+same inputs and against the golden vectors produced by the reference.
+
+Tolerances (floating point, fp32 everywhere):
+* cost volume, dot mode: max |err| <= 2e-5 on values of mean magnitude ~0.06-0.09 (SURVEY: an independent float64
+  restatement is within 2.8e-5 of the reference); SAD mode 1e-4 on values ~1.3-7.
+* hidden warp / gates: 5e-6 / 2e-5 absolute on O(1) values.
+* depth re-projection: bit-exact except at round-to-nearest ties of the projected pixel (<= 0.1 % of pixels may move
+  by one pixel when the fp32 projection differs in the last ulp); measured: 0 mismatches.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dvmvs_oracle as orc
+import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(hip_device):
+    from dvmvs.hip import _capi
+    _capi.lib()  # the HIP library must be there: no fallback
+    return hip_device
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from dvmvs.hip import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def utils(dev):
+    from dvmvs import utils as u
+    return u
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def to(dev, *ts):
+    return [t.to(dev) for t in ts]
+
+
+def maxerr(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+def check_pins(t, z, prefix, atol):
+    t = t.detach().cpu()
+    assert list(t.shape) == list(z[f"{prefix}_shape"])
+    idx = syn.sample_indices(t.numel())
+    np.testing.assert_allclose(t.reshape(-1)[idx].numpy(), z[f"{prefix}_samples"], atol=atol, rtol=0)
+    scale = float(z[f"{prefix}_abs_sum"])
+    assert abs(t.double().sum().item() - float(z[f"{prefix}_sum"])) <= 2e-5 * scale
+
+
+VARIANTS = [0, 1, 2]
+
+
+def run_cv(ops, dev, f1, f2s, p1, p2s, K, lo, hi, D, dot, variant):
+    return ops.cost_volume(f1.to(dev), [t.to(dev) for t in f2s], p1.to(dev), [p.to(dev) for p in p2s], K.to(dev), lo, hi, D, dot, variant)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# cost volume
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_cost_volume_small_goldens(ops, dev, golden_dir, variant):
+    z = load(golden_dir, "cost_volume_small")
+    K = torch.from_numpy(z["K"])
+    feats = [syn.analytic_features(s, 8, 32, 40) for s in range(4)]
+    for tag, (r, ms) in json.loads(str(z["pose_sets"])).items():
+        for dot in (True, False):
+            if variant == 2 and not dot:
+                continue
+            got = run_cv(ops, dev, feats[0], [feats[1 + i] for i in range(len(ms))], syn.pose(r), [syn.pose(m) for m in ms], K,
+                         0.25, 20.0, 16, dot, variant)
+            exp = torch.from_numpy(z[f"{tag}_{'dot' if dot else 'sad'}"])
+            assert maxerr(got, exp) < (2e-5 if dot else 1e-4), (tag, dot)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_cost_volume_full_size_known_answers(ops, dev, golden_dir, variant):
+    """320x256 -> 160x128 features, 32 channels, 64 planes (BASELINE.json config): KAT-CV, behind-camera pair, noise."""
+    z = load(golden_dir, "cost_volume_full_pins")
+    halfK = syn.scaled_K(syn.full_K(), 2.0)
+    f = [syn.analytic_features(s) for s in range(3)]
+    cv = run_cv(ops, dev, f[0], [f[1], f[2]], syn.pose(9), [syn.pose(6), syn.pose(0)], halfK, 0.25, 20.0, 64, True, variant)
+    assert abs(cv.double().sum().item() - 78687.558811) < 1.0
+    assert abs(cv[0, 0, 64, 80].item() - 0.31054920) < 2e-5
+    assert abs(cv[0, 31, 10, 20].item() - 0.36512548) < 2e-5
+    assert abs(cv[0, 63, 127, 159].item() - 0.02026378) < 2e-5
+    check_pins(cv, z, "kat_cv", atol=2e-5)
+    exp = orc.cost_volume_fusion(f[0], [f[1], f[2]], syn.pose(9), [syn.pose(6), syn.pose(0)], halfK, 0.25, 20.0, 64, True)
+    d = (cv.cpu() - exp).abs()
+    assert d.max().item() < 2e-5 and d.mean().item() < 1e-6
+    back = run_cv(ops, dev, f[0], [f[1]], syn.pose(141), [syn.pose(135)], halfK, 0.25, 20.0, 64, True, variant)
+    check_pins(back, z, "behind", atol=2e-5)
+    nf = [syn.smooth_noise((1, 32, 128, 160), seed=40 + i) for i in range(3)]
+    ncv = run_cv(ops, dev, nf[0], [nf[1], nf[2]], syn.pose(13), [syn.pose(12), syn.pose(9)], halfK, 0.25, 20.0, 64, True, variant)
+    check_pins(ncv, z, "noise", atol=2e-5)
+
+
+def test_cost_volume_sad_known_answer(ops, dev, golden_dir):
+    """The baselines' mode: RGB (C=3), SAD, 0.5-50 m (KAT-SAD)."""
+    z = load(golden_dir, "cost_volume_full_pins")
+    halfK = syn.scaled_K(syn.full_K(), 2.0)
+    f = [syn.analytic_features(s)[:, :3].contiguous() for s in range(2)]
+    sad = run_cv(ops, dev, f[0], [f[1]], syn.pose(9), [syn.pose(6)], halfK, 0.5, 50.0, 64, False, 0)
+    assert abs(sad.double().sum().item() - 1749443.403785) < 20.0
+    assert abs(sad[0, 5, 64, 80].item() - 2.28013682) < 1e-4
+    check_pins(sad, z, "kat_sad", atol=1e-4)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("shape", [(2, 5, 33, 47, 10, 3), (3, 32, 16, 24, 64, 1), (1, 1, 7, 5, 3, 2), (2, 32, 64, 80, 64, 2)])
+def test_cost_volume_ragged_shapes_and_batches(ops, dev, shape, variant):
+    """Sizes that are not multiples of the workgroup tile, odd channel counts, per-batch poses/intrinsics."""
+    B, C, H, W, D, M = shape
+    g = torch.Generator().manual_seed(B * 1000 + C * 100 + H)
+    f1 = torch.randn(B, C, H, W, generator=g)
+    f2s = [torch.randn(B, C, H, W, generator=g) for _ in range(M)]
+    pose_ids = [9, 10, 13, 16, 20, 141]
+    p1 = torch.cat([syn.pose(pose_ids[b % 6]) for b in range(B)])
+    p2s = [torch.cat([syn.pose(pose_ids[(b + 1 + m) % 6] - 3) for b in range(B)]) for m in range(M)]
+    K = torch.cat([syn.scaled_K(syn.full_K(), 320.0 / W) * torch.tensor([1.0 + 0.01 * b]) for b in range(B)])
+    K[:, 2, 2] = 1.0
+    for dot in (True, False):
+        if variant == 2 and not dot:
+            continue
+        got = run_cv(ops, dev, f1, f2s, p1, p2s, K, 0.25, 20.0, D, dot, variant)
+        exp = orc.cost_volume_fusion(f1, f2s, p1, p2s, K, 0.25, 20.0, D, dot)
+        assert maxerr(got, exp) < (5e-5 if dot else 2e-4) * max(1.0, exp.abs().max().item()), (shape, dot)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_cost_volume_properties_full_size(ops, dev, variant):
+    """Size-independent properties at the BASELINE.json size: linearity in the reference features (dot mode),
+    fusion == mean of the single-frame volumes, identity pose == plain per-pixel correlation at the rescaled grid."""
+    halfK = syn.scaled_K(syn.full_K(), 2.0)
+    f = [syn.smooth_noise((1, 32, 128, 160), seed=90 + i) for i in range(4)]
+    args = dict(lo=0.25, hi=20.0, D=64, dot=True, variant=variant)
+    cv_a = run_cv(ops, dev, f[0], [f[2]], syn.pose(10), [syn.pose(9)], halfK, **args)
+    cv_b = run_cv(ops, dev, f[1], [f[2]], syn.pose(10), [syn.pose(9)], halfK, **args)
+    cv_ab = run_cv(ops, dev, 0.5 * f[0] - 2.0 * f[1], [f[2]], syn.pose(10), [syn.pose(9)], halfK, **args)
+    assert maxerr(cv_ab, 0.5 * cv_a - 2.0 * cv_b) < 2e-5
+    cv_c = run_cv(ops, dev, f[0], [f[3]], syn.pose(10), [syn.pose(6)], halfK, **args)
+    fused = run_cv(ops, dev, f[0], [f[2], f[3]], syn.pose(10), [syn.pose(9), syn.pose(6)], halfK, **args)
+    assert maxerr(fused, (cv_a + cv_c) / 2) < 1e-6
+    # identical poses: every plane samples at u*(W-1)/W, v*(H-1)/H, independent of depth
+    same = run_cv(ops, dev, f[0], [f[2]], syn.pose(10), [syn.pose(10)], halfK, **args)
+    assert maxerr(same[:, 0], same[:, 63]) < 2e-5
+    ys, xs = torch.meshgrid(torch.arange(128.0), torch.arange(160.0), indexing="ij")
+    warped = orc.bilinear_zeros_gather(f[2], (xs * 159 / 160).reshape(1, -1), (ys * 127 / 128).reshape(1, -1)).reshape(1, 32, 128, 160)
+    assert maxerr(same[:, 17], (f[0] * warped).sum(1) / 32) < 2e-5
+
+
+def test_cost_volume_surface_and_errors(utils, dev):
+    halfK = syn.scaled_K(syn.full_K(), 2.0)
+    f = [syn.analytic_features(s, 8, 32, 40) for s in range(2)]
+    K = syn.scaled_K(halfK, 4.0)
+    grid = utils.get_warp_grid_for_cost_volume_calculation(40, 32, dev)
+    assert tuple(grid.shape) == (3, 32 * 40) and grid[0, 41].item() == 1.0 and grid[1, 41].item() == 1.0
+    one = utils.calculate_cost_volume_by_warping(f[0].to(dev), f[1].to(dev), syn.pose(9).to(dev), syn.pose(6).to(dev), K.to(dev), grid,
+                                                 0.25, 20.0, 16, dev, True)
+    fused = utils.cost_volume_fusion(f[0].to(dev), [f[1].to(dev)], syn.pose(9).to(dev), [syn.pose(6).to(dev)], K.to(dev), grid,
+                                     0.25, 20.0, 16, dev, True)
+    assert torch.equal(one, fused) and tuple(one.shape) == (1, 16, 32, 40)
+    with pytest.raises(RuntimeError):  # CPU tensors: no fallback
+        utils.cost_volume_fusion(f[0], [f[1]], syn.pose(9), [syn.pose(6)], K, None, 0.25, 20.0, 16, "cpu", True)
+    with pytest.raises(ValueError):
+        utils.cost_volume_fusion(f[0].to(dev), [f[1].to(dev)], syn.pose(9).to(dev), [syn.pose(6).to(dev)], K.to(dev),
+                                 grid[:, :100], 0.25, 20.0, 16, dev, True)
+
+
+def test_cost_volume_gradients(ops, dev, golden_dir):
+    """Autograd through the custom op (dvmvs_cost_volume_bwd) vs the reference's autograd (golden) and the oracle's."""
+    z = load(golden_dir, "cost_volume_small_grad")
+    K = torch.from_numpy(load(golden_dir, "cost_volume_small")["K"])
+    sf = [syn.analytic_features(s, 8, 32, 40) for s in range(3)]
+    f1 = sf[0].to(dev).requires_grad_(True)
+    f2 = [sf[1].to(dev).requires_grad_(True), sf[2].to(dev).requires_grad_(True)]
+    out = ops.cost_volume(f1, f2, syn.pose(12).to(dev), [syn.pose(9).to(dev), syn.pose(3).to(dev)], K.to(dev), 0.25, 20.0, 16, True, 0)
+    out.backward(torch.from_numpy(z["grad_out"]).to(dev))
+    assert maxerr(f1.grad, torch.from_numpy(z["grad_image1"])) < 2e-5
+    assert maxerr(f2[0].grad, torch.from_numpy(z["grad_image2_0"])) < 2e-5
+    assert maxerr(f2[1].grad, torch.from_numpy(z["grad_image2_1"])) < 2e-5
+    # a second geometry (behind-camera pair, B=2) against the oracle's autograd
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(2, 6, 20, 28, generator=g)
+    b = torch.randn(2, 6, 20, 28, generator=g)
+    p1, p2 = torch.cat([syn.pose(141), syn.pose(10)]), torch.cat([syn.pose(135), syn.pose(9)])
+    K2 = torch.cat([syn.scaled_K(syn.full_K(), 320.0 / 28)] * 2)
+    go = torch.randn(2, 12, 20, 28, generator=g)
+    ac, bc = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    orc.cost_volume_fusion(ac, [bc], p1, [p2], K2, 0.25, 20.0, 12, True).backward(go)
+    ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    ops.cost_volume(ad, [bd], p1.to(dev), [p2.to(dev)], K2.to(dev), 0.25, 20.0, 12, True, 0).backward(go.to(dev))
+    assert maxerr(ad.grad, ac.grad) < 5e-5 and maxerr(bd.grad, bc.grad) < 5e-5
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# depth re-projection
+# ----------------------------------------------------------------------------------------------------------------------
+def test_depth_reprojection(ops, utils, dev, golden_dir):
+    z = load(golden_dir, "reproject")
+    fullK = syn.full_K()
+    halfK = syn.scaled_K(fullK, 2.0)
+    prev = syn.analytic_depth()
+    out = utils.get_non_differentiable_rectangle_depth_estimation(*to(dev, syn.pose(10), syn.pose(9), prev, fullK, halfK), 320, 256)
+    assert tuple(out.shape) == (1, 1, 128, 160)
+    got, exp = out.cpu().numpy(), z["kat"]
+    mism = int((got != exp).sum())
+    assert mism <= 20, f"{mism} pixels differ from the reference splat"   # round-to-nearest ties only
+    assert abs(float(got.astype(np.float64).sum()) - 30690.716363) < 5.0
+    if mism == 0:
+        assert int((got != 0).sum()) == 20307 and abs(got[0, 0, 64, 80] - 1.03667092) < 1e-6
+    full, low = ops.depth_reproject_lowres(*to(dev, syn.pose(10), syn.pose(9), prev, fullK, halfK), 16)
+    assert torch.equal(full, out) and torch.equal(low, out[..., ::16, ::16])
+    assert int((low.cpu().numpy() != z["kat_low"]).sum()) <= 1
+    # harder case: zeros in the source depth, a far wall, larger motion; and a batch of two different problems
+    prev2 = prev.clone()
+    prev2[:, :, 40:90, 100:180] = 0.0
+    prev2[:, :, 150:, :] = 6.0
+    out2 = ops.depth_reproject(*to(dev, torch.cat([syn.pose(16), syn.pose(10)]), torch.cat([syn.pose(9), syn.pose(9)]),
+                                   torch.cat([prev2, prev]), torch.cat([fullK, fullK]), torch.cat([halfK, halfK])))
+    assert int((out2[0, 0].cpu().numpy() != z["hard"][0, 0]).sum()) <= 20
+    assert torch.equal(out2[1], out[0])
+    # order independence: the atomic z-buffer is deterministic
+    again = ops.depth_reproject(*to(dev, syn.pose(10), syn.pose(9), prev, fullK, halfK))
+    assert torch.equal(again, out)
+
+
+def test_relative_pose(ops, dev):
+    a = torch.cat([syn.pose(i) for i in (9, 40, 141, 200)])
+    c = torch.cat([syn.pose(i) for i in (10, 9, 135, 3)])
+    got = ops.relative_pose(a.to(dev), c.to(dev)).cpu()
+    exp = (torch.linalg.inv(a.double()) @ c.double())
+    assert (got.double() - exp).abs().max().item() < 1e-6
+    assert torch.equal(got[:, 3], torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(4, 4))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# hidden-state warp
+# ----------------------------------------------------------------------------------------------------------------------
+def test_hidden_warp_goldens(ops, utils, dev, golden_dir):
+    z = load(golden_dir, "hidden_warp")
+    lK = syn.scaled_K(syn.full_K(), 32.0)
+    _, _, h0, _ = syn.analytic_lstm_inputs()
+    t = lambda k: torch.from_numpy(z[k])
+    got = utils.warp_frame_depth(*to(dev, h0, t("depth"), t("T"), lK))
+    assert maxerr(got, t("warped")) < 5e-6
+    got = ops.hidden_warp(*to(dev, h0, t("depth_masked"), t("T"), lK), True)
+    assert maxerr(got, t("warped_masked")) < 5e-6
+    assert float(got[0, :, 2:5, 3:7].abs().max()) == 0.0
+    got = utils.warp_frame_depth(*to(dev, h0, t("depth"), t("T_far"), lK))
+    assert maxerr(got, t("warped_far")) < 5e-6
+    with pytest.raises(ValueError):
+        utils.warp_frame_depth(*to(dev, h0[0], t("depth"), t("T"), lK))
+    with pytest.raises(TypeError):
+        utils.warp_frame_depth(h0.numpy(), t("depth"), t("T"), lK)
+
+
+def test_hidden_warp_other_shapes(ops, dev):
+    g = torch.Generator().manual_seed(11)
+    for (B, C, H, W) in ((2, 7, 8, 8), (1, 512, 15, 20), (3, 1, 5, 9)):
+        src = torch.randn(B, C, H, W, generator=g)
+        depth = torch.rand(B, 1, H, W, generator=g) * 3.0
+        depth[:, :, 0, :] = 0.0
+        T = torch.linalg.inv(torch.cat([syn.pose(9 + b) for b in range(B)])) @ torch.cat([syn.pose(10 + 2 * b) for b in range(B)])
+        K = torch.cat([syn.scaled_K(syn.full_K(), 320.0 / W)] * B)
+        for mask in (False, True):
+            got = ops.hidden_warp(*to(dev, src, depth, T, K), mask)
+            assert maxerr(got, orc.warp_hidden_state(src, depth, T, K, zero_invalid=mask)) < 2e-5
+
+
+def test_hidden_warp_gradient_is_not_masked(ops, dev, golden_dir):
+    z = load(golden_dir, "lstm_grads")
+    hw = load(golden_dir, "hidden_warp")
+    lK = syn.scaled_K(syn.full_K(), 32.0)
+    _, _, h0, _ = syn.analytic_lstm_inputs()
+    src = h0[:, :64].to(dev).requires_grad_(True)
+    out = ops.hidden_warp(src, torch.from_numpy(hw["depth_masked"]).to(dev), torch.from_numpy(hw["T"]).to(dev), lK.to(dev), True)
+    out.backward(torch.from_numpy(z["warp_grad_out"]).to(dev))
+    assert maxerr(src.grad, torch.from_numpy(z["warp_grad_src"])) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ConvLSTM
+# ----------------------------------------------------------------------------------------------------------------------
+def analytic_cc():
+    o = np.arange(2048, dtype=np.float64).reshape(-1, 1, 1)
+    yy = np.arange(8, dtype=np.float64).reshape(1, -1, 1)
+    xx = np.arange(10, dtype=np.float64).reshape(1, 1, -1)
+    return torch.from_numpy((2.0 * np.sin(0.013 * o + 0.7 * yy + 0.3 * xx) + 0.5 * np.cos(0.05 * o * xx)).astype(np.float32)).unsqueeze(0)
+
+
+def test_lstm_gates_goldens(ops, dev, golden_dir):
+    z = load(golden_dir, "lstm_gates")
+    _, _, _, c0 = syn.analytic_lstm_inputs()
+    h, c = ops.lstm_gates(analytic_cc().to(dev), c0.to(dev))
+    assert maxerr(h, torch.from_numpy(z["h_next"])) < 1e-5 and maxerr(c, torch.from_numpy(z["c_next"])) < 1e-5
+    # LayerNorm property: every (b, channel) plane of c' has mean 0 and biased variance 1 (up to eps)
+    assert c.mean(dim=(-2, -1)).abs().max().item() < 1e-5
+    assert (c.var(dim=(-2, -1), unbiased=False) - 1).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("shape", [(4, 512, 8, 8), (1, 512, 8, 10), (2, 24, 15, 20), (1, 8, 3, 5), (2, 16, 20, 30), (1, 4, 32, 32)])
+def test_lstm_gates_shapes(ops, dev, shape):
+    B, hid, H, W = shape
+    g = torch.Generator().manual_seed(H * W + hid)
+    cc = torch.randn(B, 4 * hid, H, W, generator=g) * 1.5
+    c = torch.randn(B, hid, H, W, generator=g)
+    h, cn = ops.lstm_gates(cc.to(dev), c.to(dev))
+    eh, ec = orc.lstm_gates(cc, c)
+    assert maxerr(h, eh) < 2e-5 and maxerr(cn, ec) < 2e-5
+
+
+def test_lstm_gates_gradients(ops, dev, golden_dir):
+    z = load(golden_dir, "lstm_grads")
+    cc = torch.from_numpy(z["cc"]).to(dev).requires_grad_(True)
+    c = torch.from_numpy(z["c"]).to(dev).requires_grad_(True)
+    h, cn = ops.lstm_gates(cc, c)
+    ((h * torch.from_numpy(z["grad_h"]).to(dev)).sum() + (cn * torch.from_numpy(z["grad_c"]).to(dev)).sum()).backward()
+    assert maxerr(cc.grad, torch.from_numpy(z["grad_cc"])) < 2e-5
+    assert maxerr(c.grad, torch.from_numpy(z["grad_c_cur"])) < 2e-5
+
+
+def test_convlstm_cell_known_answer(dev, golden_dir):
+    """KAT-LSTM: the module (pose op + warp/mask kernel + MIOpen conv + gate kernel) against the reference cell."""
+    from dvmvs.convlstm import MVSLayernormConvLSTMCell
+    z = load(golden_dir, "lstm_gates")
+    weight, x, h0, c0 = syn.analytic_lstm_inputs()
+    lK = syn.scaled_K(syn.full_K(), 32.0)
+    de16 = torch.from_numpy(load(golden_dir, "reproject")["kat_low"])
+    cell = MVSLayernormConvLSTMCell(512, 512, (3, 3), torch.celu).to(dev)
+    assert list(cell.state_dict().keys()) == ["conv.weight"]
+    with torch.no_grad():
+        cell.conv.weight.copy_(weight.to(dev))
+        hn, cn = cell(*to(dev, x), to(dev, h0, c0), *to(dev, syn.pose(9), syn.pose(10), de16, lK))
+        # K = 9216 fp32 reduction inside the conv: summation order differs between MIOpen and the CPU reference
+        assert maxerr(hn, torch.from_numpy(z["kat_h"])) < 2e-4 and maxerr(cn, torch.from_numpy(z["kat_c"])) < 2e-4
+        assert abs(hn.double().abs().sum().item() - 14085.416424) < 0.5
+        # first step of a sequence: no previous pose -> no warp
+        h1, c1 = cell(*to(dev, x), list(cell.init_hidden(1, (8, 10))), None, syn.pose(9).to(dev), de16.to(dev), lK.to(dev))
+        eh, ec = orc.convlstm_cell(weight, x, torch.zeros_like(h0), torch.zeros_like(c0), None, syn.pose(9), de16, lK)
+        assert maxerr(h1, eh) < 2e-4 and maxerr(c1, ec) < 2e-4
