@@ -1,0 +1,265 @@
+"""Headline benchmark: fusionnet depth frames/sec at 320x256, 64 planes, on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 200 --warmup 30
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one keyframe of one synthetic posed sequence through the timed region of the reference's
+fusionnet/run-testing.py:151-204 (features -> cost volume -> encoder -> re-projection -> ConvLSTM -> decoder), inputs
+already resident in HBM.  N > 1: one independent sequence per rank (weak scaling), no collective on the data path; the
+barrier + max-over-ranks timing is the only communication.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+* ``roofline``     -- the fused warp + cost-volume kernel: algorithmic bytes per launch / its average duration, measured
+                      here with HIP events around a back-to-back hipGraph of launches on the launch stream;
+* ``cpu_baseline`` -- the CPU oracle pipeline (oracle/fusionnet_cpu.py, "port" of the reference loop) timed on this
+                      box's host cores on a bounded sample of the same sequence (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "deep-video-mvs_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--measurement-frames", type=int, default=2)
+    ap.add_argument("--no-graphs", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-fold-bn", action="store_true")
+    ap.add_argument("--no-feature-cache", action="store_true", help="recompute measurement features every frame like the reference")
+    ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--kernel-reps", type=int, default=50)
+    ap.add_argument("--stage-times", action="store_true", help="also print eager per-stage GPU times to stderr")
+    return ap.parse_args()
+
+
+def build_modules():
+    import synthetic as syn
+    from dvmvs.fusionnet.model import CostVolumeDecoder, CostVolumeEncoder, FeatureExtractor, FeatureShrinker, LSTMFusion
+    return syn.build_e2e_modules((FeatureExtractor, FeatureShrinker, CostVolumeEncoder, LSTMFusion, CostVolumeDecoder))
+
+
+def synthetic_sequence(seq_id, n_images, n_poses):
+    """Images ~ low-passed N(0,1) (already "normalised"), smooth trajectory with ~0.12 m keyframe baseline."""
+    import synthetic as syn
+    images = [syn.smooth_noise((1, 3, 256, 320), seed=1000 * (seq_id + 1) + i) for i in range(n_images)]
+    poses = torch.from_numpy(syn.synthetic_trajectory(n_poses, seed=1000 + seq_id)).float()
+    return images, poses, syn.full_K()
+
+
+def measure_cost_volume_kernel(engine, n_meas, reps):
+    """Average duration of one fused cost-volume launch: a hipGraph of ``reps`` back-to-back launches (no host gaps),
+    timed with HIP events on the stream it is replayed on."""
+    from dvmvs.hip import _capi
+    s = engine._static
+    ref = s["ref_half"]
+    B, C, H, W = ref.shape
+    D = engine.n_depth_levels
+    out = torch.empty(B, D, H, W, device=ref.device)
+    img_ptrs = _capi.pointer_array([t.data_ptr() for t in s["meas_feat"][:n_meas]])
+    pose_ptrs = _capi.pointer_array([t.data_ptr() for t in s["meas_pose"][:n_meas]])
+    lib = _capi.lib()
+    from dvmvs import utils
+    ws_bytes = lib.dvmvs_cost_volume_workspace_bytes(B, n_meas)
+    workspace = torch.empty((ws_bytes + 3) // 4, device=ref.device)
+
+    def launch():
+        rc = lib.dvmvs_cost_volume_fwd(ref.data_ptr(), img_ptrs, s["pose"].data_ptr(), pose_ptrs, s["half_K"].data_ptr(), out.data_ptr(),
+                                       B, n_meas, C, H, W, D, engine.min_depth, engine.max_depth, 1, utils.COST_VOLUME_VARIANT,
+                                       workspace.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
+        _capi.check(rc, "dvmvs_cost_volume_fwd")
+
+    launch()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            launch()
+    graph.replay()
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    rounds = 5
+    start.record()
+    for _ in range(rounds):
+        graph.replay()
+    end.record()
+    torch.cuda.synchronize()
+    seconds = start.elapsed_time(end) * 1e-3 / (rounds * reps)
+    algorithmic_bytes = (1 + n_meas) * B * C * H * W * 4 + B * D * H * W * 4
+    return seconds, algorithmic_bytes
+
+
+def usable_cores():
+    """Host cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (os.cpu_count() alone
+    reports the whole socket inside a quota-limited container, and oversubscribing it makes oneDNN/OpenMP crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                quota = float(txt[0])
+                period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_baseline(args, modules, n_meas):
+    from fusionnet_cpu import CpuDepthPipeline
+    cores = min(usable_cores(), 64)      # batch-1 convolutions of this size stop scaling long before 64 threads
+    torch.set_num_threads(cores)
+    images, poses, full_K = synthetic_sequence(0, 8, 64)
+    pipe = CpuDepthPipeline(*modules)
+    frames, t_total = 0, 0.0
+    k = n_meas
+    # one untimed frame (thread pools, oneDNN primitive caches), then a bounded timed sample
+    t0 = time.perf_counter()
+    pipe.step(images[k % 8], poses[k:k + 1], [images[(k - 1 - i) % 8] for i in range(n_meas)],
+              [poses[k - 1 - i:k - i] for i in range(n_meas)], full_K)
+    first = time.perf_counter() - t0
+    if first > args.cpu_baseline_seconds:      # pathologically slow host: report the one frame we have and stop
+        frames, t_total = 1, first
+    else:
+        pipe.stage_seconds.clear()
+    while t_total < args.cpu_baseline_seconds and frames < 24:
+        k += 1
+        t0 = time.perf_counter()
+        pipe.step(images[k % 8], poses[k:k + 1], [images[(k - 1 - i) % 8] for i in range(n_meas)],
+                  [poses[k - 1 - i:k - i] for i in range(n_meas)], full_K)
+        t_total += time.perf_counter() - t0
+        frames += 1
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": frames / t_total, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} keyframes of the same synthetic fusionnet sequence (320x256, 64 planes, M={n_meas}) on {cpu_model}; "
+                      f"oracle/fusionnet_cpu.py with torch CPU kernels, {cores} threads",
+            "stage_ms": {k2: round(1e3 * v / frames, 2) for k2, v in pipe.stage_seconds.items()}}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the plane-sweep path has no CPU fallback")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from dvmvs.engine import DepthEngine
+    torch.backends.cudnn.benchmark = True   # MIOpen solver search during the warm-up frames
+    modules = build_modules()
+    engine = DepthEngine(*modules, device=device, fold_bn=not args.no_fold_bn, cache_features=not args.no_feature_cache,
+                         use_graphs=not args.no_graphs, channels_last=args.channels_last)
+    M = args.measurement_frames
+    n_images = 32
+    total = args.warmup + args.steps
+    images, poses, full_K = synthetic_sequence(rank, n_images, total + M + 1)   # one independent sequence per rank
+    images = [im.to(device) for im in images]
+    poses = poses.to(device)
+    full_K = full_K.to(device)
+
+    def run_frame(k):
+        ids = [k - 1 - i for i in range(M)]
+        meas_images = None if not args.no_feature_cache else [images[i % n_images] for i in ids]
+        return engine.step(images[k % n_images], poses[k:k + 1], meas_images, [poses[i:i + 1] for i in ids], full_K,
+                           frame_id=k if not args.no_feature_cache else None, measurement_ids=ids if not args.no_feature_cache else None)
+
+    with torch.no_grad():
+        # buffer fill: the first M keyframes only contribute features (reference: keyframe-buffer response 0 / short lists)
+        if not args.no_feature_cache:
+            for k in range(M):
+                engine._half_features(k, images[k % n_images])
+        k = M
+        for _ in range(args.warmup):
+            run_frame(k)
+            k += 1
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run_frame(k)
+            k += 1
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    depth_mean = float(engine._static["depth"].mean())
+    assert np.isfinite(depth_mean), "non-finite depth"
+
+    result = None
+    if rank == 0:
+        kernel_s, alg_bytes = measure_cost_volume_kernel(engine, M, args.kernel_reps)
+        achieved = alg_bytes / kernel_s / 1e9
+        result = {
+            "metric": "depth frames/sec/GPU @ 320x256x64 planes (fusionnet); rel-L1 vs ref",
+            "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "fusionnet inference, one synthetic posed sequence per GPU, 320x256, 64 planes, "
+                                   f"M={M} measurement frames, batch 1 (BASELINE.json configs[2]; configs[3] at N>1)",
+                       "sequences_per_gpu": 1, "hip_graphs": not args.no_graphs, "bn_folded": not args.no_fold_bn,
+                       "feature_cache": not args.no_feature_cache, "weights": "seeded (tests/synthetic.py) + published FPN checkpoint",
+                       "parallelism": f"sequence-sharded x{world}, no data-path collective"},
+            "roofline": {"kernel": "cost_volume (fused warp + correlation, all planes, all measurement frames)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "kernel_us": kernel_s * 1e6, "algorithmic_bytes": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cpu_mods = build_modules()
+            result["cpu_baseline"] = cpu_baseline(args, cpu_mods, M)
+        else:
+            result["cpu_baseline"] = None
+        if args.stage_times:
+            print(f"[bench] final depth mean {depth_mean:.4f}", file=sys.stderr)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

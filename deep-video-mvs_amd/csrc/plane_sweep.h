@@ -15,7 +15,10 @@ struct CostVolumeArgs {
   float* out;
   int B, M, C, H, W, D;
   double inv_depth_base, inv_depth_step;
+  const float* setup;  // optional [B][M][12]: Hm (9) + kt (3) written by sweep_setup_kernel; nullptr = derive per workgroup
 };
+
+constexpr int kSetupFloats = 12;
 
 // Per-(batch, measurement) sweep constants, evaluated once per workgroup into LDS.
 //   Hm = K R K^-1 (row-major 3x3), kt = K t   with [R|t] = inverse(pose2) * pose1     (utils.py:51-56)
@@ -47,7 +50,16 @@ __device__ inline float plane_depth(double inv_base, double inv_step, int d) {
 // Fills s_H[M][9], s_kt[M][3] and s_ktd[M][planes][3] (= kt / depth_d for d in [d_begin, d_begin+planes)).
 __device__ inline void sweep_setup(const CostVolumeArgs& a, int b, int d_begin, int planes, int tid, int nthreads,
                                    float* s_H, float* s_kt, float* s_ktd) {
-  if (tid < a.M) sweep_matrices(a.pose1 + b * 16, a.pose2[tid] + b * 16, a.K + b * 9, s_H + tid * 9, s_kt + tid * 3);
+  if (a.setup != nullptr) {
+    for (int i = tid; i < a.M * kSetupFloats; i += nthreads) {
+      const float v = a.setup[static_cast<size_t>(b) * a.M * kSetupFloats + i];
+      const int m = i / kSetupFloats, k = i - m * kSetupFloats;
+      if (k < 9) s_H[m * 9 + k] = v;
+      else s_kt[m * 3 + (k - 9)] = v;
+    }
+  } else if (tid < a.M) {
+    sweep_matrices(a.pose1 + b * 16, a.pose2[tid] + b * 16, a.K + b * 9, s_H + tid * 9, s_kt + tid * 3);
+  }
   __syncthreads();
   for (int i = tid; i < a.M * planes * 3; i += nthreads) {
     const int k = i % 3;
@@ -61,11 +73,13 @@ __device__ inline void sweep_setup(const CostVolumeArgs& a, int b, int d_begin, 
 
 // Sample position of reference pixel (x, y) on one plane of one measurement frame, in measurement-image pixels.
 // Op order follows utils.py:68-73 and ATen's align_corners un-normalisation.
-__device__ inline void sweep_position(const float* Hm, const float* ktd, float xf, float yf, int W, int H, float* ix, float* iy) {
+__device__ inline void sweep_position(const float* Hm, const float* ktd, float xf, float yf, int W, int H, float* ix, float* iy,
+                                      float* z_out = nullptr) {
   const float X = fmaf(Hm[2], 1.0f, fmaf(Hm[1], yf, Hm[0] * xf)) + ktd[0];
   const float Y = fmaf(Hm[5], 1.0f, fmaf(Hm[4], yf, Hm[3] * xf)) + ktd[1];
   const float Z = fmaf(Hm[8], 1.0f, fmaf(Hm[7], yf, Hm[6] * xf)) + ktd[2];
   const float denom = Z + 1e-8f;
+  if (z_out) *z_out = denom;
   const float u = X / denom;
   const float v = Y / denom;
   const float wn = static_cast<float>(W) * 0.5f;
@@ -96,6 +110,7 @@ inline int fill_sweep_args(CostVolumeArgs* a, const float* image1, const float* 
   // utils.py:59-60, python doubles
   a->inv_depth_base = 1.0 / max_depth;
   a->inv_depth_step = D > 1 ? (1.0 / min_depth - 1.0 / max_depth) / (D - 1) : 0.0;
+  a->setup = nullptr;
   return 0;
 }
 

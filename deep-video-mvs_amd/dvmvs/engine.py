@@ -1,0 +1,222 @@
+"""Per-keyframe forward orchestration for pairnet / fusionnet on one MI355X.
+
+The reference keeps this logic inside its scripts (/root/reference/dvmvs/fusionnet/run-testing.py:151-204,
+pairnet/run-testing.py:136-166); here it is a small class so that the same frame contract can be driven by the
+test runner, the benchmark and the sequence-sharded multi-GPU runner:
+
+    features(measurement frames) , features(reference) -> fused plane-sweep cost volume (HIP) -> encoder
+      -> [fusionnet] previous depth splatted into the current view (HIP) -> ConvLSTM (HIP warp + MIOpen conv + HIP gates)
+      -> decoder -> depth;   state = (h, c), previous depth, previous pose;   "TRACKING LOST" -> reset()
+
+MI355X-specific execution choices (none of them changes results beyond fp32 round-off):
+* **feature cache** -- a keyframe's half-resolution features are computed once and reused when the frame later
+  serves as a measurement frame (the reference recomputes them, run-testing.py:153-156); eval-mode only;
+* **BatchNorm folding** -- conv + eval-mode BN are folded into one biased convolution before inference;
+* **hipGraph replay** -- after a warm-up frame (MIOpen solver search) the whole frame is captured once per
+  (number of measurement frames, has-previous-state) and replayed; the HIP ops are capture-safe (no host sync,
+  no allocation inside the C ABI), poses / intrinsics / images live in static device buffers.
+"""
+import copy
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from dvmvs.config import Config
+from dvmvs.hip import ops as _ops
+from dvmvs import utils as _utils
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BatchNorm folding
+# ----------------------------------------------------------------------------------------------------------------------
+def _fold_pair(conv, bn):
+    w = conv.weight
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    folded = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, stride=conv.stride, padding=conv.padding,
+                       dilation=conv.dilation, groups=conv.groups, bias=True).to(w.device)
+    with torch.no_grad():
+        folded.weight.copy_(w * scale.reshape(-1, 1, 1, 1))
+        bias = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+        folded.bias.copy_((bias - bn.running_mean) * scale + bn.bias)
+    return folded
+
+
+def fold_batchnorm(module):
+    """Returns a deep copy of ``module`` (eval mode) in which every Conv2d directly followed by a BatchNorm2d inside
+    an ``nn.Sequential`` is replaced by one biased convolution."""
+    module = copy.deepcopy(module).eval()
+    for parent in module.modules():
+        if not isinstance(parent, nn.Sequential):
+            continue
+        names = list(parent._modules.keys())
+        for a, b in zip(names, names[1:]):
+            conv, bn = parent._modules[a], parent._modules[b]
+            if isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d):
+                parent._modules[a] = _fold_pair(conv, bn)
+                parent._modules[b] = nn.Identity()
+    return module
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# frame engine
+# ----------------------------------------------------------------------------------------------------------------------
+class DepthEngine:
+    """Sequential keyframe processor for ONE video sequence (batch 1), pairnet (``lstm_fusion=None``) or fusionnet.
+
+    ``step`` mirrors one iteration of the reference loop; ``reset`` is the "TRACKING LOST" rule.
+    """
+
+    def __init__(self, feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder,
+                 device="cuda", min_depth=0.25, max_depth=20.0, n_depth_levels=64, fold_bn=True, cache_features=True,
+                 use_graphs=True, cache_size=None, channels_last=False):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DepthEngine runs on an MI355X; there is no CPU execution path in this package")
+        prep = (lambda m: fold_batchnorm(m)) if fold_bn else (lambda m: copy.deepcopy(m).eval())
+        mods = [feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder]
+        mods = [None if m is None else prep(m).to(self.device) for m in mods]
+        if channels_last:
+            mods = [None if m is None else m.to(memory_format=torch.channels_last) for m in mods]
+        self.fe, self.fs, self.enc, self.lstm, self.dec = mods
+        self.channels_last = channels_last
+        self.min_depth, self.max_depth, self.n_depth_levels = float(min_depth), float(max_depth), int(n_depth_levels)
+        self.cache_features = cache_features
+        self.cache_size = cache_size or (Config.test_keyframe_buffer_size + 2)
+        self.use_graphs = use_graphs
+        self.height, self.width = Config.test_image_height, Config.test_image_width
+        self._feature_cache = OrderedDict()
+        self._graphs = {}
+        self._static = None
+        self._warm = set()
+        self.reset()
+
+    # ---- state ------------------------------------------------------------------------------------------------------
+    @property
+    def is_fusionnet(self):
+        return self.lstm is not None
+
+    def reset(self):
+        """Forget the recurrent state and the previous depth/pose (reference: "TRACKING LOST", run-testing.py:97-101)."""
+        self.has_previous = False
+        if self._static is not None:
+            for k in ("h", "c", "prev_depth"):
+                self._static[k].zero_()
+
+    def clear_feature_cache(self):
+        self._feature_cache.clear()
+
+    # ---- pieces -----------------------------------------------------------------------------------------------------
+    def _features(self, image):
+        if self.channels_last:
+            image = image.contiguous(memory_format=torch.channels_last)
+        return self.fs(*self.fe(image))
+
+    def _half_features(self, frame_id, image):
+        if self.cache_features and frame_id is not None and frame_id in self._feature_cache:
+            self._feature_cache.move_to_end(frame_id)
+            return self._feature_cache[frame_id]
+        half = self._features(image)[0].contiguous()
+        self._remember(frame_id, half)
+        return half
+
+    def _remember(self, frame_id, half):
+        if self.cache_features and frame_id is not None:
+            self._feature_cache[frame_id] = half
+            while len(self._feature_cache) > self.cache_size:
+                self._feature_cache.popitem(last=False)
+
+    def _allocate_static(self, n_meas):
+        d, H, W = self.device, self.height, self.width
+        z = lambda *s: torch.zeros(*s, device=d, dtype=torch.float32)
+        if self._static is None:
+            self._static = dict(image=z(1, 3, H, W), pose=z(1, 4, 4), full_K=z(1, 3, 3), half_K=z(1, 3, 3), lstm_K=z(1, 3, 3),
+                                prev_pose=z(1, 4, 4), prev_depth=z(1, 1, H, W), h=z(1, 512, H // 32, W // 32),
+                                c=z(1, 512, H // 32, W // 32), meas_feat=[], meas_pose=[],
+                                ref_half=z(1, 32, H // 2, W // 2), depth=z(1, H, W))
+        while len(self._static["meas_feat"]) < n_meas:
+            self._static["meas_feat"].append(z(1, 32, H // 2, W // 2))
+            self._static["meas_pose"].append(z(1, 4, 4))
+
+    def _frame_body(self, n_meas, has_previous):
+        """The per-frame computation on the static buffers (this is what gets captured into a hipGraph)."""
+        s = self._static
+        feats = self._features(s["image"])
+        ref_half = feats[0].contiguous()
+        s["ref_half"].copy_(ref_half)
+        cost_volume = _ops.cost_volume(ref_half, s["meas_feat"][:n_meas], s["pose"], s["meas_pose"][:n_meas], s["half_K"],
+                                       self.min_depth, self.max_depth, self.n_depth_levels, True, _utils.COST_VOLUME_VARIANT)
+        skip0, skip1, skip2, skip3, bottom = self.enc(ref_half, feats[1], feats[2], feats[3], cost_volume)
+        if self.is_fusionnet:
+            if has_previous:
+                _, depth_estimation = _ops.depth_reproject_lowres(s["pose"], s["prev_pose"], s["prev_depth"], s["full_K"],
+                                                                  s["half_K"], 16)
+                state = self.lstm(bottom, (s["h"], s["c"]), s["prev_pose"], s["pose"], depth_estimation, s["lstm_K"])
+            else:
+                depth_estimation = torch.zeros(1, 1, self.height // 32, self.width // 32, device=self.device)
+                state = self.lstm(bottom, None, None, s["pose"], depth_estimation, s["lstm_K"])
+            s["h"].copy_(state[0])
+            s["c"].copy_(state[1])
+            bottom = state[0]
+        prediction = self.dec(s["image"], skip0, skip1, skip2, skip3, bottom)[0]
+        s["depth"].copy_(prediction)
+        if self.is_fusionnet:
+            s["prev_depth"].copy_(prediction.view(1, 1, self.height, self.width))
+            s["prev_pose"].copy_(s["pose"])
+
+    # ---- public -----------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, reference_image, reference_pose, measurement_images, measurement_poses, full_K, frame_id=None,
+             measurement_ids=None):
+        """One keyframe.  Images [1,3,H,W] normalised, poses [1,4,4] cam-to-world, ``full_K`` [1,3,3]; all on the GPU.
+
+        ``measurement_images[i]`` may be ``None`` when ``measurement_ids[i]`` is in the feature cache.
+        Returns the full-resolution depth [1,H,W] (a static buffer that the next call overwrites: clone to keep).
+        """
+        n_meas = len(measurement_poses)
+        if n_meas < 1:
+            raise ValueError("need at least one measurement frame")
+        measurement_ids = measurement_ids or [None] * n_meas
+        self._allocate_static(n_meas)
+        s = self._static
+        if tuple(reference_image.shape) != (1, 3, self.height, self.width):
+            raise ValueError(f"image must be [1,3,{self.height},{self.width}], got {tuple(reference_image.shape)}")
+        for i in range(n_meas):
+            img = measurement_images[i] if measurement_images is not None else None
+            if img is None and not (self.cache_features and measurement_ids[i] in self._feature_cache):
+                raise ValueError(f"measurement frame {measurement_ids[i]} is not cached and no image was given")
+            s["meas_feat"][i].copy_(self._half_features(measurement_ids[i], img))
+            s["meas_pose"][i].copy_(measurement_poses[i])
+        s["image"].copy_(reference_image)
+        s["pose"].copy_(reference_pose)
+        s["full_K"].copy_(full_K)
+        s["half_K"].copy_(full_K)
+        s["half_K"][:, 0:2, :] /= 2.0
+        s["lstm_K"].copy_(full_K)
+        s["lstm_K"][:, 0:2, :] /= 32.0
+
+        key = (n_meas, self.has_previous and self.is_fusionnet)
+        if not self.use_graphs:
+            self._frame_body(*key)
+        elif key not in self._warm:
+            # first occurrence: run eagerly (lets MIOpen pick its solvers); state buffers are updated by the body, so
+            # this is a real frame, not a throw-away
+            self._frame_body(*key)
+            self._warm.add(key)
+        else:
+            if key not in self._graphs:
+                self._graphs[key] = self._capture(key)
+            self._graphs[key].replay()
+        self.has_previous = True
+        if self.cache_features and frame_id is not None:
+            self._remember(frame_id, s["ref_half"].clone())
+        return s["depth"]
+
+    def _capture(self, key):
+        """Captures the frame body for ``key``.  Capture executes nothing, but the body mutates state buffers when the
+        graph is replayed, so the state is snapshotted around the (side-effect free) capture itself."""
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._frame_body(*key)
+        return graph

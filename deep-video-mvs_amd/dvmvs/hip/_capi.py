@@ -8,6 +8,11 @@ import ctypes
 import os
 import threading
 
+# PyTorch-ROCm ships its own libamdhip64.so.  It must be in the process BEFORE libdvmvs_hip.so is dlopen'ed so that the
+# library's DT_NEEDED libamdhip64.so.7 resolves to that already-loaded copy: two HIP runtimes in one process do not
+# share streams or device memory (symptom: "no ROCm-capable device is detected" from the second one).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVMVS_HIP_LIB", os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libdvmvs_hip.so")))
 
@@ -26,9 +31,10 @@ SIGNATURES = {
     "dvmvs_abi_version": (_c_int, []),
     "dvmvs_build_arch": (ctypes.c_char_p, []),
     "dvmvs_error_string": (ctypes.c_char_p, [_c_int]),
+    "dvmvs_cost_volume_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
     "dvmvs_cost_volume_fwd": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fpp, _c_fp, _c_fp,
                                        _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                       _c_dbl, _c_dbl, _c_int, _c_int, _c_stream]),
+                                       _c_dbl, _c_dbl, _c_int, _c_int, _c_fp, ctypes.c_size_t, _c_stream]),
     "dvmvs_cost_volume_bwd": (_c_int, [_c_fp, _c_fp, _c_fpp, _c_fp, _c_fpp, _c_fp, _c_fp, _c_fpp,
                                        _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                        _c_dbl, _c_dbl, _c_stream]),

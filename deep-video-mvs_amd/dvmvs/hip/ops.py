@@ -56,12 +56,15 @@ def cost_volume(image1: Tensor, image2s: Sequence[Tensor], pose1: Tensor, pose2s
         if t.shape != image1.shape:
             raise ValueError(f"dvmvs::cost_volume: measurement features {tuple(t.shape)} != reference {tuple(image1.shape)}")
     out = torch.empty((B, n_depth_levels, H, W), dtype=torch.float32, device=image1.device)
+    lib = _capi.lib()
+    ws_bytes = lib.dvmvs_cost_volume_workspace_bytes(B, M)
+    workspace = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=image1.device)
     with torch.cuda.device(image1.device):
-        rc = _capi.lib().dvmvs_cost_volume_fwd(
+        rc = lib.dvmvs_cost_volume_fwd(
             _ptr(image1), _capi.pointer_array([_ptr(t) for t in image2s]), _ptr(pose1),
             _capi.pointer_array([_ptr(t) for t in pose2s]), _ptr(K), _ptr(out),
             B, M, C, H, W, n_depth_levels, float(min_depth), float(max_depth), int(bool(dot_product)), int(variant),
-            _stream(image1))
+            _ptr(workspace), ws_bytes, _stream(image1))
     _capi.check(rc, "dvmvs_cost_volume_fwd")
     return out
 
@@ -107,7 +110,7 @@ def _cost_volume_backward(ctx, grad):
             _capi.pointer_array([_ptr(t) for t in g2] if need2 else [None] * M),
             B, M, C, H, W, D, float(min_depth), float(max_depth), _stream(image1))
     _capi.check(rc, "dvmvs_cost_volume_bwd")
-    return g1, (g2 if need2 else None), None, None, None, None, None, None, None, None
+    return g1, (g2 if need2 else [None] * M), None, [None] * M, None, None, None, None, None, None
 
 
 torch.library.register_autograd("dvmvs::cost_volume", _cost_volume_backward, setup_context=_cost_volume_setup)

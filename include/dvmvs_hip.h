@@ -50,15 +50,19 @@ const char* dvmvs_error_string(int code);
  *   K           [B,3,3]     intrinsics at the feature resolution
  *   cost_volume [B,D,H,W]   out; plane 0 = max_depth ... plane D-1 = min_depth, uniform in inverse depth
  *   dot_product 1: sum_c(f1*warp(f2))/C   0: sum_c|f1-warp(f2)|  (utils.py:81-84); result is the mean over M
- *   variant     0 = pick the fastest kernel for the shape; 1 = force the generic reference-order kernel;
- *               2 = force the tap-reuse kernel (dot_product only)
- * The 3x3 homography K R K^-1 and K t of utils.py:51-56 are evaluated on the device from the poses.
+ *   variant     0 = pick the fastest kernel for the shape; 1 = force the generic reference-order kernel (taps through
+ *               the vector L1); 2 = force the LDS-tiled kernel (dot_product only)
+ *   workspace   optional device scratch of dvmvs_cost_volume_workspace_bytes(B, M) bytes.  When given, the 3x3
+ *               homography K R K^-1 and K t of utils.py:51-56 are evaluated once by a one-workgroup set-up launch and
+ *               read by the sweep kernel; when NULL every workgroup of the sweep kernel derives them itself (one
+ *               launch, slightly longer).  Either way they are computed on the device from the poses (fp64).
  */
+size_t dvmvs_cost_volume_workspace_bytes(int B, int M);
 int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, const float* pose1,
                           const float* const* pose2s, const float* K, float* cost_volume,
                           int B, int M, int C, int H, int W, int D,
                           double min_depth, double max_depth, int dot_product, int variant,
-                          dvmvs_stream_t stream);
+                          float* workspace, size_t workspace_bytes, dvmvs_stream_t stream);
 
 /*
  * Gradient of the fused cost volume (dot_product mode) w.r.t. both feature maps; poses/K carry no gradient

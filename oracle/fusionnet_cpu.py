@@ -1,0 +1,71 @@
+"""CPU restatement of the reference's per-keyframe forward loop.  TEST INFRASTRUCTURE ONLY (see dvmvs_oracle.py).
+
+Order of operations follows /root/reference/dvmvs/fusionnet/run-testing.py:151-204 (fusionnet) and
+/root/reference/dvmvs/pairnet/run-testing.py:136-166 (pairnet, ``lstm_fusion=None``): measurement-frame features are
+recomputed every frame exactly as the reference does, the hot-path functions are the oracle's.  Used by the GPU
+end-to-end parity test and as the ``cpu_baseline`` ("port") leg of bench.py; never by the product package.
+"""
+import time
+
+import torch
+
+import dvmvs_oracle as orc
+
+
+class CpuDepthPipeline:
+    def __init__(self, feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder,
+                 min_depth=0.25, max_depth=20.0, n_depth_levels=64):
+        self.fe, self.fs, self.enc, self.lstm, self.dec = (feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion,
+                                                           cost_volume_decoder)
+        for m in (self.fe, self.fs, self.enc, self.lstm, self.dec):
+            if m is not None:
+                m.eval()
+        self.depth_range = (min_depth, max_depth, n_depth_levels)
+        self.stage_seconds = {}
+        self.reset()
+
+    def reset(self):
+        self.lstm_state, self.previous_depth, self.previous_pose = None, None, None
+
+    def _timed(self, name, fn):
+        t0 = time.perf_counter()
+        out = fn()
+        self.stage_seconds[name] = self.stage_seconds.get(name, 0.0) + time.perf_counter() - t0
+        return out
+
+    @torch.no_grad()
+    def step(self, reference_image, reference_pose, measurement_images, measurement_poses, full_K, record=None):
+        H, W = reference_image.shape[-2:]
+        half_K = full_K.clone()
+        half_K[:, 0:2, :] = half_K[:, 0:2, :] / 2.0
+        lstm_K = full_K.clone()
+        lstm_K[:, 0:2, :] = lstm_K[:, 0:2, :] / 32.0
+        lo, hi, D = self.depth_range
+
+        meas_half = self._timed("features", lambda: [self.fs(*self.fe(img))[0] for img in measurement_images])
+        ref_feats = self._timed("features", lambda: self.fs(*self.fe(reference_image)))
+        cv = self._timed("cost_volume", lambda: orc.cost_volume_fusion(ref_feats[0], meas_half, reference_pose, measurement_poses,
+                                                                        half_K, lo, hi, D, True))
+        skip0, skip1, skip2, skip3, bottom = self._timed("encoder", lambda: self.enc(*ref_feats, cv))
+        de = None
+        if self.lstm is not None:
+            if self.previous_depth is not None:
+                de = self._timed("reprojection", lambda: orc.nearest_downsample(
+                    orc.reproject_depth(reference_pose, self.previous_pose, self.previous_depth, full_K, half_K, W, H), 16))
+            else:
+                de = torch.zeros(1, 1, H // 32, W // 32)
+            h, c = self.lstm_state if self.lstm_state is not None else (torch.zeros_like(bottom), torch.zeros_like(bottom))
+            weight = self.lstm.lstm_cell.conv.weight
+            self.lstm_state = self._timed("lstm", lambda: orc.convlstm_cell(weight, bottom, h, c, self.previous_pose, reference_pose,
+                                                                           de, lstm_K))
+            bottom_out = self.lstm_state[0]
+        else:
+            bottom_out = bottom
+        pred = self._timed("decoder", lambda: self.dec(reference_image, skip0, skip1, skip2, skip3, bottom_out)[0])
+        if self.lstm is not None:
+            self.previous_depth = pred.view(1, 1, H, W)
+            self.previous_pose = reference_pose
+        if record is not None:
+            record(feat_half=ref_feats[0], cost_volume=cv, bottom=bottom, depth_estimation=de,
+                   h=None if self.lstm is None else self.lstm_state[0], c=None if self.lstm is None else self.lstm_state[1], depth=pred)
+        return pred

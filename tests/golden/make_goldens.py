@@ -281,6 +281,27 @@ def end_to_end_goldens(ref):
                 print(f"frame {n}: depth range {pred.min().item():.4f} .. {pred.max().item():.4f}, mean {pred.mean().item():.4f}; "
                       f"cv mean|.| {cv.abs().mean().item():.4f}; bottom std {bottom.std().item():.3f}; h std {lstm_state[0].std().item():.3f}")
             state = one_frame(r, ms, *state, record=record)
+    # float64 arbitration run: same weights, same inputs, the oracle pipeline in double precision.  It tells how far the
+    # reference's OWN float32 forward is from the exact arithmetic, i.e. what "equal up to fp32 round-off" means for
+    # this (random-weight, hence sensitive) network.
+    import copy
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle"))
+    sys.modules.setdefault("dvmvs_oracle", ref.oracle)
+    from fusionnet_cpu import CpuDepthPipeline
+    pipe64 = CpuDepthPipeline(*[copy.deepcopy(mod).double() for mod in modules])
+    for n, (r, ms) in enumerate(syn.E2E_FRAMES):
+        rec = {}
+        pipe64.step(image(r).double(), syn.pose(r).double(), [image(i).double() for i in ms], [syn.pose(i).double() for i in ms],
+                    fullK.double(), record=lambda **kw: rec.update(kw))
+        ref32 = torch.from_numpy(arrays[f"f{n}_depth_sub4"].numpy() if isinstance(arrays[f"f{n}_depth_sub4"], torch.Tensor)
+                                 else arrays[f"f{n}_depth_sub4"]).double()
+        d64 = rec["depth"][0, ::4, ::4]
+        arrays[f"f{n}_depth64_sub4"] = d64
+        for tag in ("h", "c", "bottom", "cost_volume"):
+            arrays[f"f{n}_{tag}64_samples"] = rec[tag].reshape(-1)[syn.sample_indices(rec[tag].numel())]
+        rel = float(((ref32 - d64).abs() / d64).mean())
+        REPORT[f"e2e_frame{n}_reference_fp32_vs_float64_depth_rel_l1"] = rel
+        print(f"frame {n}: reference fp32 vs float64 depth rel-L1 {rel:.3e}")
     save("fusionnet_e2e", **arrays)
 
     # pairnet: one frame, M = 1 (reference pairnet/run-testing.py:136-166); same weights minus the LSTM
