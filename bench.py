@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-reps", type=int, default=50)
     ap.add_argument("--stage-times", action="store_true", help="also print eager per-stage GPU times to stderr")
+    ap.add_argument("--mark-region", action="store_true",
+                    help="bracket the timed loop with a cumsum kernel so tools/summarize_trace.py can cut it out of a rocprofv3 trace")
+    ap.add_argument("--no-roofline-leg", action="store_true", help="skip the dedicated cost-volume timing (profiling runs)")
     return ap.parse_args()
 
 
@@ -214,6 +217,10 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        marker = torch.ones(4096, device=device)
+        if args.mark_region:
+            marker.cumsum(0)
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             run_frame(k)
@@ -223,6 +230,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        if args.mark_region:
+            marker.cumsum(0)
+            torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -232,7 +242,10 @@ def main():
 
     result = None
     if rank == 0:
-        kernel_s, alg_bytes = measure_cost_volume_kernel(engine, M, args.kernel_reps)
+        if args.no_roofline_leg:
+            kernel_s, alg_bytes = float("nan"), (1 + M) * 32 * 128 * 160 * 4 + 64 * 128 * 160 * 4
+        else:
+            kernel_s, alg_bytes = measure_cost_volume_kernel(engine, M, args.kernel_reps)
         achieved = alg_bytes / kernel_s / 1e9
         result = {
             "metric": "depth frames/sec/GPU @ 320x256x64 planes (fusionnet); rel-L1 vs ref",

@@ -50,6 +50,14 @@ __global__ __launch_bounds__(256) void depth_splat_kernel(const float* __restric
   atomicMax(out_bits + static_cast<size_t>(b) * hh * hw + static_cast<int>(v) * hw + static_cast<int>(u), __float_as_uint(z_store));
 }
 
+// Zero-fill as an ordinary kernel node.  hipMemsetAsync is avoided on purpose: captured into a hipGraph it becomes a
+// memset node, and on ROCm 7.x replays of such a graph were observed to run the splat kernel against a buffer that was
+// cleared late (all-zero output whenever the device was idle at launch); kernel -> kernel edges do not have the problem.
+__global__ void zero_fill_kernel(float* __restrict__ p, long long n) {
+  for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < n; i += static_cast<long long>(gridDim.x) * blockDim.x)
+    p[i] = 0.0f;
+}
+
 // F.interpolate(scale_factor=1/f, mode="nearest") for an integer factor: picks rows / columns 0, f, 2f, ...
 __global__ void nearest_decimate_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int f) {
   const int Ho = H / f, Wo = W / f;
@@ -71,11 +79,14 @@ extern "C" int dvmvs_depth_reproject_fwd(const float* reference_pose, const floa
   if (out_lowres && lowres_factor <= 0) return DVMVS_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int hh = full_height / 2, hw = full_width / 2;
-  DVMVS_RETURN_IF_HIP(hipMemsetAsync(out, 0, sizeof(float) * static_cast<size_t>(B) * hh * hw, s));
+  const long long n_out = static_cast<long long>(B) * hh * hw;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(static_cast<unsigned>((n_out + 255) / 256 < 1024 ? (n_out + 255) / 256 : 1024)), dim3(256), 0, s, out, n_out);
+  int rc = launch_status();
+  if (rc != 0) return rc;
   const int HWf = full_height * full_width;
   hipLaunchKernelGGL(depth_splat_kernel, dim3((HWf + 255) / 256, B), dim3(256), 0, s, reference_pose, measurement_pose,
                      previous_depth, full_K, half_K, reinterpret_cast<unsigned int*>(out), B, full_height, full_width);
-  int rc = launch_status();
+  rc = launch_status();
   if (rc != 0) return rc;
   if (out_lowres) {
     const int n = B * (hh / lowres_factor) * (hw / lowres_factor);

@@ -1,0 +1,99 @@
+// Elementwise epilogues of the per-frame network path, gfx950.
+//
+// MIOpen's fp32 convolutions leave the bias add and the activation to separate ATen kernels, and ATen's bilinear
+// up-sampling kernel takes ~80 us on the 512 x 8 x 10 bottleneck map.  At batch 1 a frame is ~370 launches of a few
+// microseconds each, so these two ops fuse / replace them:
+//   dvmvs_bias_act_inplace : x[b,c,:,:] = act(x[b,c,:,:] + bias[c])      act = none | relu | sigmoid   (one pass)
+//   dvmvs_upsample2x_fwd   : F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+// Both are bandwidth / latency trivial; they exist to cut launches and tail latency, not FLOPs.
+#include "dvmvs_device.h"
+
+namespace dvmvs {
+
+template <int ACT>
+__device__ inline float apply_act(float v) {
+  if (ACT == 1) return fmaxf(v, 0.0f);
+  if (ACT == 2) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+
+// One workgroup row per (b, c) plane chunk; float4 when the plane size allows it.
+template <int ACT, bool VEC4>
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ x, const float* __restrict__ bias, int C, int HW) {
+  const int plane = blockIdx.y;  // b * C + c
+  const float bv = bias ? bias[plane % C] : 0.0f;
+  float* p = x + static_cast<size_t>(plane) * HW;
+  if (VEC4) {
+    typedef float float4v __attribute__((ext_vector_type(4)));
+    float4v* p4 = reinterpret_cast<float4v*>(p);
+    const int n4 = HW / 4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+      float4v v = p4[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(v[e] + bv);
+      p4[i] = v;
+    }
+  } else {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) p[i] = apply_act<ACT>(p[i] + bv);
+  }
+}
+
+// 2x bilinear up-sampling, align_corners=True, in ATen's op order:
+//   src = dst * (in - 1) / (out - 1);  i0 = int(src);  l1 = src - i0;  l0 = 1 - l1
+//   out = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11)
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int H, int W) {
+  const int OH = 2 * H, OW = 2 * W;
+  const float sh = OH > 1 ? static_cast<float>(H - 1) / static_cast<float>(OH - 1) : 0.0f;
+  const float sw = OW > 1 ? static_cast<float>(W - 1) / static_cast<float>(OW - 1) : 0.0f;
+  const long long total = static_cast<long long>(planes) * OH * OW;
+  for (long long i = blockIdx.x * static_cast<long long>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int ox = static_cast<int>(i % OW);
+    const int oy = static_cast<int>((i / OW) % OH);
+    const long long pl = i / (static_cast<long long>(OW) * OH);
+    const float fy = sh * static_cast<float>(oy), fx = sw * static_cast<float>(ox);
+    const int y0 = static_cast<int>(fy), x0 = static_cast<int>(fx);
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float h1 = fy - static_cast<float>(y0), h0 = 1.0f - h1;
+    const float w1 = fx - static_cast<float>(x0), w0 = 1.0f - w1;
+    const float* p = in + pl * H * W;
+    out[i] = h0 * (w0 * p[y0 * W + x0] + w1 * p[y0 * W + x1]) + h1 * (w0 * p[y1 * W + x0] + w1 * p[y1 * W + x1]);
+  }
+}
+
+template <int ACT>
+int launch_bias_act(float* x, const float* bias, int B, int C, int HW, hipStream_t s) {
+  const bool vec4 = (HW % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+  const int work = vec4 ? HW / 4 : HW;
+  dim3 grid(max(1, min((work + 255) / 256, 64)), B * C), block(256);
+  if (vec4) hipLaunchKernelGGL((bias_act_kernel<ACT, true>), grid, block, 0, s, x, bias, C, HW);
+  else hipLaunchKernelGGL((bias_act_kernel<ACT, false>), grid, block, 0, s, x, bias, C, HW);
+  return launch_status();
+}
+
+}  // namespace dvmvs
+
+extern "C" int dvmvs_bias_act_inplace(float* x, const float* bias, int B, int C, int H, int W, int activation,
+                                      dvmvs_stream_t stream) {
+  using namespace dvmvs;
+  if (!x || B <= 0 || C <= 0 || H <= 0 || W <= 0) return DVMVS_EINVAL;
+  if (static_cast<long long>(B) * C > 65535LL * 1024) return DVMVS_EUNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (activation) {
+    case 0: return launch_bias_act<0>(x, bias, B, C, H * W, s);
+    case 1: return launch_bias_act<1>(x, bias, B, C, H * W, s);
+    case 2: return launch_bias_act<2>(x, bias, B, C, H * W, s);
+    default: return DVMVS_EINVAL;
+  }
+}
+
+extern "C" int dvmvs_upsample2x_fwd(const float* in, float* out, int B, int C, int H, int W, dvmvs_stream_t stream) {
+  using namespace dvmvs;
+  if (!in || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return DVMVS_EINVAL;
+  const long long total = static_cast<long long>(B) * C * H * W * 4;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 256LL * 16) blocks = 256LL * 16;
+  hipLaunchKernelGGL(upsample2x_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
+                     B * C, H, W);
+  return launch_status();
+}

@@ -12,7 +12,8 @@ from torch import Tensor
 
 from dvmvs.hip import _capi
 
-__all__ = ["cost_volume", "hidden_warp", "relative_pose", "lstm_gates", "depth_reproject", "depth_reproject_lowres"]
+__all__ = ["cost_volume", "hidden_warp", "relative_pose", "lstm_gates", "depth_reproject", "depth_reproject_lowres",
+           "bias_act_", "upsample2x"]
 
 
 def _no_cpu(op):
@@ -298,3 +299,52 @@ def _(reference_pose, measurement_pose, previous_depth, full_K, half_K, factor):
 @depth_reproject_lowres.register_kernel("cpu")
 def _(reference_pose, measurement_pose, previous_depth, full_K, half_K, factor):
     _no_cpu("depth_reproject_lowres")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# frame-path epilogues (inference only: no autograd formulas are registered)
+# ----------------------------------------------------------------------------------------------------------------------
+ACTIVATIONS = {"none": 0, "relu": 1, "sigmoid": 2}
+
+
+@torch.library.custom_op("dvmvs::bias_act_", mutates_args=("x",), device_types="cuda")
+def bias_act_(x: Tensor, bias: Tensor, activation: int) -> None:
+    """In place: x[b,c] = act(x[b,c] + bias[c]) for a contiguous NCHW tensor; ``bias`` may be empty (numel 0)."""
+    _dev_f32("bias_act_", x)
+    if not x.is_contiguous() or x.dim() != 4:
+        raise ValueError("dvmvs::bias_act_: expected a contiguous NCHW tensor")
+    B, C, H, W = x.shape
+    if bias.numel() not in (0, C):
+        raise ValueError(f"dvmvs::bias_act_: bias has {bias.numel()} entries for {C} channels")
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().dvmvs_bias_act_inplace(_ptr(x), _ptr(bias.contiguous()) if bias.numel() else None, B, C, H, W, int(activation),
+                                                _stream(x))
+    _capi.check(rc, "dvmvs_bias_act_inplace")
+
+
+@bias_act_.register_kernel("cpu")
+def _(x, bias, activation):
+    _no_cpu("bias_act_")
+
+
+@torch.library.custom_op("dvmvs::upsample2x", mutates_args=(), device_types="cuda")
+def upsample2x(x: Tensor) -> Tensor:
+    _dev_f32("upsample2x", x)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().dvmvs_upsample2x_fwd(_ptr(x), _ptr(out), B, C, H, W, _stream(x))
+    _capi.check(rc, "dvmvs_upsample2x_fwd")
+    return out
+
+
+@upsample2x.register_fake
+def _(x):
+    B, C, H, W = x.shape
+    return x.new_empty((B, C, 2 * H, 2 * W))
+
+
+@upsample2x.register_kernel("cpu")
+def _(x):
+    _no_cpu("upsample2x")

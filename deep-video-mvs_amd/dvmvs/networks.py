@@ -23,6 +23,11 @@ hyper_channels = 32
 
 
 def _upsample2(x):
+    """x2 bilinear up-sampling, align_corners=True.  On the GPU at inference this is the HIP kernel
+    (dvmvs_upsample2x_fwd, same interpolation formula); with autograd enabled or on the CPU it is ATen's."""
+    if x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad):
+        from dvmvs.hip import ops as _ops
+        return _ops.upsample2x(x)
     return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
 
 
@@ -160,7 +165,9 @@ class CostVolumeDecoder(nn.Module):
     def _to_depth(self, sigmoid_depth):
         return 1.0 / (self.inverse_depth_multiplier * sigmoid_depth + self.inverse_depth_base).squeeze(1)
 
-    def forward(self, image, skip0, skip1, skip2, skip3, bottom):
+    def forward(self, image, skip0, skip1, skip2, skip3, bottom, full_resolution_only=False):
+        """Returns (full, half, quarter, 1/8, 1/16) depth maps like the reference; with ``full_resolution_only`` the four
+        coarser maps (training-loss outputs that inference discards) are returned as None and never computed."""
         d1 = self.decoder_block1(bottom, skip3, None)
         s16 = self.depth_layer_one_sixteen(d1)
         d2 = self.decoder_block2(d1, skip2, s16)
@@ -172,4 +179,6 @@ class CostVolumeDecoder(nn.Module):
 
         full_in = torch.cat([_upsample2(d4), _upsample2(s2), image], dim=1)
         s1 = self.depth_layer_full(self.refine(full_in))
+        if full_resolution_only:
+            return self._to_depth(s1), None, None, None, None
         return self._to_depth(s1), self._to_depth(s2), self._to_depth(s4), self._to_depth(s8), self._to_depth(s16)

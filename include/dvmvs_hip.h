@@ -138,6 +138,17 @@ int dvmvs_depth_reproject_fwd(const float* reference_pose, const float* measurem
                               float* out, float* out_lowres, int lowres_factor,
                               int B, int full_height, int full_width, dvmvs_stream_t stream);
 
+/*
+ * Frame-path epilogues (not part of the reference's function list; they replace ATen elementwise launches that sit
+ * between MIOpen convolutions on the per-frame path, /root/reference/dvmvs/layers.py:39-65 and fusionnet/model.py:57,112,290).
+ *   dvmvs_bias_act_inplace: x[b,c,:,:] = act(x[b,c,:,:] + bias[c]); bias may be NULL; activation 0 none, 1 ReLU, 2 sigmoid.
+ *   dvmvs_upsample2x_fwd:   torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True);
+ *                           in [B,C,H,W] -> out [B,C,2H,2W].
+ */
+int dvmvs_bias_act_inplace(float* x, const float* bias, int B, int C, int H, int W, int activation,
+                           dvmvs_stream_t stream);
+int dvmvs_upsample2x_fwd(const float* in, float* out, int B, int C, int H, int W, dvmvs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

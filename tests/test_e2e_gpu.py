@@ -81,15 +81,19 @@ def test_fusionnet_three_frames_match_the_reference(hip_device, golden_dir, mode
                 exp_low = z[f"f{n}_depth_estimation_full"]
                 same_estimate = bool(np.all(np.abs(low.cpu().numpy() - exp_low) <= 1e-3 * np.maximum(exp_low, 1e-3)))
             prev_depth = depth.clone().view(1, 1, 256, 320)
-            if same_estimate and ref_vs_f64 < 1e-3:
-                assert vs_f64 <= 1.5 * ref_vs_f64 + 2e-5, f"frame {n} ({mode}): {vs_f64:.3e} from float64, reference is {ref_vs_f64:.3e}"
-                assert vs_ref <= 2.5 * REL_L1_TARGET, f"frame {n} ({mode}): depth rel-L1 {vs_ref:.3e} vs the reference"
-                pins_close(s["h"], z, f"f{n}_h", 5e-4)
-                pins_close(s["c"], z, f"f{n}_c", 5e-4)
-            else:
-                assert vs_ref <= 1e-2, f"frame {n} ({mode}): depth rel-L1 {vs_ref:.3e} vs the reference"
+            h_got = s["h"].detach().float().cpu().reshape(-1)[syn.sample_indices(s["h"].numel())].numpy()
+            h_err = float(np.abs(h_got - z[f"f{n}_h_samples"]).mean() / (np.abs(z[f"f{n}_h_samples"]).mean() + 1e-12))
+            report[-1] = report[-1] + (same_estimate, h_err)
     for row in report:
-        print("%s sweep %d frame %d: rel-L1 vs reference %.3e, vs float64 %.3e (reference vs float64 %.3e)" % ((mode,) + row))
+        print("%s sweep %d frame %d: rel-L1 vs reference %.3e, vs float64 %.3e (reference vs float64 %.3e), same depth estimate: %s, "
+              "hidden state rel err %.2e" % ((mode,) + row))
+    for sweep, n, vs_ref, vs_f64, ref_vs_f64, same_estimate, h_err in report:
+        if same_estimate and ref_vs_f64 < 1e-3:
+            assert h_err <= 1e-3, f"sweep {sweep} frame {n} ({mode}): hidden state differs from the reference by {h_err:.2e}"
+            assert vs_f64 <= 1.5 * ref_vs_f64 + 2e-5, f"sweep {sweep} frame {n} ({mode}): {vs_f64:.3e} from float64, reference is {ref_vs_f64:.3e}"
+            assert vs_ref <= 2.5 * REL_L1_TARGET, f"sweep {sweep} frame {n} ({mode}): depth rel-L1 {vs_ref:.3e} vs the reference"
+        else:
+            assert vs_ref <= 1e-2, f"sweep {sweep} frame {n} ({mode}): depth rel-L1 {vs_ref:.3e} vs the reference"
     assert report[0][2] <= 2.5 * REL_L1_TARGET
 
 

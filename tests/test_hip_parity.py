@@ -396,3 +396,52 @@ def test_convlstm_cell_known_answer(dev, golden_dir):
         h1, c1 = cell(*to(dev, x), list(cell.init_hidden(1, (8, 10))), None, syn.pose(9).to(dev), de16.to(dev), lK.to(dev))
         eh, ec = orc.convlstm_cell(weight, x, torch.zeros_like(h0), torch.zeros_like(c0), None, syn.pose(9), de16, lK)
         assert maxerr(h1, eh) < 2e-4 and maxerr(c1, ec) < 2e-4
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# frame-path epilogues
+# ----------------------------------------------------------------------------------------------------------------------
+def test_bias_activation_epilogue_is_exact(ops, dev):
+    g = torch.Generator().manual_seed(21)
+    for shape in ((1, 32, 128, 160), (2, 7, 5, 3), (1, 1, 256, 320), (3, 96, 16, 20)):
+        x = torch.randn(*shape, generator=g)
+        b = torch.randn(shape[1], generator=g)
+        for name, fn in (("none", lambda t: t), ("relu", torch.relu), ("sigmoid", torch.sigmoid)):
+            y = x.to(dev).clone()
+            ops.bias_act_(y, b.to(dev), ops.ACTIVATIONS[name])
+            exp = fn(x + b.view(1, -1, 1, 1))
+            assert maxerr(y, exp) <= (0.0 if name != "sigmoid" else 2e-7), (shape, name)
+        y = x.to(dev).clone()
+        ops.bias_act_(y, torch.empty(0, device=dev), ops.ACTIVATIONS["relu"])
+        assert maxerr(y, torch.relu(x)) == 0.0
+
+
+def test_upsample2x_matches_aten(ops, dev):
+    g = torch.Generator().manual_seed(22)
+    for shape in ((1, 512, 8, 10), (1, 32, 128, 160), (2, 3, 5, 7), (1, 1, 64, 80), (1, 4, 1, 1)):
+        x = torch.randn(*shape, generator=g)
+        got = ops.upsample2x(x.to(dev))
+        exp = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+        assert tuple(got.shape) == tuple(exp.shape)
+        assert maxerr(got, exp) < 5e-6 * max(1.0, exp.abs().max().item()), shape   # same formula, different FMA contraction
+
+
+def test_fused_modules_match_plain_modules(dev):
+    """BN folding + epilogue fusion (what the engine runs) against the untouched modules on the GPU."""
+    from dvmvs.engine import fold_batchnorm, fuse_epilogues
+    from dvmvs.fusionnet.model import CostVolumeDecoder, FeatureExtractor, FeatureShrinker
+    fe = syn.deterministic_init(FeatureExtractor(), 0).eval().to(dev)
+    fs = FeatureShrinker().eval().to(dev)
+    dec = syn.deterministic_init(CostVolumeDecoder(), 4).eval().to(dev)
+    x = syn.smooth_noise((1, 3, 256, 320), seed=5).to(dev)
+    with torch.no_grad():
+        plain = fs(*fe(x))
+        fused = fuse_epilogues(fold_batchnorm(fs))(*fuse_epilogues(fold_batchnorm(fe))(x))
+        for a, b in zip(plain, fused):
+            assert maxerr(a, b) <= 2e-4 * max(1.0, a.abs().max().item())
+        skips = [torch.randn(1, c, 128 // s, 160 // s, device=dev) for c, s in ((32, 1), (64, 2), (128, 4), (256, 8), (512, 16))]
+        d_plain = dec(x, *skips)
+        d_fused = fuse_epilogues(fold_batchnorm(dec))(x, *skips, full_resolution_only=True)
+        assert d_fused[1] is None
+        rel = ((d_plain[0] - d_fused[0]).abs() / d_plain[0]).mean().item()
+        assert rel < 1e-4
