@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
-    ap.add_argument("--kernel-reps", type=int, default=50)
+    ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--stage-times", action="store_true", help="also print eager per-stage GPU times to stderr")
     ap.add_argument("--mark-region", action="store_true",
                     help="bracket the timed loop with a cumsum kernel so tools/summarize_trace.py can cut it out of a rocprofv3 trace")
@@ -57,17 +57,34 @@ def build_modules():
     return syn.build_e2e_modules((FeatureExtractor, FeatureShrinker, CostVolumeEncoder, LSTMFusion, CostVolumeDecoder))
 
 
-def synthetic_sequence(seq_id, n_images, n_poses):
-    """Images ~ low-passed N(0,1) (already "normalised"), smooth trajectory with ~0.12 m keyframe baseline."""
+def synthetic_sequence(seq_id, n_images, n_frames, n_meas):
+    """One posed sequence: synthetic images (low-passed N(0,1), i.e. already "normalised") on the camera geometry of the
+    reference's sample scene.  Frame j is line j of the keyframe index sample-data/indices/keyframe+hololens-dataset+000+
+    nmeas+2 (committed under tests/golden/indices): its reference pose and its measurement poses, so that parallax,
+    rotation and the mix of sideways / forward motion are those of real hand-held capture (median keyframe baseline
+    0.144 m).  Sequences of different ranks start at different lines; the list wraps around.
+    Returns images, [(ref_pose[1,4,4], [meas_pose...]) per frame], full_K."""
     import synthetic as syn
     images = [syn.smooth_noise((1, 3, 256, 320), seed=1000 * (seq_id + 1) + i) for i in range(n_images)]
-    poses = torch.from_numpy(syn.synthetic_trajectory(n_poses, seed=1000 + seq_id)).float()
-    return images, poses, syn.full_K()
+    all_poses = torch.from_numpy(syn.sample_poses()).float()
+    names = {n: i for i, n in enumerate(syn.sample_image_names())}
+    lines = [l.split() for l in open(os.path.join(ROOT, "tests", "golden", "indices", "keyframe+hololens-dataset+000+nmeas+2"))]
+    lines = [[names[x] for x in l] for l in lines if len(l) == 3]
+    frames = []
+    for j in range(n_frames):
+        ref, *meas = lines[(j + 37 * seq_id) % len(lines)]
+        meas = (meas * n_meas)[:n_meas]
+        frames.append((all_poses[ref:ref + 1], [all_poses[i:i + 1] for i in meas]))
+    return images, frames, syn.full_K()
 
 
-def measure_cost_volume_kernel(engine, n_meas, reps):
-    """Average duration of one fused cost-volume launch: a hipGraph of ``reps`` back-to-back launches (no host gaps),
-    timed with HIP events on the stream it is replayed on."""
+def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
+    """Average duration of one fused cost-volume launch over the geometries of the timed region.
+
+    ``pose_sets``: (reference pose, [measurement poses]) of keyframes sampled evenly from the timed loop -- the kernel's
+    duration depends on the epipolar geometry (how large the LDS-staged footprint of a tile is), so one geometry is not
+    representative.  For each, a hipGraph of ``reps`` back-to-back launches (no host gaps) is timed with HIP events on the
+    stream it is replayed on.  Returns (mean seconds per launch, algorithmic bytes per launch, [per-geometry seconds])."""
     from dvmvs.hip import _capi
     s = engine._static
     ref = s["ref_half"]
@@ -75,6 +92,8 @@ def measure_cost_volume_kernel(engine, n_meas, reps):
     D = engine.n_depth_levels
     out = torch.empty(B, D, H, W, device=ref.device)
     img_ptrs = _capi.pointer_array([t.data_ptr() for t in s["meas_feat"][:n_meas]])
+    layout = _capi.LAYOUT_NHWC if all(t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+                                      for t in s["meas_feat"][:n_meas]) else _capi.LAYOUT_NCHW
     pose_ptrs = _capi.pointer_array([t.data_ptr() for t in s["meas_pose"][:n_meas]])
     lib = _capi.lib()
     from dvmvs import utils
@@ -83,7 +102,7 @@ def measure_cost_volume_kernel(engine, n_meas, reps):
 
     def launch():
         rc = lib.dvmvs_cost_volume_fwd(ref.data_ptr(), img_ptrs, s["pose"].data_ptr(), pose_ptrs, s["half_K"].data_ptr(), out.data_ptr(),
-                                       B, n_meas, C, H, W, D, engine.min_depth, engine.max_depth, 1, utils.COST_VOLUME_VARIANT,
+                                       B, n_meas, C, H, W, D, engine.min_depth, engine.max_depth, 1, utils.COST_VOLUME_VARIANT, layout,
                                        workspace.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
         _capi.check(rc, "dvmvs_cost_volume_fwd")
 
@@ -93,18 +112,23 @@ def measure_cost_volume_kernel(engine, n_meas, reps):
     with torch.cuda.graph(graph):
         for _ in range(reps):
             launch()
-    graph.replay()
-    torch.cuda.synchronize()
-    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    rounds = 5
-    start.record()
-    for _ in range(rounds):
+    per_geometry = []
+    rounds = 3
+    for ref_pose, meas_poses in pose_sets:
+        s["pose"].copy_(ref_pose)
+        for i in range(n_meas):
+            s["meas_pose"][i].copy_(meas_poses[i])
         graph.replay()
-    end.record()
-    torch.cuda.synchronize()
-    seconds = start.elapsed_time(end) * 1e-3 / (rounds * reps)
+        torch.cuda.synchronize()
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(rounds):
+            graph.replay()
+        end.record()
+        torch.cuda.synchronize()
+        per_geometry.append(start.elapsed_time(end) * 1e-3 / (rounds * reps))
     algorithmic_bytes = (1 + n_meas) * B * C * H * W * 4 + B * D * H * W * 4
-    return seconds, algorithmic_bytes
+    return sum(per_geometry) / len(per_geometry), algorithmic_bytes, per_geometry
 
 
 def usable_cores():
@@ -132,14 +156,17 @@ def cpu_baseline(args, modules, n_meas):
     from fusionnet_cpu import CpuDepthPipeline
     cores = min(usable_cores(), 64)      # batch-1 convolutions of this size stop scaling long before 64 threads
     torch.set_num_threads(cores)
-    images, poses, full_K = synthetic_sequence(0, 8, 64)
-    pipe = CpuDepthPipeline(*modules)
+    images, seq, full_K = synthetic_sequence(0, 8, 64, n_meas)
+    pipe = CpuDepthPipeline(*modules, planewise_cost_volume=True)
     frames, t_total = 0, 0.0
     k = n_meas
+
+    def cpu_frame(k):
+        pipe.step(images[k % 8], seq[k][0], [images[(k - 1 - i) % 8] for i in range(n_meas)], seq[k][1], full_K)
+
     # one untimed frame (thread pools, oneDNN primitive caches), then a bounded timed sample
     t0 = time.perf_counter()
-    pipe.step(images[k % 8], poses[k:k + 1], [images[(k - 1 - i) % 8] for i in range(n_meas)],
-              [poses[k - 1 - i:k - i] for i in range(n_meas)], full_K)
+    cpu_frame(k)
     first = time.perf_counter() - t0
     if first > args.cpu_baseline_seconds:      # pathologically slow host: report the one frame we have and stop
         frames, t_total = 1, first
@@ -148,8 +175,7 @@ def cpu_baseline(args, modules, n_meas):
     while t_total < args.cpu_baseline_seconds and frames < 24:
         k += 1
         t0 = time.perf_counter()
-        pipe.step(images[k % 8], poses[k:k + 1], [images[(k - 1 - i) % 8] for i in range(n_meas)],
-                  [poses[k - 1 - i:k - i] for i in range(n_meas)], full_K)
+        cpu_frame(k)
         t_total += time.perf_counter() - t0
         frames += 1
     cpu_model = "unknown"
@@ -193,15 +219,15 @@ def main():
     M = args.measurement_frames
     n_images = 32
     total = args.warmup + args.steps
-    images, poses, full_K = synthetic_sequence(rank, n_images, total + M + 1)   # one independent sequence per rank
+    images, seq, full_K = synthetic_sequence(rank, n_images, total + M + 1, M)   # one independent sequence per rank
     images = [im.to(device) for im in images]
-    poses = poses.to(device)
+    seq = [(r.to(device), [p.to(device) for p in ms]) for r, ms in seq]
     full_K = full_K.to(device)
 
     def run_frame(k):
         ids = [k - 1 - i for i in range(M)]
         meas_images = None if not args.no_feature_cache else [images[i % n_images] for i in ids]
-        return engine.step(images[k % n_images], poses[k:k + 1], meas_images, [poses[i:i + 1] for i in ids], full_K,
+        return engine.step(images[k % n_images], seq[k][0], meas_images, seq[k][1], full_K,
                            frame_id=k if not args.no_feature_cache else None, measurement_ids=ids if not args.no_feature_cache else None)
 
     with torch.no_grad():
@@ -243,23 +269,34 @@ def main():
     result = None
     if rank == 0:
         if args.no_roofline_leg:
-            kernel_s, alg_bytes = float("nan"), (1 + M) * 32 * 128 * 160 * 4 + 64 * 128 * 160 * 4
+            kernel_s, alg_bytes, per_geometry = float("nan"), (1 + M) * 32 * 128 * 160 * 4 + 64 * 128 * 160 * 4, []
         else:
-            kernel_s, alg_bytes = measure_cost_volume_kernel(engine, M, args.kernel_reps)
+            first = M + args.warmup
+            sample = [first + (i * max(args.steps - 1, 1)) // 7 for i in range(8)]
+            pose_sets = [seq[j] for j in sample]
+            kernel_s, alg_bytes, per_geometry = measure_cost_volume_kernel(engine, M, args.kernel_reps, pose_sets)
         achieved = alg_bytes / kernel_s / 1e9
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, see profiles/)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_cost_volume_pmc.json")))
+            if pmc.get("shape") == [1, M, 32, 128, 160, 64]:
+                traffic = pmc["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         result = {
             "metric": "depth frames/sec/GPU @ 320x256x64 planes (fusionnet); rel-L1 vs ref",
             "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "fusionnet inference, one synthetic posed sequence per GPU, 320x256, 64 planes, "
-                                   f"M={M} measurement frames, batch 1 (BASELINE.json configs[2]; configs[3] at N>1)",
+            "config": {"workload": "fusionnet inference, one synthetic-image sequence per GPU on the sample scene's keyframe poses, "
+                                   f"320x256, 64 planes, M={M} measurement frames, batch 1 (BASELINE.json configs[2]; configs[3] at N>1)",
                        "sequences_per_gpu": 1, "hip_graphs": not args.no_graphs, "bn_folded": not args.no_fold_bn,
                        "feature_cache": not args.no_feature_cache, "weights": "seeded (tests/synthetic.py) + published FPN checkpoint",
                        "parallelism": f"sequence-sharded x{world}, no data-path collective"},
             "roofline": {"kernel": "cost_volume (fused warp + correlation, all planes, all measurement frames)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel_us": kernel_s * 1e6, "algorithmic_bytes": alg_bytes},
+                         "traffic": traffic, "kernel_us": kernel_s * 1e6, "algorithmic_bytes": alg_bytes,
+                         "kernel_us_per_geometry": [round(t * 1e6, 2) for t in per_geometry]},
         }
         if world == 1 and not args.no_cpu_baseline:
             cpu_mods = build_modules()

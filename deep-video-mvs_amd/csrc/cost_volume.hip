@@ -23,7 +23,7 @@ __global__ __launch_bounds__(kWave* kGenericPlaneGroups) void cost_volume_generi
   __shared__ float s_ktd[DVMVS_MAX_MEASUREMENTS * kPlanesPerBlock * 3];
 
   const int b = blockIdx.z;
-  const int d_block = blockIdx.y * kPlanesPerBlock;
+  const int d_block = (gridDim.y - 1 - blockIdx.y) * kPlanesPerBlock;   // near (scattered) planes first, see the tiled kernel
   const int tid = threadIdx.y * kWave + threadIdx.x;
   sweep_setup(a, b, d_block, kPlanesPerBlock, tid, kWave * kGenericPlaneGroups, s_H, s_kt, s_ktd);
 
@@ -121,19 +121,71 @@ struct TiledConfig {
   static_assert(CCH % 4 == 0 && ((kRec / 4) % 2) == 1, "record stride must be an odd number of 16-byte slots");
 };
 
-template <int TW, int TH, int DP, int CCH, int CAP>
+// Bounding box of the tile's sample positions over planes [j_lo, j_hi] of measurement frame m, evaluated by the first 8
+// lanes (tile corner x extreme plane) and published through s_box: {x_lo, y_lo, RW, RH, state}.
+//   state 1: box staged through LDS; 2: box entirely outside the image (zeros); 0: does not fit / not well defined.
+template <int TW, int TH, int DP, int CAP>
+__device__ inline void publish_sample_box(const CostVolumeArgs& a, const float* Hm, const float* ktd_m, int tile_x, int tile_y,
+                                          int j_lo, int j_hi, int tid, int* s_box) {
+  if (tid < 64) {
+    float ix = 0.0f, iy = 0.0f, z = 1.0f;
+    if (tid < 8) {
+      const int cx = (tid & 1) ? min(tile_x * TW + TW - 1, a.W - 1) : tile_x * TW;
+      const int cy = (tid & 2) ? min(tile_y * TH + TH - 1, a.H - 1) : tile_y * TH;
+      const int dl = (tid & 4) ? j_hi : j_lo;
+      sweep_position(Hm, ktd_m + dl * 3, static_cast<float>(cx), static_cast<float>(cy), a.W, a.H, &ix, &iy, &z);
+    }
+    float lo_x = ix, hi_x = ix, lo_y = iy, hi_y = iy, lo_z = z;
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) {
+      lo_x = fminf(lo_x, __shfl_xor(lo_x, off, 8));
+      hi_x = fmaxf(hi_x, __shfl_xor(hi_x, off, 8));
+      lo_y = fminf(lo_y, __shfl_xor(lo_y, off, 8));
+      hi_y = fmaxf(hi_y, __shfl_xor(hi_y, off, 8));
+      lo_z = fminf(lo_z, __shfl_xor(lo_z, off, 8));
+    }
+    if (tid == 0) {
+      // NaN-safe: every comparison below is false for NaN, which leaves state == 0
+      const bool finite = (lo_x > -1e6f) && (hi_x < 1e6f) && (lo_y > -1e6f) && (hi_y < 1e6f) && (lo_z > 1e-6f);
+      int state = 0, x_lo = 0, y_lo = 0, RW = 0, RH = 0;
+      if (finite) {
+        // 0.05 px of slack for round-off between the corner samples and interior pixels; one apron pixel outside the
+        // image is enough, everything further out is zero as well
+        x_lo = max(-1, static_cast<int>(floorf(lo_x - 0.05f)));
+        y_lo = max(-1, static_cast<int>(floorf(lo_y - 0.05f)));
+        const int x_hi = min(a.W, static_cast<int>(floorf(hi_x + 0.05f)) + 1);
+        const int y_hi = min(a.H, static_cast<int>(floorf(hi_y + 0.05f)) + 1);
+        RW = x_hi - x_lo + 1;
+        RH = y_hi - y_lo + 1;
+        if (RW <= 0 || RH <= 0) state = 2;
+        else if (RW * RH <= CAP) state = 1;
+      }
+      s_box[0] = x_lo; s_box[1] = y_lo; s_box[2] = RW; s_box[3] = RH; s_box[4] = state;
+    }
+  }
+  __syncthreads();
+}
+
+// NHWC: the measurement maps are channels-last ([B,H,W,C] in memory).  A box position's CCH channels are then 4*CCH
+// contiguous bytes (staging = plain 16-byte copies, no transposition through registers) and, more importantly, a gather
+// tap of the spill path is one cache line for all 32 channels instead of 32 lines.
+template <int TW, int TH, int DP, int CCH, int CAP, bool NHWC>
 __global__ __launch_bounds__(TW* TH) void cost_volume_tiled_kernel(CostVolumeArgs a) {
   using Cfg = TiledConfig<TW, TH, DP, CCH, CAP>;
   constexpr int NT = Cfg::kThreads;
+  constexpr int REC = Cfg::kRec;
+  typedef float float4v __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) float s_tile[];  // [CAP][kRec]
   __shared__ float s_H[DVMVS_MAX_MEASUREMENTS * 9];
   __shared__ float s_kt[DVMVS_MAX_MEASUREMENTS * 3];
   __shared__ float s_ktd[DVMVS_MAX_MEASUREMENTS * DP * 3];
-  __shared__ int s_box[5];  // x_lo, y_lo, RW, RH, usable
+  __shared__ int s_box[5];
 
   const int tiles_x = (a.W + TW - 1) / TW;
   const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
-  const int d_block = blockIdx.y * DP;
+  // Near planes first: their footprints are the large ones (parallax and magnification grow with inverse depth), so the
+  // workgroups most likely to spill to the gather path are dispatched first and the cheap far planes fill the tail.
+  const int d_block = (gridDim.y - 1 - blockIdx.y) * DP;
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
   sweep_setup(a, b, d_block, DP, tid, NT, s_H, s_kt, s_ktd);
@@ -144,6 +196,7 @@ __global__ __launch_bounds__(TW* TH) void cost_volume_tiled_kernel(CostVolumeArg
   const float xf = static_cast<float>(x), yf = static_cast<float>(y);
   const int pix = live ? y * a.W + x : 0;
   const int planes = min(DP, a.D - d_block);
+  const float* ref = a.image1 + static_cast<size_t>(b) * a.C * HW + pix;
 
   float fused[DP];
 #pragma unroll
@@ -151,171 +204,244 @@ __global__ __launch_bounds__(TW* TH) void cost_volume_tiled_kernel(CostVolumeArg
 
   for (int m = 0; m < a.M; ++m) {
     const float* Hm = s_H + m * 9;
-    // ---- bounding box of the tile's samples over this workgroup's planes (threads 0..7: corner x extreme plane) ----
-    if (tid < 64) {
-      float ix = 0.0f, iy = 0.0f, z = 1.0f;
-      if (tid < 8) {
-        const int cx = (tid & 1) ? min(tile_x * TW + TW - 1, a.W - 1) : tile_x * TW;
-        const int cy = (tid & 2) ? min(tile_y * TH + TH - 1, a.H - 1) : tile_y * TH;
-        const int dl = (tid & 4) ? planes - 1 : 0;
-        sweep_position(Hm, s_ktd + (m * DP + dl) * 3, static_cast<float>(cx), static_cast<float>(cy), a.W, a.H, &ix, &iy, &z);
-      }
-      float lo_x = ix, hi_x = ix, lo_y = iy, hi_y = iy, lo_z = z;
-#pragma unroll
-      for (int off = 4; off > 0; off >>= 1) {
-        lo_x = fminf(lo_x, __shfl_xor(lo_x, off, 8));
-        hi_x = fmaxf(hi_x, __shfl_xor(hi_x, off, 8));
-        lo_y = fminf(lo_y, __shfl_xor(lo_y, off, 8));
-        hi_y = fmaxf(hi_y, __shfl_xor(hi_y, off, 8));
-        lo_z = fminf(lo_z, __shfl_xor(lo_z, off, 8));
-      }
-      if (tid == 0) {
-        // NaN-safe: every comparison below is false for NaN, which leaves usable == 0
-        const bool finite = (lo_x > -1e6f) && (hi_x < 1e6f) && (lo_y > -1e6f) && (hi_y < 1e6f) && (lo_z > 1e-6f);
-        int usable = 0, x_lo = 0, y_lo = 0, RW = 0, RH = 0;
-        if (finite) {
-          // 0.05 px of slack for round-off between the corner samples and interior pixels; one apron pixel outside
-          // the image is enough, everything further out is zero as well
-          x_lo = max(-1, static_cast<int>(floorf(lo_x - 0.05f)));
-          y_lo = max(-1, static_cast<int>(floorf(lo_y - 0.05f)));
-          const int x_hi = min(a.W, static_cast<int>(floorf(hi_x + 0.05f)) + 1);
-          const int y_hi = min(a.H, static_cast<int>(floorf(hi_y + 0.05f)) + 1);
-          RW = x_hi - x_lo + 1;
-          RH = y_hi - y_lo + 1;
-          if (RW <= 0 || RH <= 0) {
-            usable = 2;  // the whole footprint lies outside the image: this frame contributes zeros
-          } else if (RW * RH <= CAP) {
-            usable = 1;
-          }
-        }
-        s_box[0] = x_lo; s_box[1] = y_lo; s_box[2] = RW; s_box[3] = RH; s_box[4] = usable;
-      }
-    }
-    __syncthreads();
-    const int x_lo = s_box[0], y_lo = s_box[1], RW = s_box[2], RH = s_box[3];
-    int usable = s_box[4];
-
-    // ---- this thread's taps: region-relative base offsets and weights, checked against the box ----
-    int base[DP];
-    float w_nw[DP], w_ne[DP], w_sw[DP], w_se[DP];
-    int violation = 0;
-    if (usable == 1) {
-#pragma unroll
-      for (int j = 0; j < DP; ++j) {
-        float ix, iy;
-        sweep_position(Hm, s_ktd + (m * DP + j) * 3, xf, yf, a.W, a.H, &ix, &iy);
-        const BilinearTaps t = make_taps(ix, iy, a.W, a.H);
-        // taps entirely outside [-1, W] x [-1, H] see only zeros; everything else must lie inside the staged box
-        const bool dead = (t.x0 < -1) || (t.x0 > a.W - 1) || (t.y0 < -1) || (t.y0 > a.H - 1) || (j >= planes) || !live;
-        const int rx = t.x0 - x_lo, ry = t.y0 - y_lo;
-        const bool inside = (rx >= 0) && (rx + 1 < RW) && (ry >= 0) && (ry + 1 < RH);
-        if (!dead && !inside) violation = 1;
-        const bool use = !dead && inside;
-        base[j] = use ? ry * RW + rx : 0;
-        w_nw[j] = use ? t.w_nw : 0.0f;
-        w_ne[j] = use ? t.w_ne : 0.0f;
-        w_sw[j] = use ? t.w_sw : 0.0f;
-        w_se[j] = use ? t.w_se : 0.0f;
-      }
-    }
-    if (__syncthreads_or(violation)) usable = 0;
-
-    if (usable == 2) continue;
-
+    const float* ktd_m = s_ktd + m * DP * 3;
+    const float* meas = a.image2[m] + static_cast<size_t>(b) * a.C * HW;
     float acc[DP];
 #pragma unroll
     for (int j = 0; j < DP; ++j) acc[j] = 0.0f;
-    const float* meas = a.image2[m] + static_cast<size_t>(b) * a.C * HW;
-    const float* ref = a.image1 + static_cast<size_t>(b) * a.C * HW + pix;
 
-    if (usable == 1) {
-      // ---- staging plan: each thread copies up to kSlots region elements per channel ----
-      const int RS = RW * RH;
-      int goff[Cfg::kSlots];
-      bool gin[Cfg::kSlots];
-#pragma unroll
-      for (int k = 0; k < Cfg::kSlots; ++k) {
-        const int r = tid + k * NT;
-        const int ry = r / RW, rx = r - ry * RW;
-        const int gx = x_lo + rx, gy = y_lo + ry;
-        gin[k] = (r < RS) && (gx >= 0) && (gx < a.W) && (gy >= 0) && (gy < a.H);
-        goff[k] = gin[k] ? gy * a.W + gx : 0;
-      }
-      constexpr int REC = Cfg::kRec;
-      typedef float float4v __attribute__((ext_vector_type(4)));
-      for (int c0 = 0; c0 < a.C; c0 += CCH) {
-        const int nch = min(CCH, a.C - c0);
-        // reference features of this pass: issued before the staging loads so their latency overlaps the copy
-        float rv[CCH];
-#pragma unroll
-        for (int c = 0; c < CCH; ++c) rv[c] = (c < nch) ? ref[static_cast<size_t>(c0 + c) * HW] : 0.0f;
-        // global (NCHW, coalesced along x) -> registers -> LDS records (transposed): all loads of a position are in
-        // flight before its CCH/4 ds_write_b128
-#pragma unroll
-        for (int k = 0; k < Cfg::kSlots; ++k) {
-          const int r = tid + k * NT;
-          float4v v[CCH / 4];
-#pragma unroll
-          for (int c = 0; c < CCH; ++c) {
-            const float* plane = meas + static_cast<size_t>(c0 + min(c, nch - 1)) * HW;
-            v[c / 4][c % 4] = (gin[k] && c < nch) ? plane[goff[k]] : 0.0f;
-          }
-          if (r < RS) {
-#pragma unroll
-            for (int q = 0; q < CCH / 4; ++q) *reinterpret_cast<float4v*>(s_tile + r * REC + q * 4) = v[q];
-          }
-        }
-        __syncthreads();
-        if (live) {
+    // The planes of this workgroup are processed in segments [seg_lo, seg_hi): normally one segment with all of them.
+    // When their common footprint does not fit the LDS budget (strong parallax: near planes under forward motion) the
+    // segment is halved, down to kMinStagedPlanes (4, which fits for 97 % of the workgroups on the reference's sample
+    // scene); a segment that still does not fit has no locality worth staging and takes the global-memory path with all
+    // of its planes in flight (16 gathers per channel, the generic kernel's structure).
+    constexpr int kMinStagedPlanes = DP < 4 ? DP : 4;
+    int seg_hint = DP;   // planes per segment that fitted last time: parallax per plane is uniform along the sweep
+    int seg_lo = 0;
+    while (seg_lo < planes) {
+      int seg_len = min(planes - seg_lo, seg_hint);
+      int state;
+      int base[DP];
+      float w_nw[DP], w_ne[DP], w_sw[DP], w_se[DP];
+      for (;;) {
+        publish_sample_box<TW, TH, DP, CAP>(a, Hm, ktd_m, tile_x, tile_y, seg_lo, seg_lo + seg_len - 1, tid, s_box);
+        state = s_box[4];
+        // this thread's taps: box-relative base offsets and weights, checked against the box
+        int violation = 0;
+        if (state == 1) {
+          const int x_lo = s_box[0], y_lo = s_box[1], RW = s_box[2], RH = s_box[3];
 #pragma unroll
           for (int j = 0; j < DP; ++j) {
-            const float* row0 = s_tile + base[j] * REC;
-            const float* row1 = row0 + RW * REC;
-            float sum = 0.0f;
-#pragma unroll
-            for (int q = 0; q < CCH / 4; ++q) {
-              const float4v nw = *reinterpret_cast<const float4v*>(row0 + q * 4);
-              const float4v ne = *reinterpret_cast<const float4v*>(row0 + REC + q * 4);
-              const float4v sw = *reinterpret_cast<const float4v*>(row1 + q * 4);
-              const float4v se = *reinterpret_cast<const float4v*>(row1 + REC + q * 4);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                float t = nw[e] * w_nw[j];
-                t += ne[e] * w_ne[j];
-                t += sw[e] * w_sw[j];
-                t += se[e] * w_se[j];
-                sum += rv[q * 4 + e] * t;   // rv == 0 for channels beyond nch
+            base[j] = 0;
+            w_nw[j] = w_ne[j] = w_sw[j] = w_se[j] = 0.0f;
+            if (j >= seg_lo && j < seg_lo + seg_len && live) {
+              float ix, iy;
+              sweep_position(Hm, ktd_m + j * 3, xf, yf, a.W, a.H, &ix, &iy);
+              const BilinearTaps t = make_taps(ix, iy, a.W, a.H);
+              // taps entirely outside [-1, W] x [-1, H] see only zeros; everything else must lie inside the staged box
+              const bool dead = (t.x0 < -1) || (t.x0 > a.W - 1) || (t.y0 < -1) || (t.y0 > a.H - 1);
+              const int rx = t.x0 - x_lo, ry = t.y0 - y_lo;
+              const bool inside = (rx >= 0) && (rx + 1 < RW) && (ry >= 0) && (ry + 1 < RH);
+              if (!dead && !inside) violation = 1;
+              if (!dead && inside) {
+                base[j] = ry * RW + rx;
+                w_nw[j] = t.w_nw; w_ne[j] = t.w_ne; w_sw[j] = t.w_sw; w_se[j] = t.w_se;
               }
             }
-            acc[j] += sum;
           }
         }
-        __syncthreads();
+        // (the barrier inside __syncthreads_or also orders this round's s_box reads before the next round's write)
+        if (__syncthreads_or(violation)) state = 0;
+        if (state != 0 || seg_len <= kMinStagedPlanes) break;
+        seg_len = max((seg_len + 1) / 2, kMinStagedPlanes);
       }
-    } else if (live) {
-      // ---- fallback: taps straight from global memory (same arithmetic as the generic kernel) ----
-      for (int j = 0; j < planes; ++j) {
-        float ix, iy;
-        sweep_position(Hm, s_ktd + (m * DP + j) * 3, xf, yf, a.W, a.H, &ix, &iy);
-        const BilinearTaps t = make_taps(ix, iy, a.W, a.H);
-        const int xa = t.in_x0 ? t.x0 : 0, xb = t.in_x1 ? t.x0 + 1 : 0;
-        const int ya = t.in_y0 ? t.y0 : 0, yb = t.in_y1 ? t.y0 + 1 : 0;
-        const float g0 = (t.in_x0 && t.in_y0) ? t.w_nw : 0.0f, g1 = (t.in_x1 && t.in_y0) ? t.w_ne : 0.0f;
-        const float g2 = (t.in_x0 && t.in_y1) ? t.w_sw : 0.0f, g3 = (t.in_x1 && t.in_y1) ? t.w_se : 0.0f;
-        float sum = 0.0f;
-        for (int c = 0; c < a.C; ++c) {
-          const float* plane = meas + static_cast<size_t>(c) * HW;
-          float s = plane[ya * a.W + xa] * g0;
-          s += plane[ya * a.W + xb] * g1;
-          s += plane[yb * a.W + xa] * g2;
-          s += plane[yb * a.W + xb] * g3;
-          sum += ref[static_cast<size_t>(c) * HW] * s;
-        }
-        // acc[] is indexed with a compile-time constant below, so select instead of indexing dynamically
+      seg_hint = max(seg_len, kMinStagedPlanes);
+      const int seg_hi = seg_lo + seg_len;
+
+      if (state == 1) {
+        const int x_lo = s_box[0], y_lo = s_box[1], RW = s_box[2], RH = s_box[3];
+        const int RS = RW * RH;
+        // staging plan.  NCHW: each thread copies up to kSlots box positions per pass (CCH dword loads each, transposed
+        // into the record).  NHWC: each thread copies up to kItems 16-byte pieces (position, channel quad) per pass.
+        constexpr int kItems = (CAP * (CCH / 4) + NT - 1) / NT;
+        constexpr int kPlan = NHWC ? kItems : Cfg::kSlots;
+        int goff[kPlan];   // element offset into the measurement map, -1 = outside the image (zero apron) or past the box
 #pragma unroll
-        for (int jj = 0; jj < DP; ++jj)
-          if (jj == j) acc[jj] = sum;
+        for (int k = 0; k < kPlan; ++k) {
+          const int item = tid + k * NT;
+          const int r = NHWC ? item / (CCH / 4) : item;
+          const int ry = r / RW, rx = r - ry * RW;
+          const int gx = x_lo + rx, gy = y_lo + ry;
+          const bool in = (r < RS) && (gx >= 0) && (gx < a.W) && (gy >= 0) && (gy < a.H);
+          goff[k] = in ? (NHWC ? (gy * a.W + gx) * a.C + (item % (CCH / 4)) * 4 : gy * a.W + gx) : -1;
+        }
+        for (int c0 = 0; c0 < a.C; c0 += CCH) {
+          const int nch = min(CCH, a.C - c0);
+          // reference features of this pass: issued before the staging loads so their latency overlaps the copy
+          float rv[CCH];
+#pragma unroll
+          for (int c = 0; c < CCH; ++c) rv[c] = (c < nch) ? ref[static_cast<size_t>(c0 + c) * HW] : 0.0f;
+          if (NHWC) {
+            // kStageBatch 16-byte loads in flight, then their ds_write_b128s (channels beyond C are never read: rv == 0)
+            constexpr int kStageBatch = 4;
+#pragma unroll
+            for (int k0 = 0; k0 < kPlan; k0 += kStageBatch) {
+              float4v v[kStageBatch];
+#pragma unroll
+              for (int kk = 0; kk < kStageBatch; ++kk) {
+                const int k = k0 + kk;
+                v[kk] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+                if (k < kPlan) {
+                  const int item = tid + k * NT;
+                  if (goff[k < kPlan ? k : 0] >= 0 && c0 + (item % (CCH / 4)) * 4 < a.C)
+                    v[kk] = *reinterpret_cast<const float4v*>(meas + goff[k < kPlan ? k : 0] + c0);
+                }
+              }
+#pragma unroll
+              for (int kk = 0; kk < kStageBatch; ++kk) {
+                const int item = tid + (k0 + kk) * NT;
+                if (k0 + kk < kPlan && item < RS * (CCH / 4))
+                  *reinterpret_cast<float4v*>(s_tile + (item / (CCH / 4)) * REC + (item % (CCH / 4)) * 4) = v[kk];
+              }
+            }
+          } else {
+            // global (NCHW, coalesced along x) -> registers -> LDS records (transposed): all loads of a position are in
+            // flight before its CCH/4 ds_write_b128
+#pragma unroll
+            for (int k = 0; k < kPlan; ++k) {
+              const int r = tid + k * NT;
+              float4v v[CCH / 4];
+#pragma unroll
+              for (int c = 0; c < CCH; ++c) {
+                const float* plane = meas + static_cast<size_t>(c0 + min(c, nch - 1)) * HW;
+                v[c / 4][c % 4] = (goff[k] >= 0 && c < nch) ? plane[goff[k]] : 0.0f;
+              }
+              if (r < RS) {
+#pragma unroll
+                for (int q = 0; q < CCH / 4; ++q) *reinterpret_cast<float4v*>(s_tile + r * REC + q * 4) = v[q];
+              }
+            }
+          }
+          __syncthreads();
+          if (live) {
+#pragma unroll
+            for (int j = 0; j < DP; ++j) {
+              if (j >= seg_lo && j < seg_hi) {   // workgroup-uniform
+                const float* row0 = s_tile + base[j] * REC;
+                const float* row1 = row0 + RW * REC;
+                float sum = 0.0f;
+#pragma unroll
+                for (int q = 0; q < CCH / 4; ++q) {
+                  const float4v nw = *reinterpret_cast<const float4v*>(row0 + q * 4);
+                  const float4v ne = *reinterpret_cast<const float4v*>(row0 + REC + q * 4);
+                  const float4v sw = *reinterpret_cast<const float4v*>(row1 + q * 4);
+                  const float4v se = *reinterpret_cast<const float4v*>(row1 + REC + q * 4);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    float t = nw[e] * w_nw[j];
+                    t += ne[e] * w_ne[j];
+                    t += sw[e] * w_sw[j];
+                    t += se[e] * w_se[j];
+                    sum += rv[q * 4 + e] * t;   // rv == 0 for channels beyond nch
+                  }
+                }
+                acc[j] += sum;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      } else if (state == 0 && live) {
+        // Footprint cannot be staged: taps straight from global memory.  The gathers are scattered (a different cache
+        // line per lane and channel), so what matters is memory-level parallelism: two planes x four taps x eight
+        // channels = 64 independent loads are issued before the first use, which cuts the dependent-latency chain of a
+        // segment to (planes / 2) * (C / 8) steps.
+        constexpr int kPair = 2, kChan = 4;
+        for (int j0 = seg_lo; j0 < seg_hi; j0 += kPair) {
+          int off[kPair][4];
+          float wgt[kPair][4], part[kPair];
+#pragma unroll
+          for (int u = 0; u < kPair; ++u) {
+            const int j = min(j0 + u, seg_hi - 1);
+            float ix, iy;
+            sweep_position(Hm, ktd_m + j * 3, xf, yf, a.W, a.H, &ix, &iy);
+            const BilinearTaps t = make_taps(ix, iy, a.W, a.H);
+            const int xa = t.in_x0 ? t.x0 : 0, xb = t.in_x1 ? t.x0 + 1 : 0;
+            const int ya = t.in_y0 ? t.y0 : 0, yb = t.in_y1 ? t.y0 + 1 : 0;
+            const int es = NHWC ? a.C : 1;   // elements per pixel step
+            off[u][0] = (ya * a.W + xa) * es; off[u][1] = (ya * a.W + xb) * es;
+            off[u][2] = (yb * a.W + xa) * es; off[u][3] = (yb * a.W + xb) * es;
+            const bool on = j0 + u < seg_hi;
+            wgt[u][0] = (on && t.in_x0 && t.in_y0) ? t.w_nw : 0.0f;
+            wgt[u][1] = (on && t.in_x1 && t.in_y0) ? t.w_ne : 0.0f;
+            wgt[u][2] = (on && t.in_x0 && t.in_y1) ? t.w_sw : 0.0f;
+            wgt[u][3] = (on && t.in_x1 && t.in_y1) ? t.w_se : 0.0f;
+            part[u] = 0.0f;
+          }
+          // under strong magnification most pixels sample outside the image: a wave whose 64 pixels are all dead for
+          // this plane pair skips its channel loop (wave-uniform branch)
+          float any_w = 0.0f;
+#pragma unroll
+          for (int u = 0; u < kPair; ++u) any_w += wgt[u][0] + wgt[u][1] + wgt[u][2] + wgt[u][3];
+          if (!__any(any_w != 0.0f)) {
+            // contributes zeros; acc[] entries stay 0
+          } else if (NHWC) {
+            // one 16-byte load per (plane, tap, channel quad): 8 loads (32 values) in flight per step; the eight quads of
+            // a tap share one 128-byte line, so only the first step of a plane pair misses
+            for (int cq = 0; cq < a.C; cq += 4) {
+              float4v v[kPair][4];
+              float r[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) r[e] = ref[static_cast<size_t>(cq + e) * HW];
+#pragma unroll
+              for (int u = 0; u < kPair; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[u][t] = *reinterpret_cast<const float4v*>(meas + off[u][t] + cq);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int u = 0; u < kPair; ++u) {
+                  float t = v[u][0][e] * wgt[u][0];
+                  t += v[u][1][e] * wgt[u][1];
+                  t += v[u][2][e] * wgt[u][2];
+                  t += v[u][3][e] * wgt[u][3];
+                  part[u] += r[e] * t;
+                }
+            }
+          } else {
+            for (int c0 = 0; c0 < a.C; c0 += kChan) {
+              float v[kChan][kPair][4], r[kChan];
+#pragma unroll
+              for (int cc = 0; cc < kChan; ++cc) {
+                const int c = min(c0 + cc, a.C - 1);
+                const float* plane = meas + static_cast<size_t>(c) * HW;
+                r[cc] = (c0 + cc < a.C) ? ref[static_cast<size_t>(c) * HW] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < kPair; ++u)
+#pragma unroll
+                  for (int t = 0; t < 4; ++t) v[cc][u][t] = plane[off[u][t]];
+              }
+#pragma unroll
+              for (int cc = 0; cc < kChan; ++cc)
+#pragma unroll
+                for (int u = 0; u < kPair; ++u) {
+                  float t = v[cc][u][0] * wgt[u][0];
+                  t += v[cc][u][1] * wgt[u][1];
+                  t += v[cc][u][2] * wgt[u][2];
+                  t += v[cc][u][3] * wgt[u][3];
+                  part[u] += r[cc] * t;
+                }
+            }
+          }
+#pragma unroll
+          for (int jj = 0; jj < DP; ++jj)   // compile-time indexed select keeps acc[] in registers
+#pragma unroll
+            for (int u = 0; u < kPair; ++u)
+              if (jj == j0 + u && jj < seg_hi) acc[jj] = part[u];
+        }
       }
+      // state == 2: the whole footprint of the segment lies outside the image -> zeros
+      seg_lo = seg_hi;
     }
 #pragma unroll
     for (int j = 0; j < DP; ++j) fused[j] += acc[j] / static_cast<float>(a.C);
@@ -329,10 +455,10 @@ __global__ __launch_bounds__(TW* TH) void cost_volume_tiled_kernel(CostVolumeArg
   }
 }
 
-template <int TW, int TH, int DP, int CCH, int CAP>
-int launch_cost_volume_tiled(const CostVolumeArgs& a, hipStream_t stream) {
+template <int TW, int TH, int DP, int CCH, int CAP, bool NHWC>
+int launch_cost_volume_tiled_layout(const CostVolumeArgs& a, hipStream_t stream) {
   using Cfg = TiledConfig<TW, TH, DP, CCH, CAP>;
-  auto kernel = cost_volume_tiled_kernel<TW, TH, DP, CCH, CAP>;
+  auto kernel = cost_volume_tiled_kernel<TW, TH, DP, CCH, CAP, NHWC>;
   static bool configured = false;  // raising the dynamic-LDS limit is idempotent; racing threads set the same value
   if (!configured) {
     DVMVS_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -343,6 +469,12 @@ int launch_cost_volume_tiled(const CostVolumeArgs& a, hipStream_t stream) {
   dim3 grid(tiles, (a.D + DP - 1) / DP, a.B), block(Cfg::kThreads);
   hipLaunchKernelGGL(kernel, grid, block, Cfg::kLdsBytes, stream, a);
   return launch_status();
+}
+
+template <int TW, int TH, int DP, int CCH, int CAP>
+int launch_cost_volume_tiled(const CostVolumeArgs& a, hipStream_t stream) {
+  if (a.image2_nhwc) return launch_cost_volume_tiled_layout<TW, TH, DP, CCH, CAP, true>(a, stream);
+  return launch_cost_volume_tiled_layout<TW, TH, DP, CCH, CAP, false>(a, stream);
 }
 
 // One thread per (batch, measurement frame): the matrices above into the caller's workspace, so that the sweep
@@ -371,14 +503,18 @@ extern "C" size_t dvmvs_cost_volume_workspace_bytes(int B, int M) {
 extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, const float* pose1,
                                      const float* const* pose2s, const float* K, float* cost_volume,
                                      int B, int M, int C, int H, int W, int D,
-                                     double min_depth, double max_depth, int dot_product, int variant,
+                                     double min_depth, double max_depth, int dot_product, int variant, int image2_layout,
                                      float* workspace, size_t workspace_bytes, dvmvs_stream_t stream) {
   using namespace dvmvs;
+  if (image2_layout != DVMVS_LAYOUT_NCHW && image2_layout != DVMVS_LAYOUT_NHWC) return DVMVS_EINVAL;
   if (variant < 0 || (variant > 2 && variant < 16) || variant > 31) return DVMVS_EINVAL;
   if (variant == 2 && !dot_product) return DVMVS_EUNSUPPORTED;
   CostVolumeArgs a;
   const int rc = fill_sweep_args(&a, image1, image2s, pose1, pose2s, K, cost_volume, B, M, C, H, W, D, min_depth, max_depth, true);
   if (rc != 0) return rc;
+  a.image2_nhwc = image2_layout == DVMVS_LAYOUT_NHWC ? 1 : 0;
+  // channels-last measurement maps are understood by the LDS-tiled dot-product kernel only (16-byte channel quads)
+  if (a.image2_nhwc && (!dot_product || variant == 1 || C % 4 != 0 || H * W < 64 * 64)) return DVMVS_EUNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (workspace != nullptr) {
     if (workspace_bytes < dvmvs_cost_volume_workspace_bytes(B, M)) return DVMVS_EINVAL;
@@ -406,7 +542,7 @@ extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* im
       default: return DVMVS_EINVAL;
     }
   }
-  const bool tiled = dot_product && (variant == 2 || (variant == 0 && H * W >= 64 * 64));
+  const bool tiled = dot_product && (variant == 2 || a.image2_nhwc || (variant == 0 && H * W >= 64 * 64));
   if (tiled) return launch_cost_volume_tiled<32, 8, 8, 16, 640>(a, s);
   return launch_cost_volume_generic(a, dot_product != 0, s);
 }

@@ -42,6 +42,9 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ x, co
 //   src = dst * (in - 1) / (out - 1);  i0 = int(src);  l1 = src - i0;  l0 = 1 - l1
 //   out = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11)
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int H, int W) {
+  // No FMA contraction: the fractional weight must come from the ROUNDED product sh * oy, the same value whose integer part
+  // selects the tap (ATen does exactly that); fma(sh, oy, -y0) would mix a rounded index with an unrounded fraction.
+#pragma clang fp contract(off)
   const int OH = 2 * H, OW = 2 * W;
   const float sh = OH > 1 ? static_cast<float>(H - 1) / static_cast<float>(OH - 1) : 0.0f;
   const float sw = OW > 1 ? static_cast<float>(W - 1) / static_cast<float>(OW - 1) : 0.0f;

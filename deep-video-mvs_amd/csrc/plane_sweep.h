@@ -15,6 +15,7 @@ struct CostVolumeArgs {
   float* out;
   int B, M, C, H, W, D;
   double inv_depth_base, inv_depth_step;
+  int image2_nhwc;     // measurement maps are channels-last ([B,H,W,C]); reference map and output stay NCHW
   const float* setup;  // optional [B][M][12]: Hm (9) + kt (3) written by sweep_setup_kernel; nullptr = derive per workgroup
 };
 
@@ -111,6 +112,7 @@ inline int fill_sweep_args(CostVolumeArgs* a, const float* image1, const float* 
   a->inv_depth_base = 1.0 / max_depth;
   a->inv_depth_step = D > 1 ? (1.0 / min_depth - 1.0 / max_depth) / (D - 1) : 0.0;
   a->setup = nullptr;
+  a->image2_nhwc = 0;
   return 0;
 }
 

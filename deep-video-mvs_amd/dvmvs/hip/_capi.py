@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("DVMVS_HIP_LIB", os.path.normpath(os.path.join(_HERE, 
 ABI_VERSION = 1
 MAX_MEASUREMENTS = 8
 MAX_DEPTH_LEVELS = 256
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 
 _c_fp = ctypes.c_void_p          # device pointer to float
 _c_fpp = ctypes.POINTER(ctypes.c_void_p)  # host array of device pointers
@@ -34,7 +35,7 @@ SIGNATURES = {
     "dvmvs_cost_volume_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
     "dvmvs_cost_volume_fwd": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fpp, _c_fp, _c_fp,
                                        _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                       _c_dbl, _c_dbl, _c_int, _c_int, _c_fp, ctypes.c_size_t, _c_stream]),
+                                       _c_dbl, _c_dbl, _c_int, _c_int, _c_int, _c_fp, ctypes.c_size_t, _c_stream]),
     "dvmvs_cost_volume_bwd": (_c_int, [_c_fp, _c_fp, _c_fpp, _c_fp, _c_fpp, _c_fp, _c_fp, _c_fpp,
                                        _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                        _c_dbl, _c_dbl, _c_stream]),

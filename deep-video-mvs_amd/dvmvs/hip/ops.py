@@ -48,14 +48,18 @@ def cost_volume(image1: Tensor, image2s: Sequence[Tensor], pose1: Tensor, pose2s
     if M == 0 or M != len(pose2s):
         raise ValueError("dvmvs::cost_volume: need as many measurement poses as measurement feature maps (>= 1)")
     B, C, H, W = image1.shape
-    image1 = image1.contiguous()
-    image2s = [t.contiguous() for t in image2s]
-    pose1 = pose1.contiguous()
-    pose2s = [t.contiguous() for t in pose2s]
-    K = K.contiguous()
     for t in image2s:
         if t.shape != image1.shape:
             raise ValueError(f"dvmvs::cost_volume: measurement features {tuple(t.shape)} != reference {tuple(image1.shape)}")
+    image1 = image1.contiguous()
+    # Measurement maps that are already channels-last in memory (the frame engine caches them that way) are passed as NHWC;
+    # anything else is made NCHW-contiguous, the reference's layout.
+    nhwc_ok = bool(dot_product) and variant != 1 and C % 4 == 0 and C > 1 and H * W >= 64 * 64
+    nhwc = nhwc_ok and all(t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous() for t in image2s)
+    image2s = list(image2s) if nhwc else [t.contiguous() for t in image2s]
+    pose1 = pose1.contiguous()
+    pose2s = [t.contiguous() for t in pose2s]
+    K = K.contiguous()
     out = torch.empty((B, n_depth_levels, H, W), dtype=torch.float32, device=image1.device)
     lib = _capi.lib()
     ws_bytes = lib.dvmvs_cost_volume_workspace_bytes(B, M)
@@ -65,7 +69,7 @@ def cost_volume(image1: Tensor, image2s: Sequence[Tensor], pose1: Tensor, pose2s
             _ptr(image1), _capi.pointer_array([_ptr(t) for t in image2s]), _ptr(pose1),
             _capi.pointer_array([_ptr(t) for t in pose2s]), _ptr(K), _ptr(out),
             B, M, C, H, W, n_depth_levels, float(min_depth), float(max_depth), int(bool(dot_product)), int(variant),
-            _ptr(workspace), ws_bytes, _stream(image1))
+            _capi.LAYOUT_NHWC if nhwc else _capi.LAYOUT_NCHW, _ptr(workspace), ws_bytes, _stream(image1))
     _capi.check(rc, "dvmvs_cost_volume_fwd")
     return out
 

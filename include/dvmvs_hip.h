@@ -28,6 +28,9 @@ extern "C" {
 #define DVMVS_MAX_MEASUREMENTS 8      /* measurement frames fused per launch */
 #define DVMVS_MAX_DEPTH_LEVELS 256    /* sweep planes per launch */
 
+#define DVMVS_LAYOUT_NCHW 0           /* [B,C,H,W] contiguous: the reference's layout */
+#define DVMVS_LAYOUT_NHWC 1           /* [B,H,W,C] contiguous ("channels last") */
+
 #define DVMVS_EINVAL (-1)             /* null pointer / non-positive dimension / out-of-range count */
 #define DVMVS_EUNSUPPORTED (-2)       /* shape outside what the kernels were built for */
 
@@ -52,6 +55,11 @@ const char* dvmvs_error_string(int code);
  *   dot_product 1: sum_c(f1*warp(f2))/C   0: sum_c|f1-warp(f2)|  (utils.py:81-84); result is the mean over M
  *   variant     0 = pick the fastest kernel for the shape; 1 = force the generic reference-order kernel (taps through
  *               the vector L1); 2 = force the LDS-tiled kernel (dot_product only)
+ *   image2_layout DVMVS_LAYOUT_NCHW, or DVMVS_LAYOUT_NHWC when the MEASUREMENT maps are stored channels-last (a keyframe's
+ *               features are reused as measurement features by later frames, so a runner converts them once per
+ *               keyframe): a bilinear tap is then one 128-byte line for all 32 channels, which is what keeps the kernel
+ *               fast on wide-baseline / forward-motion pairs whose sample footprint does not fit in LDS.  Supported by the
+ *               LDS-tiled dot-product kernel (C % 4 == 0, H*W >= 4096); image1 and cost_volume are always NCHW.
  *   workspace   optional device scratch of dvmvs_cost_volume_workspace_bytes(B, M) bytes.  When given, the 3x3
  *               homography K R K^-1 and K t of utils.py:51-56 are evaluated once by a one-workgroup set-up launch and
  *               read by the sweep kernel; when NULL every workgroup of the sweep kernel derives them itself (one
@@ -61,7 +69,7 @@ size_t dvmvs_cost_volume_workspace_bytes(int B, int M);
 int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, const float* pose1,
                           const float* const* pose2s, const float* K, float* cost_volume,
                           int B, int M, int C, int H, int W, int D,
-                          double min_depth, double max_depth, int dot_product, int variant,
+                          double min_depth, double max_depth, int dot_product, int variant, int image2_layout,
                           float* workspace, size_t workspace_bytes, dvmvs_stream_t stream);
 
 /*

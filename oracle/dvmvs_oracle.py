@@ -145,16 +145,38 @@ def cost_volume(image1: Tensor, image2: Tensor, pose1: Tensor, pose2: Tensor, K:
     return out
 
 
+def cost_volume_planewise(image1: Tensor, image2: Tensor, pose1: Tensor, pose2: Tensor, K: Tensor,
+                          min_depth: float, max_depth: float, n_depth_levels: int, dot_product: bool = True) -> Tensor:
+    """Same result as ``cost_volume`` computed plane by plane with torch's own ``grid_sample`` -- the efficient way to run
+    this op on a CPU (one fused bilinear kernel per plane instead of four index gathers), used for the ``cpu_baseline`` leg
+    of bench.py so that the CPU number is not handicapped by the oracle's vectorised-gather formulation.
+    Loop structure as in /root/reference/dvmvs/utils.py:65-84; tests assert it equals ``cost_volume``."""
+    B, C, H, W = image1.shape
+    dt = image1.dtype
+    KRKinv, Kt = plane_sweep_setup(pose1, pose2, K)
+    base = KRKinv @ pixel_grid(W, H, dt).unsqueeze(0)
+    out = torch.empty(B, n_depth_levels, H, W, dtype=dt)
+    for i, depth in enumerate(plane_depths(min_depth, max_depth, n_depth_levels)):
+        warp = (base + Kt / depth).transpose(1, 2)
+        uv = warp[:, :, 0:2] / (warp[:, :, 2:3] + 1e-8)
+        grid = torch.stack([(uv[..., 0] - W / 2.0) / (W / 2.0), (uv[..., 1] - H / 2.0) / (H / 2.0)], dim=-1).view(B, H, W, 2)
+        warped = torch.nn.functional.grid_sample(image2, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+        out[:, i] = (image1 * warped).sum(dim=1) / C if dot_product else (image1 - warped).abs().sum(dim=1)
+    return out
+
+
 def cost_volume_fusion(image1: Tensor, image2s: Sequence[Tensor], pose1: Tensor, pose2s: Sequence[Tensor], K: Tensor,
-                       min_depth: float, max_depth: float, n_depth_levels: int, dot_product: bool = True) -> Tensor:
+                       min_depth: float, max_depth: float, n_depth_levels: int, dot_product: bool = True,
+                       planewise: bool = False) -> Tensor:
     """Mean of ``cost_volume`` over the measurement frames (sum, then one division).
 
     /root/reference/dvmvs/utils.py:89-107.
     """
     B, C, H, W = image1.shape
     fused = torch.zeros(B, n_depth_levels, H, W, dtype=image1.dtype)
+    one = cost_volume_planewise if planewise else cost_volume
     for image2, pose2 in zip(image2s, pose2s):
-        fused = fused + cost_volume(image1, image2, pose1, pose2, K, min_depth, max_depth, n_depth_levels, dot_product)
+        fused = fused + one(image1, image2, pose1, pose2, K, min_depth, max_depth, n_depth_levels, dot_product)
     return fused / len(pose2s)
 
 

@@ -14,13 +14,14 @@ import dvmvs_oracle as orc
 
 class CpuDepthPipeline:
     def __init__(self, feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder,
-                 min_depth=0.25, max_depth=20.0, n_depth_levels=64):
+                 min_depth=0.25, max_depth=20.0, n_depth_levels=64, planewise_cost_volume=False):
         self.fe, self.fs, self.enc, self.lstm, self.dec = (feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion,
                                                            cost_volume_decoder)
         for m in (self.fe, self.fs, self.enc, self.lstm, self.dec):
             if m is not None:
                 m.eval()
         self.depth_range = (min_depth, max_depth, n_depth_levels)
+        self.planewise = planewise_cost_volume   # bench.py: the per-plane grid_sample formulation is the fast one on CPUs
         self.stage_seconds = {}
         self.reset()
 
@@ -45,7 +46,7 @@ class CpuDepthPipeline:
         meas_half = self._timed("features", lambda: [self.fs(*self.fe(img))[0] for img in measurement_images])
         ref_feats = self._timed("features", lambda: self.fs(*self.fe(reference_image)))
         cv = self._timed("cost_volume", lambda: orc.cost_volume_fusion(ref_feats[0], meas_half, reference_pose, measurement_poses,
-                                                                        half_K, lo, hi, D, True))
+                                                                        half_K, lo, hi, D, True, planewise=self.planewise))
         skip0, skip1, skip2, skip3, bottom = self._timed("encoder", lambda: self.enc(*ref_feats, cv))
         de = None
         if self.lstm is not None:

@@ -54,7 +54,7 @@ def test_argument_validation_without_gpu(library):
     assert lib.dvmvs_lstm_gates_fwd(null, null, null, null, 1, 512, 8, 10, null) == -1
     assert lib.dvmvs_hidden_warp_fwd(null, null, null, null, null, 1, 512, 8, 10, 1, null) == -1
     arr = library.pointer_array([None])
-    assert lib.dvmvs_cost_volume_fwd(null, arr, null, arr, null, null, 1, 1, 32, 128, 160, 64, 0.25, 20.0, 1, 0, null, 0, null) == -1
+    assert lib.dvmvs_cost_volume_fwd(null, arr, null, arr, null, null, 1, 1, 32, 128, 160, 64, 0.25, 20.0, 1, 0, 0, null, 0, null) == -1
     assert lib.dvmvs_cost_volume_workspace_bytes(2, 3) == 2 * 3 * 12 * 4
 
 

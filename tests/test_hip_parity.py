@@ -187,6 +187,25 @@ def test_cost_volume_properties_full_size(ops, dev, variant):
     assert maxerr(same[:, 17], (f[0] * warped).sum(1) / 32) < 2e-5
 
 
+def test_cost_volume_channels_last_measurement_maps(ops, dev):
+    """DVMVS_LAYOUT_NHWC: measurement maps handed over channels-last give the same volume as NCHW ones (staged and
+    spill paths: the second geometry has tiles whose footprint does not fit in LDS)."""
+    halfK = syn.scaled_K(syn.full_K(), 2.0)
+    f = [syn.smooth_noise((2, 32, 128, 160), seed=70 + i) for i in range(3)]
+    for (r, ms) in ((9, (6, 0)), (202, (196, 188)), (141, (135, 130))):
+        p1 = torch.cat([syn.pose(r), syn.pose(r)])
+        p2s = [torch.cat([syn.pose(m), syn.pose(max(m - 1, 0))]) for m in ms]
+        K = torch.cat([halfK, halfK])
+        nchw = ops.cost_volume(f[0].to(dev), [t.to(dev) for t in f[1:]], p1.to(dev), [p.to(dev) for p in p2s], K.to(dev), 0.25, 20.0, 64, True, 2)
+        cl = [t.to(dev).contiguous(memory_format=torch.channels_last) for t in f[1:]]
+        assert all(not t.is_contiguous() for t in cl)
+        nhwc = ops.cost_volume(f[0].to(dev), cl, p1.to(dev), [p.to(dev) for p in p2s], K.to(dev), 0.25, 20.0, 64, True, 0)
+        assert maxerr(nhwc, nchw) < 1e-6
+        exp = orc.cost_volume_fusion(f[0][:1], [t[:1] for t in f[1:]], p1[:1], [p[:1] for p in p2s], K[:1], 0.25, 20.0, 64, True)
+        exp64 = orc.cost_volume_fusion(*f64(f[0][:1], [t[:1] for t in f[1:]], p1[:1], [p[:1] for p in p2s], K[:1]), 0.25, 20.0, 64, True)
+        as_accurate_as_reference(nhwc[:1], exp, exp64, floor=1e-5)
+
+
 def test_cost_volume_surface_and_errors(utils, dev):
     halfK = syn.scaled_K(syn.full_K(), 2.0)
     f = [syn.analytic_features(s, 8, 32, 40) for s in range(2)]
@@ -423,7 +442,8 @@ def test_upsample2x_matches_aten(ops, dev):
         got = ops.upsample2x(x.to(dev))
         exp = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
         assert tuple(got.shape) == tuple(exp.shape)
-        assert maxerr(got, exp) < 5e-6 * max(1.0, exp.abs().max().item()), shape   # same formula, different FMA contraction
+        err = maxerr(got, exp)
+        assert err < 5e-6 * max(1.0, exp.abs().max().item()), (shape, err)   # same formula, different FMA contraction
 
 
 def test_fused_modules_match_plain_modules(dev):

@@ -132,3 +132,13 @@ def test_lstm_goldens(golden_dir):
     assert abs(cn.double().abs().sum().item() - 33620.061688) < 0.05
     assert (hn - torch.from_numpy(z["kat_h"])).abs().max().item() < 2e-5
     assert (cn - torch.from_numpy(z["kat_c"])).abs().max().item() < 2e-5
+
+
+def test_planewise_cost_volume_equals_gather_formulation():
+    """The grid_sample-per-plane variant timed as cpu_baseline is the same function as the oracle proper."""
+    K = syn.scaled_K(syn.full_K(), 4.0)
+    f = [syn.smooth_noise((1, 16, 64, 80), seed=s) for s in (1, 2, 3)]
+    for dot in (True, False):
+        a = orc.cost_volume_fusion(f[0], f[1:], syn.pose(9), [syn.pose(6), syn.pose(141)], K, 0.25, 20.0, 32, dot)
+        b = orc.cost_volume_fusion(f[0], f[1:], syn.pose(9), [syn.pose(6), syn.pose(141)], K, 0.25, 20.0, 32, dot, planewise=True)
+        assert (a - b).abs().max().item() < (1e-6 if dot else 1e-5)
