@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
-    ap.add_argument("--kernel-reps", type=int, default=20)
+    ap.add_argument("--kernel-reps", type=int, default=10)
     ap.add_argument("--stage-times", action="store_true", help="also print eager per-stage GPU times to stderr")
     ap.add_argument("--mark-region", action="store_true",
                     help="bracket the timed loop with a cumsum kernel so tools/summarize_trace.py can cut it out of a rocprofv3 trace")
@@ -272,7 +272,8 @@ def main():
             kernel_s, alg_bytes, per_geometry = float("nan"), (1 + M) * 32 * 128 * 160 * 4 + 64 * 128 * 160 * 4, []
         else:
             first = M + args.warmup
-            sample = [first + (i * max(args.steps - 1, 1)) // 7 for i in range(8)]
+            n_geo = min(25, args.steps)
+            sample = [first + (i * max(args.steps - 1, 1)) // max(n_geo - 1, 1) for i in range(n_geo)]
             pose_sets = [seq[j] for j in sample]
             kernel_s, alg_bytes, per_geometry = measure_cost_volume_kernel(engine, M, args.kernel_reps, pose_sets)
         achieved = alg_bytes / kernel_s / 1e9
