@@ -1,0 +1,156 @@
+"""Data-parallel fusionnet training step (BASELINE.json configs[4]): forward over an 8-frame sub-sequence, L1 loss on
+inverse depth at five scales, backward through the HIP ops, one bucketed gradient all-reduce over RCCL/xGMI.
+
+The forward follows /root/reference/dvmvs/fusionnet/run-training.py:184-284 (features of all frames first; frame i uses
+frame i-1 as its single measurement frame; the hidden state is warped with the *ground-truth* depth, nearest /32; the
+warp is executed for every step including the first) and the loss follows /root/reference/dvmvs/losses.py:48-80 with
+``loss_type = "L1-inv"`` and unit weights.  Batch-norm statistics stay per GPU, exactly like the single-GPU reference at
+the same per-device batch.
+
+Communication design for MI355X: gradients live in a few large flat fp32 buckets (default 32 MB; parameters are 138.7 MB in
+the last unfreezing stage) and ``param.grad`` tensors are views into them, so autograd accumulates straight into the
+communication buffer; a bucket's all-reduce is launched (asynchronously, on RCCL's stream) from a post-accumulate hook
+as soon as its last gradient lands, overlapping the rest of backward.  xGMI is point-to-point, so fewer, larger
+collectives beat many small ones; nothing else on this path communicates.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from dvmvs.config import Config
+from dvmvs.utils import calculate_cost_volume_by_warping, get_warp_grid_for_cost_volume_calculation
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# loss
+# ----------------------------------------------------------------------------------------------------------------------
+def inverse_depth_l1(prediction, groundtruth):
+    """Sum over valid pixels of |1/gt - 1/pred| and the number of valid pixels; ``groundtruth`` is nearest-resized to
+    the prediction's resolution and pixels with gt == 0 are invalid (losses.py:48-80)."""
+    b, h, w = prediction.shape
+    gt = F.interpolate(groundtruth.view(b, 1, *groundtruth.shape[-2:]), size=(h, w), mode="nearest").view(b, h, w)
+    valid = gt != 0
+    count = valid.sum()
+    diff = (1.0 / gt[valid] - 1.0 / prediction[valid]).abs().sum()
+    return diff, count
+
+
+def multi_scale_loss(predictions, groundtruth, weights=(1, 1, 1, 1, 1)):
+    """sum_j w_j * L1-inv(prediction_j) / valid_j over the decoder's five outputs (coarse to fine or any order)."""
+    total = 0.0
+    for weight, prediction in zip(weights, predictions):
+        s, n = inverse_depth_l1(prediction, groundtruth)
+        total = total + weight * (s / n.clamp(min=1))
+    return total
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# forward over one sub-sequence
+# ----------------------------------------------------------------------------------------------------------------------
+def fusionnet_subsequence_loss(model, images, depths, poses, K, warp_grid=None):
+    """``model`` = [feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder];
+    ``images`` list of [B,3,H,W], ``depths`` list of [B,H,W], ``poses`` list of [B,4,4], ``K`` [B,3,3] (full resolution).
+    Returns (loss summed over frames 1..n-1, list of full-resolution predictions)."""
+    fe, fs, enc, lstm, dec = model
+    B, _, H, W = images[0].shape
+    half_K = K.clone()
+    half_K[:, 0:2, :] = half_K[:, 0:2, :] * 0.5
+    lstm_K = K.clone()
+    lstm_K[:, 0:2, :] = lstm_K[:, 0:2, :] / 32.0
+    if warp_grid is None:
+        warp_grid = get_warp_grid_for_cost_volume_calculation(W // 2, H // 2, images[0].device)
+
+    feats = [fs(*fe(img)) for img in images]
+    loss = 0.0
+    state = None
+    full_predictions = []
+    for i in range(1, len(images)):
+        ref, meas = feats[i], feats[i - 1]
+        cost_volume = calculate_cost_volume_by_warping(ref[0], meas[0], poses[i], poses[i - 1], half_K, warp_grid, Config.train_min_depth,
+                                                       Config.train_max_depth, Config.train_n_depth_levels, images[0].device, True)
+        skip0, skip1, skip2, skip3, bottom = enc(ref[0], ref[1], ref[2], ref[3], cost_volume)
+        depth_estimation = F.interpolate(depths[i].view(B, 1, H, W), scale_factor=1.0 / 32.0, mode="nearest")
+        state = lstm(bottom, state, poses[i - 1], poses[i], depth_estimation, lstm_K)
+        full, half, quarter, one_eight, one_sixteen = dec(images[i], skip0, skip1, skip2, skip3, state[0])
+        loss = loss + multi_scale_loss([one_sixteen, one_eight, quarter, half, full], depths[i])
+        full_predictions.append(full)
+    return loss, full_predictions
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bucketed gradient all-reduce
+# ----------------------------------------------------------------------------------------------------------------------
+class BucketedGradientReducer:
+    """Averages gradients over the data-parallel group with a few large asynchronous all-reduces that overlap backward.
+
+    Usage per step:  ``reducer.zero_grad()``; ``loss.backward()``; ``reducer.finish()``; ``optimizer.step()``.
+    With no process group (single GPU) it only provides the flat, view-backed gradient storage.
+    """
+
+    def __init__(self, parameters, bucket_bytes=32 << 20, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        params = [p for p in parameters if p.requires_grad]
+        # autograd produces gradients roughly in reverse parameter order: fill buckets in that order so that the first
+        # bucket to complete is the first to be reduced
+        params = list(reversed(params))
+        self.buckets = []
+        current, size = [], 0
+        for p in params:
+            current.append(p)
+            size += p.numel() * p.element_size()
+            if size >= bucket_bytes:
+                self.buckets.append(current)
+                current, size = [], 0
+        if current:
+            self.buckets.append(current)
+        self.flat, self._pending, self._handles = [], [], []
+        for b, bucket in enumerate(self.buckets):
+            n = sum(p.numel() for p in bucket)
+            flat = torch.zeros(n, dtype=bucket[0].dtype, device=bucket[0].device)
+            offset = 0
+            for p in bucket:
+                p.grad = flat[offset:offset + p.numel()].view_as(p)   # autograd accumulates in place into the bucket
+                offset += p.numel()
+                p.register_post_accumulate_grad_hook(self._make_hook(b))
+            self.flat.append(flat)
+            self._pending.append(len(bucket))
+        self.launched_during_backward = 0
+
+    def _make_hook(self, b):
+        def hook(param):
+            self._pending[b] -= 1
+            if self._pending[b] == 0 and self.world > 1:
+                self._handles.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.launched_during_backward += 1
+        return hook
+
+    def zero_grad(self):
+        for b, flat in enumerate(self.flat):
+            flat.zero_()
+            self._pending[b] = len(self.buckets[b])
+        self._handles = []
+        self.launched_during_backward = 0
+
+    def finish(self):
+        """Waits for the in-flight all-reduces, reduces buckets whose parameters received no gradient this step, and
+        turns the sums into means."""
+        if self.world == 1:
+            return
+        for b, pending in enumerate(self._pending):
+            if pending != 0:   # some parameter of the bucket was unused in this step: reduce it now (zeros contribute 0)
+                self._handles.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for h in self._handles:
+            h.wait()
+        for flat in self.flat:
+            flat.div_(self.world)
+
+
+def train_step(model, optimizer, reducer, images, depths, poses, K, warp_grid=None):
+    """One optimisation step on this rank's batch of sub-sequences; returns the (local) loss value as a tensor."""
+    reducer.zero_grad()
+    loss, _ = fusionnet_subsequence_loss(model, images, depths, poses, K, warp_grid)
+    loss.backward()
+    reducer.finish()
+    optimizer.step()
+    return loss.detach()

@@ -280,7 +280,9 @@ def warp_hidden_state(image_src: Tensor, depth_dst: Tensor, src_trans_dst: Tenso
     gy = uv[..., 1] * fy - 1
     out = bilinear_zeros_gather(image_src, unnormalize_align_corners(gx, W), unnormalize_align_corners(gy, H))
     if zero_invalid:
-        out = out * (depth_dst > 0.01).to(out.dtype)
+        # the reference zeroes through ``.data`` (convlstm.py:41): the forward value is masked, the gradient is not
+        keep = (depth_dst > 0.01).to(out.dtype)
+        out = out + (out * keep - out).detach()
     return out
 
 

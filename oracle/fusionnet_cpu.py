@@ -70,3 +70,31 @@ class CpuDepthPipeline:
             record(feat_half=ref_feats[0], cost_volume=cv, bottom=bottom, depth_estimation=de,
                    h=None if self.lstm is None else self.lstm_state[0], c=None if self.lstm is None else self.lstm_state[1], depth=pred)
         return pred
+
+
+def cpu_subsequence_loss(model, images, depths, poses, K, min_depth=0.25, max_depth=20.0, n_depth_levels=64):
+    """CPU restatement of the fusionnet TRAINING forward + L1-inv loss over one sub-sequence, differentiable through the
+    oracle ops.  Order of operations: /root/reference/dvmvs/fusionnet/run-training.py:184-284; loss:
+    /root/reference/dvmvs/losses.py:26-80 with loss_type "L1-inv", weights 1.  Checker for the GPU training step."""
+    fe, fs, enc, lstm, dec = model
+    B, _, H, W = images[0].shape
+    half_K = K.clone()
+    half_K[:, 0:2, :] = half_K[:, 0:2, :] * 0.5
+    lstm_K = K.clone()
+    lstm_K[:, 0:2, :] = lstm_K[:, 0:2, :] / 32.0
+    feats = [fs(*fe(img)) for img in images]
+    total = 0.0
+    state = None
+    for i in range(1, len(images)):
+        cv = orc.cost_volume(feats[i][0], feats[i - 1][0], poses[i], poses[i - 1], half_K, min_depth, max_depth, n_depth_levels, True)
+        skip0, skip1, skip2, skip3, bottom = enc(*feats[i], cv)
+        de = torch.nn.functional.interpolate(depths[i].view(B, 1, H, W), scale_factor=1.0 / 32.0, mode="nearest")
+        h, c = state if state is not None else (torch.zeros_like(bottom), torch.zeros_like(bottom))
+        state = orc.convlstm_cell(lstm.lstm_cell.conv.weight, bottom, h, c, poses[i - 1], poses[i], de, lstm_K)
+        outs = dec(images[i], skip0, skip1, skip2, skip3, state[0])
+        for pred in outs:
+            b, hs, ws = pred.shape
+            gt = torch.nn.functional.interpolate(depths[i].view(B, 1, H, W), size=(hs, ws), mode="nearest").view(b, hs, ws)
+            valid = gt != 0
+            total = total + (1.0 / gt[valid] - 1.0 / pred[valid]).abs().sum() / valid.sum()
+    return total
