@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-reps", type=int, default=10)
     ap.add_argument("--stage-times", action="store_true", help="also print eager per-stage GPU times to stderr")
+    ap.add_argument("--mode", choices=["inference", "train"], default="inference",
+                    help="inference = the headline metric (default); train = BASELINE.json configs[4] training step")
+    ap.add_argument("--train-batch", type=int, default=4, help="sub-sequences per GPU per step (train mode)")
+    ap.add_argument("--train-frames", type=int, default=8, help="frames per sub-sequence (train mode)")
     ap.add_argument("--mark-region", action="store_true",
                     help="bracket the timed loop with a cumsum kernel so tools/summarize_trace.py can cut it out of a rocprofv3 trace")
     ap.add_argument("--no-roofline-leg", action="store_true", help="skip the dedicated cost-volume timing (profiling runs)")
@@ -192,6 +196,58 @@ def cpu_baseline(args, modules, n_meas):
             "stage_ms": {k2: round(1e3 * v / frames, 2) for k2, v in pipe.stage_seconds.items()}}
 
 
+def train_mode(args, world, rank, device):
+    """BASELINE.json configs[4]: fusionnet training step, sub-sequences of 8 frames at 256x256, batch 4 per GPU, Adam,
+    L1-inv loss; gradients averaged with the bucketed RCCL all-reduce of dvmvs/training.py.  A step = one optimisation
+    step on every rank; value = sub-sequences/s over all ranks (weak scaling).  Not the headline metric."""
+    import torch.distributed as dist
+    import synthetic as syn
+    from dvmvs.config import Config
+    from dvmvs.training import BucketedGradientReducer, train_step
+    torch.backends.cudnn.benchmark = True
+    model = [m.to(device).train() for m in build_modules()]
+    params = [p for m in model for p in m.parameters()]
+    reducer = BucketedGradientReducer(params)
+    opt = torch.optim.Adam(params, lr=1e-4)
+    B, T, H, W = args.train_batch, args.train_frames, Config.train_image_height, Config.train_image_width
+    g = torch.Generator().manual_seed(77 + rank)
+    images = [syn.smooth_noise((B, 3, H, W), seed=5000 + 100 * rank + i).to(device) for i in range(T)]
+    depths = [(torch.rand(B, H, W, generator=g) * 4.5 + 0.5).to(device) for _ in range(T)]
+    all_poses = torch.from_numpy(syn.sample_poses()).float()
+    poses = [torch.stack([all_poses[(40 * b + 3 * i + 7 * rank) % len(all_poses)] for b in range(B)]).to(device) for i in range(T)]
+    K = torch.cat([syn.full_K(width=W, height=H)] * B).to(device)
+    for _ in range(max(args.warmup, 1)):
+        train_step(model, opt, reducer, images, depths, poses, K)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(model, opt, reducer, images, depths, poses, K)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "fusionnet training sub-sequences/sec (8 frames, 256x256, 64 planes)", "value": world * B * args.steps / elapsed,
+            "unit": "subsequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"fusionnet training step, subseq_len={T}, batch={B}/GPU, Adam, L1-inv loss (BASELINE.json configs[4])",
+                       "grad_buckets": len(reducer.buckets), "grad_bytes": sum(f.numel() * 4 for f in reducer.flat),
+                       "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce overlapped with backward"},
+            "final_loss": float(loss)}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,6 +266,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    if args.mode == "train":
+        return train_mode(args, world, rank, device)
 
     from dvmvs.engine import DepthEngine
     torch.backends.cudnn.benchmark = True   # MIOpen solver search during the warm-up frames

@@ -64,6 +64,46 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
   }
 }
 
+// Depthwise k x k convolution (groups == channels, "same" padding k/2, stride 1 or 2) with the bias add and activation
+// fused.  MIOpen runs these MnasNet layers through its naive reference kernel (naive_conv_ab_nonpacked_fwd_nchw) plus a
+// separate bias/activation launch; a direct kernel is one launch and reads each input element from L1 k*k times.
+// One thread per output element; the k*k weights of the channel are wave-uniform (scalar loads).
+template <int K, int ACT>
+__global__ __launch_bounds__(256) void depthwise_conv_kernel(const float* __restrict__ in, const float* __restrict__ weight,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int C, int H, int W,
+                                                             int OH, int OW, int stride) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* wk = weight + static_cast<size_t>(c) * K * K;
+  const float* src = in + (static_cast<size_t>(b) * C + c) * H * W;
+  float* dst = out + (static_cast<size_t>(b) * C + c) * OH * OW;
+  const float bv = bias ? bias[c] : 0.0f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < OH * OW; i += gridDim.x * blockDim.x) {
+    const int oy = i / OW, ox = i - oy * OW;
+    const int y0 = oy * stride - K / 2, x0 = ox * stride - K / 2;
+    float acc = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int y = y0 + ky;
+      const bool yin = y >= 0 && y < H;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int x = x0 + kx;
+        const float v = (yin && x >= 0 && x < W) ? src[y * W + x] : 0.0f;
+        acc = fmaf(v, wk[ky * K + kx], acc);
+      }
+    }
+    dst[i] = apply_act<ACT>(acc + bv);
+  }
+}
+
+template <int K, int ACT>
+int launch_depthwise(const float* in, const float* w, const float* b, float* out, int B, int C, int H, int W, int OH, int OW, int stride,
+                     hipStream_t s) {
+  dim3 grid(max(1, min((OH * OW + 255) / 256, 64)), C, B), block(256);
+  hipLaunchKernelGGL((depthwise_conv_kernel<K, ACT>), grid, block, 0, s, in, w, b, out, C, H, W, OH, OW, stride);
+  return launch_status();
+}
+
 template <int ACT>
 int launch_bias_act(float* x, const float* bias, int B, int C, int HW, hipStream_t s) {
   const bool vec4 = (HW % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
@@ -99,4 +139,25 @@ extern "C" int dvmvs_upsample2x_fwd(const float* in, float* out, int B, int C, i
   hipLaunchKernelGGL(upsample2x_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
                      B * C, H, W);
   return launch_status();
+}
+
+extern "C" int dvmvs_depthwise_conv_fwd(const float* in, const float* weight, const float* bias, float* out, int B, int C, int H, int W,
+                                        int kernel_size, int stride, int activation, dvmvs_stream_t stream) {
+  using namespace dvmvs;
+  if (!in || !weight || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return DVMVS_EINVAL;
+  if ((kernel_size != 3 && kernel_size != 5) || (stride != 1 && stride != 2) || activation < 0 || activation > 2) return DVMVS_EUNSUPPORTED;
+  if (C > 65535 || B > 65535) return DVMVS_EUNSUPPORTED;
+  const int pad = kernel_size / 2;
+  const int OH = (H + 2 * pad - kernel_size) / stride + 1, OW = (W + 2 * pad - kernel_size) / stride + 1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define DVMVS_DW(K, A) return launch_depthwise<K, A>(in, weight, bias, out, B, C, H, W, OH, OW, stride, s)
+  if (kernel_size == 3) {
+    if (activation == 0) DVMVS_DW(3, 0);
+    if (activation == 1) DVMVS_DW(3, 1);
+    DVMVS_DW(3, 2);
+  }
+  if (activation == 0) DVMVS_DW(5, 0);
+  if (activation == 1) DVMVS_DW(5, 1);
+  DVMVS_DW(5, 2);
+#undef DVMVS_DW
 }

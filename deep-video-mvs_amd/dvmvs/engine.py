@@ -75,7 +75,15 @@ class FusedConv2d(nn.Module):
         self.activation = _ops.ACTIVATIONS[activation]
         self.register_buffer("_no_bias", torch.empty(0, device=conv.weight.device), persistent=False)
 
+        k = conv.kernel_size
+        self.depthwise = (conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1 and k[0] == k[1] and k[0] in (3, 5)
+                          and tuple(conv.padding) == (k[0] // 2, k[0] // 2) and tuple(conv.dilation) == (1, 1)
+                          and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2))
+
     def forward(self, x):
+        if self.depthwise:   # MnasNet depthwise layers: one HIP launch instead of MIOpen's naive kernel + an epilogue
+            return _ops.depthwise_conv(x, self.weight, self.bias if self.bias is not None else self._no_bias, self.stride[0],
+                                       self.activation)
         y = nn.functional.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
         if not y.is_contiguous():
             y = y.contiguous()

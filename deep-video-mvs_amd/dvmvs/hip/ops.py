@@ -13,7 +13,7 @@ from torch import Tensor
 from dvmvs.hip import _capi
 
 __all__ = ["cost_volume", "hidden_warp", "relative_pose", "lstm_gates", "depth_reproject", "depth_reproject_lowres",
-           "bias_act_", "upsample2x"]
+           "bias_act_", "upsample2x", "depthwise_conv"]
 
 
 def _no_cpu(op):
@@ -352,3 +352,35 @@ def _(x):
 @upsample2x.register_kernel("cpu")
 def _(x):
     _no_cpu("upsample2x")
+
+
+@torch.library.custom_op("dvmvs::depthwise_conv", mutates_args=(), device_types="cuda")
+def depthwise_conv(x: Tensor, weight: Tensor, bias: Tensor, stride: int, activation: int) -> Tensor:
+    """Depthwise k x k convolution (weight [C,1,k,k], padding k//2) + bias (numel 0 = none) + activation, one HIP launch."""
+    _dev_f32("depthwise_conv", x, weight)
+    x, weight = x.contiguous(), weight.contiguous()
+    B, C, H, W = x.shape
+    k = weight.shape[-1]
+    if tuple(weight.shape) != (C, 1, k, k):
+        raise ValueError(f"dvmvs::depthwise_conv: weight {tuple(weight.shape)} is not depthwise for {C} channels")
+    pad = k // 2
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().dvmvs_depthwise_conv_fwd(_ptr(x), _ptr(weight), _ptr(bias.contiguous()) if bias.numel() else None, _ptr(out),
+                                                  B, C, H, W, k, int(stride), int(activation), _stream(x))
+    _capi.check(rc, "dvmvs_depthwise_conv_fwd")
+    return out
+
+
+@depthwise_conv.register_fake
+def _(x, weight, bias, stride, activation):
+    B, C, H, W = x.shape
+    k = weight.shape[-1]
+    pad = k // 2
+    return x.new_empty((B, C, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1))
+
+
+@depthwise_conv.register_kernel("cpu")
+def _(x, weight, bias, stride, activation):
+    _no_cpu("depthwise_conv")

@@ -156,6 +156,13 @@ int dvmvs_depth_reproject_fwd(const float* reference_pose, const float* measurem
 int dvmvs_bias_act_inplace(float* x, const float* bias, int B, int C, int H, int W, int activation,
                            dvmvs_stream_t stream);
 int dvmvs_upsample2x_fwd(const float* in, float* out, int B, int C, int H, int W, dvmvs_stream_t stream);
+/*
+ *   dvmvs_depthwise_conv_fwd: depthwise convolution (groups == C, weight [C,1,k,k], k in {3,5}, padding k/2, stride 1|2)
+ *                           with bias (may be NULL) and activation fused; in [B,C,H,W] -> out [B,C,OH,OW].  The MnasNet
+ *                           depthwise layers of the feature extractor (torchvision mnasnet _InvertedResidual).
+ */
+int dvmvs_depthwise_conv_fwd(const float* in, const float* weight, const float* bias, float* out, int B, int C, int H, int W,
+                             int kernel_size, int stride, int activation, dvmvs_stream_t stream);
 
 #ifdef __cplusplus
 }

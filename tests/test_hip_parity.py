@@ -465,3 +465,19 @@ def test_fused_modules_match_plain_modules(dev):
         assert d_fused[1] is None
         rel = ((d_plain[0] - d_fused[0]).abs() / d_plain[0]).mean().item()
         assert rel < 1e-4
+
+
+def test_depthwise_conv_matches_torch(ops, dev):
+    g = torch.Generator().manual_seed(23)
+    for (B, C, H, W, k, stride) in ((1, 32, 128, 160, 3, 1), (1, 48, 128, 160, 3, 2), (2, 72, 33, 41, 5, 2), (1, 240, 32, 40, 5, 1),
+                                    (1, 1152, 8, 10, 3, 1), (1, 3, 7, 5, 5, 1)):
+        x = torch.randn(B, C, H, W, generator=g)
+        w = torch.randn(C, 1, k, k, generator=g) * 0.3
+        b = torch.randn(C, generator=g)
+        for name, fn in (("none", lambda t: t), ("relu", torch.relu), ("sigmoid", torch.sigmoid)):
+            got = ops.depthwise_conv(x.to(dev), w.to(dev), b.to(dev), stride, ops.ACTIVATIONS[name])
+            exp = fn(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=k // 2, groups=C))
+            assert tuple(got.shape) == tuple(exp.shape)
+            assert maxerr(got, exp) < 2e-5 * max(1.0, exp.abs().max().item()), (B, C, H, W, k, stride, name)
+        got = ops.depthwise_conv(x.to(dev), w.to(dev), torch.empty(0, device=dev), stride, 0)
+        assert maxerr(got, torch.nn.functional.conv2d(x, w, None, stride=stride, padding=k // 2, groups=C)) < 2e-5 * 10
