@@ -18,23 +18,43 @@ __device__ inline float apply_act(float v) {
 }
 
 // One workgroup row per (b, c) plane chunk; float4 when the plane size allows it.
-template <int ACT, bool VEC4>
-__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ x, const float* __restrict__ bias, int C, int HW) {
+// RES: 0 none; 1 residual of the same shape is added after the activation; 2 the residual has half the resolution and is
+// nearest-up-sampled on the fly (the FPN top-down path: lateral + interpolate(top, "nearest")).
+template <int ACT, bool VEC4, int RES>
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ x, const float* __restrict__ bias,
+                                                       const float* __restrict__ residual, int C, int HW, int W) {
   const int plane = blockIdx.y;  // b * C + c
   const float bv = bias ? bias[plane % C] : 0.0f;
   float* p = x + static_cast<size_t>(plane) * HW;
-  if (VEC4) {
+  if (VEC4 && RES != 2) {
     typedef float float4v __attribute__((ext_vector_type(4)));
     float4v* p4 = reinterpret_cast<float4v*>(p);
+    const float4v* r4 = reinterpret_cast<const float4v*>(residual + (RES == 1 ? static_cast<size_t>(plane) * HW : 0));
     const int n4 = HW / 4;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
       float4v v = p4[i];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(v[e] + bv);
+      if (RES == 1) {
+        const float4v r = r4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += r[e];
+      }
       p4[i] = v;
     }
   } else {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) p[i] = apply_act<ACT>(p[i] + bv);
+    const int Wh = W / 2;
+    const float* r = RES == 1 ? residual + static_cast<size_t>(plane) * HW
+                              : (RES == 2 ? residual + static_cast<size_t>(plane) * (HW / 4) : nullptr);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+      float v = apply_act<ACT>(p[i] + bv);
+      if (RES == 1) v += r[i];
+      if (RES == 2) {
+        const int y = i / W, xx = i - y * W;
+        v += r[(y >> 1) * Wh + (xx >> 1)];
+      }
+      p[i] = v;
+    }
   }
 }
 
@@ -105,27 +125,34 @@ int launch_depthwise(const float* in, const float* w, const float* b, float* out
 }
 
 template <int ACT>
-int launch_bias_act(float* x, const float* bias, int B, int C, int HW, hipStream_t s) {
-  const bool vec4 = (HW % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+int launch_bias_act(float* x, const float* bias, const float* residual, int residual_mode, int B, int C, int H, int W, hipStream_t s) {
+  const int HW = H * W;
+  const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(residual) % 16 == 0);
+  const bool vec4 = (HW % 4 == 0) && aligned && residual_mode != 2;
   const int work = vec4 ? HW / 4 : HW;
   dim3 grid(max(1, min((work + 255) / 256, 64)), B * C), block(256);
-  if (vec4) hipLaunchKernelGGL((bias_act_kernel<ACT, true>), grid, block, 0, s, x, bias, C, HW);
-  else hipLaunchKernelGGL((bias_act_kernel<ACT, false>), grid, block, 0, s, x, bias, C, HW);
+#define DVMVS_BA(V, R) hipLaunchKernelGGL((bias_act_kernel<ACT, V, R>), grid, block, 0, s, x, bias, residual, C, HW, W)
+  if (residual_mode == 0) { if (vec4) DVMVS_BA(true, 0); else DVMVS_BA(false, 0); }
+  else if (residual_mode == 1) { if (vec4) DVMVS_BA(true, 1); else DVMVS_BA(false, 1); }
+  else DVMVS_BA(false, 2);
+#undef DVMVS_BA
   return launch_status();
 }
 
 }  // namespace dvmvs
 
-extern "C" int dvmvs_bias_act_inplace(float* x, const float* bias, int B, int C, int H, int W, int activation,
-                                      dvmvs_stream_t stream) {
+extern "C" int dvmvs_bias_act_inplace(float* x, const float* bias, const float* residual, int residual_mode, int B, int C, int H,
+                                      int W, int activation, dvmvs_stream_t stream) {
   using namespace dvmvs;
   if (!x || B <= 0 || C <= 0 || H <= 0 || W <= 0) return DVMVS_EINVAL;
-  if (static_cast<long long>(B) * C > 65535LL * 1024) return DVMVS_EUNSUPPORTED;
+  if (residual_mode < 0 || residual_mode > 2 || (residual_mode != 0 && !residual)) return DVMVS_EINVAL;
+  if (residual_mode == 2 && ((H & 1) || (W & 1))) return DVMVS_EUNSUPPORTED;
+  if (static_cast<long long>(B) * C > 65535LL) return DVMVS_EUNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (activation) {
-    case 0: return launch_bias_act<0>(x, bias, B, C, H * W, s);
-    case 1: return launch_bias_act<1>(x, bias, B, C, H * W, s);
-    case 2: return launch_bias_act<2>(x, bias, B, C, H * W, s);
+    case 0: return launch_bias_act<0>(x, bias, residual, residual_mode, B, C, H, W, s);
+    case 1: return launch_bias_act<1>(x, bias, residual, residual_mode, B, C, H, W, s);
+    case 2: return launch_bias_act<2>(x, bias, residual, residual_mode, B, C, H, W, s);
     default: return DVMVS_EINVAL;
   }
 }

@@ -44,6 +44,11 @@ class InvertedResidual(nn.Module):
             nn.Conv2d(mid, cout, 1, bias=False), _bn(cout))
 
     def forward(self, x):
+        # dvmvs.engine.fuse_epilogues registers ``fused_head`` (layers[:6]) and ``fused_tail`` (the project conv whose
+        # epilogue adds the shortcut) as sub-modules of shape-preserving blocks
+        tail = self._modules.get("fused_tail")
+        if tail is not None:
+            return tail(self._modules["fused_head"](x), residual=x, residual_mode=1)
         y = self.layers(x)
         return y + x if self.apply_residual else y
 
@@ -90,13 +95,19 @@ class FeaturePyramidNetwork(nn.Module):
                 nn.init.kaiming_uniform_(m.weight, a=1)
                 nn.init.constant_(m.bias, 0)
 
+    fused_top_down = False   # set by dvmvs.engine.fuse_epilogues: lateral conv epilogue adds the nearest-up-sampled coarser level
+
     def forward(self, x):
         names = list(x.keys())
         feats = list(x.values())
         top = self.inner_blocks[-1](feats[-1])
         outs = [self.layer_blocks[-1](top)]
         for level in range(len(feats) - 2, -1, -1):
-            lateral = self.inner_blocks[level](feats[level])
-            top = lateral + F.interpolate(top, size=lateral.shape[-2:], mode="nearest")
+            h, w = feats[level].shape[-2:]
+            if self.fused_top_down and (h, w) == (2 * top.shape[-2], 2 * top.shape[-1]):
+                top = self.inner_blocks[level](feats[level], residual=top, residual_mode=2)
+            else:
+                lateral = self.inner_blocks[level](feats[level])
+                top = lateral + F.interpolate(top, size=lateral.shape[-2:], mode="nearest")
             outs.insert(0, self.layer_blocks[level](top))
         return OrderedDict(zip(names, outs))

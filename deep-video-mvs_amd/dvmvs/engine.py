@@ -80,15 +80,19 @@ class FusedConv2d(nn.Module):
                           and tuple(conv.padding) == (k[0] // 2, k[0] // 2) and tuple(conv.dilation) == (1, 1)
                           and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2))
 
-    def forward(self, x):
-        if self.depthwise:   # MnasNet depthwise layers: one HIP launch instead of MIOpen's naive kernel + an epilogue
+    def forward(self, x, residual=None, residual_mode=0):
+        """``residual`` (mode 1: same shape, mode 2: half resolution, nearest-up-sampled) is added in the same epilogue."""
+        if self.depthwise and residual is None:   # MnasNet depthwise layers: one HIP launch instead of MIOpen's naive kernel + epilogue
             return _ops.depthwise_conv(x, self.weight, self.bias if self.bias is not None else self._no_bias, self.stride[0],
                                        self.activation)
         y = nn.functional.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
         if not y.is_contiguous():
             y = y.contiguous()
         bias = self.bias if self.bias is not None else self._no_bias
-        _ops.bias_act_(y, bias, self.activation)
+        if residual is None:
+            _ops.bias_act_(y, bias, self.activation, self._no_bias, 0)
+        else:
+            _ops.bias_act_(y, bias, self.activation, residual, residual_mode)
         return y
 
 
@@ -120,6 +124,13 @@ def fuse_epilogues(module):
                 m = parent._modules[name]
                 if isinstance(m, nn.Conv2d) and m.bias is not None:
                     parent._modules[name] = FusedConv2d(m, "none")
+    # shortcut sums folded into the producing convolution's epilogue
+    from dvmvs.backbone import FeaturePyramidNetwork, InvertedResidual
+    for m in module.modules():
+        if isinstance(m, InvertedResidual) and m.apply_residual and isinstance(m.layers[6], FusedConv2d):
+            m.fused_head, m.fused_tail = nn.Sequential(*list(m.layers)[:6]), m.layers[6]
+        if isinstance(m, FeaturePyramidNetwork) and all(isinstance(b, FusedConv2d) for b in m.inner_blocks):
+            m.fused_top_down = True
     return module
 
 

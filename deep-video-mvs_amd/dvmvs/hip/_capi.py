@@ -46,7 +46,7 @@ SIGNATURES = {
     "dvmvs_lstm_gates_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_depth_reproject_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int,
                                            _c_int, _c_int, _c_int, _c_stream]),
-    "dvmvs_bias_act_inplace": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "dvmvs_bias_act_inplace": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_upsample2x_fwd": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_depthwise_conv_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
 }

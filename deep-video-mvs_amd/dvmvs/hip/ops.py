@@ -311,23 +311,34 @@ def _(reference_pose, measurement_pose, previous_depth, full_K, half_K, factor):
 ACTIVATIONS = {"none": 0, "relu": 1, "sigmoid": 2}
 
 
+RESIDUAL_NONE, RESIDUAL_SAME, RESIDUAL_NEAREST_UP2 = 0, 1, 2
+
+
 @torch.library.custom_op("dvmvs::bias_act_", mutates_args=("x",), device_types="cuda")
-def bias_act_(x: Tensor, bias: Tensor, activation: int) -> None:
-    """In place: x[b,c] = act(x[b,c] + bias[c]) for a contiguous NCHW tensor; ``bias`` may be empty (numel 0)."""
+def bias_act_(x: Tensor, bias: Tensor, activation: int, residual: Tensor, residual_mode: int) -> None:
+    """In place: x[b,c] = act(x[b,c] + bias[c]) (+ residual) for a contiguous NCHW tensor.  ``bias`` / ``residual`` may be
+    empty (numel 0); residual_mode 1: same shape, 2: half resolution, nearest-up-sampled on the fly."""
     _dev_f32("bias_act_", x)
     if not x.is_contiguous() or x.dim() != 4:
         raise ValueError("dvmvs::bias_act_: expected a contiguous NCHW tensor")
     B, C, H, W = x.shape
     if bias.numel() not in (0, C):
         raise ValueError(f"dvmvs::bias_act_: bias has {bias.numel()} entries for {C} channels")
+    res_ptr = None
+    if residual_mode != RESIDUAL_NONE:
+        want = (B, C, H, W) if residual_mode == RESIDUAL_SAME else (B, C, H // 2, W // 2)
+        if tuple(residual.shape) != want:
+            raise ValueError(f"dvmvs::bias_act_: residual {tuple(residual.shape)} does not match {want}")
+        residual = residual.contiguous()
+        res_ptr = _ptr(residual)
     with torch.cuda.device(x.device):
-        rc = _capi.lib().dvmvs_bias_act_inplace(_ptr(x), _ptr(bias.contiguous()) if bias.numel() else None, B, C, H, W, int(activation),
-                                                _stream(x))
+        rc = _capi.lib().dvmvs_bias_act_inplace(_ptr(x), _ptr(bias.contiguous()) if bias.numel() else None, res_ptr, int(residual_mode),
+                                                B, C, H, W, int(activation), _stream(x))
     _capi.check(rc, "dvmvs_bias_act_inplace")
 
 
 @bias_act_.register_kernel("cpu")
-def _(x, bias, activation):
+def _(x, bias, activation, residual, residual_mode):
     _no_cpu("bias_act_")
 
 

@@ -1,0 +1,117 @@
+"""Scene runners: the loops of the reference's run-testing.py (pre-computed keyframe index) and run-testing-online.py
+(KeyframeBuffer on the fly) around the MI355X frame engine.
+
+/root/reference/dvmvs/fusionnet/run-testing.py:67-230 and run-testing-online.py:71-232, without cv2 / path / tqdm.  A scene
+folder holds ``images/*.png``, ``poses.txt`` (one 4x4 camera-to-world per line), ``K.txt`` and optionally ``depth/*.png``
+(uint16 millimetres).  Both runners return (predictions, reference_depths or None, InferenceTimer); ``save_results`` from
+``dvmvs.utils`` writes the same ``.npz`` files as the reference.
+"""
+import os
+
+import numpy as np
+import torch
+
+from dvmvs.config import Config
+from dvmvs.dataset_loader import PreprocessImage, load_depth_png, load_image
+from dvmvs.engine import DepthEngine
+from dvmvs.keyframe_buffer import KeyframeBuffer
+from dvmvs.utils import InferenceTimer
+
+SCALE_RGB = 255.0
+MEAN_RGB = [0.485, 0.456, 0.406]
+STD_RGB = [0.229, 0.224, 0.225]
+
+
+class Scene:
+    def __init__(self, folder):
+        self.folder = str(folder)
+        self.K = np.loadtxt(os.path.join(self.folder, "K.txt")).astype(np.float32)
+        self.poses = np.fromfile(os.path.join(self.folder, "poses.txt"), dtype=float, sep="\n ").reshape((-1, 4, 4))
+        self.image_names = sorted(n for n in os.listdir(os.path.join(self.folder, "images")) if n.endswith(".png"))
+        depth_dir = os.path.join(self.folder, "depth")
+        self.depth_names = sorted(n for n in os.listdir(depth_dir) if n.endswith(".png")) if os.path.isdir(depth_dir) else None
+
+    def image(self, i):
+        return load_image(os.path.join(self.folder, "images", self.image_names[i]))
+
+    def depth(self, i):
+        return load_depth_png(os.path.join(self.folder, "depth", self.depth_names[i]))
+
+
+def _to_device(image_hwc, device):
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(image_hwc, (2, 0, 1)))).float().unsqueeze(0).to(device)
+
+
+def _preprocessor(scene, raw_image):
+    return PreprocessImage(K=scene.K, old_width=raw_image.shape[1], old_height=raw_image.shape[0], new_width=Config.test_image_width,
+                           new_height=Config.test_image_height, distortion_crop=Config.test_distortion_crop,
+                           perform_crop=Config.test_perform_crop)
+
+
+def _run_frame(engine, scene, timer, device, reference_index, measurement_indices, evaluate, images=None):
+    raw = images[reference_index] if images is not None and reference_index in images else scene.image(reference_index)
+    pre = _preprocessor(scene, raw)
+    ref_image = _to_device(pre.apply_rgb(raw, SCALE_RGB, MEAN_RGB, STD_RGB), device)
+    ref_pose = torch.from_numpy(scene.poses[reference_index]).float().unsqueeze(0).to(device)
+    full_K = torch.from_numpy(pre.get_updated_intrinsics()).float().unsqueeze(0).to(device)
+    meas_images, meas_poses = [], []
+    for m in measurement_indices:
+        if engine.cache_features and m in engine._feature_cache:
+            meas_images.append(None)     # features of this keyframe are cached: no need to load / pre-process the image again
+        else:
+            raw_m = images[m] if images is not None and m in images else scene.image(m)
+            meas_images.append(_to_device(pre.apply_rgb(raw_m, SCALE_RGB, MEAN_RGB, STD_RGB), device))
+        meas_poses.append(torch.from_numpy(scene.poses[m]).float().unsqueeze(0).to(device))
+    timer.record_start_time()
+    depth = engine.step(ref_image, ref_pose, meas_images, meas_poses, full_K, frame_id=reference_index,
+                        measurement_ids=list(measurement_indices))
+    timer.record_end_time_and_elapsed_time()
+    prediction = depth.cpu().numpy().squeeze()
+    reference_depth = pre.apply_depth(scene.depth(reference_index)) if evaluate and scene.depth_names else None
+    return prediction, reference_depth
+
+
+def predict_offline(engine: DepthEngine, scene_folder, keyframe_index_file, evaluate=True, max_frames=None):
+    """Runs the lines of a keyframe index file ("ref meas1 meas2 ..." or "TRACKING LOST") through ``engine``."""
+    scene = Scene(scene_folder)
+    device = engine.device
+    position = {name: i for i, name in enumerate(scene.image_names)}
+    timer = InferenceTimer()
+    predictions, reference_depths = [], []
+    engine.reset()
+    engine.clear_feature_cache()
+    lines = [l.strip() for l in open(keyframe_index_file) if l.strip()]
+    for line in lines[:max_frames]:
+        if line == "TRACKING LOST":
+            engine.reset()
+            continue
+        indices = [position[name] for name in line.split(" ")]
+        prediction, reference_depth = _run_frame(engine, scene, timer, device, indices[0], indices[1:], evaluate)
+        predictions.append(prediction)
+        reference_depths.append(reference_depth)
+    return predictions, (reference_depths if evaluate and scene.depth_names else None), timer
+
+
+def predict_online(engine: DepthEngine, scene_folder, evaluate=False, max_frames=None):
+    """Feeds every frame of the scene to a KeyframeBuffer and predicts depth for the frames it accepts as keyframes."""
+    scene = Scene(scene_folder)
+    device = engine.device
+    buffer = KeyframeBuffer(buffer_size=Config.test_keyframe_buffer_size, keyframe_pose_distance=Config.test_keyframe_pose_distance,
+                            optimal_t_score=Config.test_optimal_t_measure, optimal_R_score=Config.test_optimal_R_measure,
+                            store_return_indices=True)
+    timer = InferenceTimer()
+    predictions, reference_depths = [], []
+    engine.reset()
+    engine.clear_feature_cache()
+    n = len(scene.poses) if max_frames is None else min(max_frames, len(scene.poses))
+    for i in range(n):
+        response = buffer.try_new_keyframe(scene.poses[i], None, index=i)
+        if response == 3:
+            engine.reset()
+        if response != 1:
+            continue
+        measurement_indices = [frame[2] for frame in buffer.get_best_measurement_frames(Config.test_n_measurement_frames)]
+        prediction, reference_depth = _run_frame(engine, scene, timer, device, i, measurement_indices, evaluate)
+        predictions.append(prediction)
+        reference_depths.append(reference_depth)
+    return predictions, (reference_depths if evaluate and scene.depth_names else None), timer

@@ -149,12 +149,14 @@ int dvmvs_depth_reproject_fwd(const float* reference_pose, const float* measurem
 /*
  * Frame-path epilogues (not part of the reference's function list; they replace ATen elementwise launches that sit
  * between MIOpen convolutions on the per-frame path, /root/reference/dvmvs/layers.py:39-65 and fusionnet/model.py:57,112,290).
- *   dvmvs_bias_act_inplace: x[b,c,:,:] = act(x[b,c,:,:] + bias[c]); bias may be NULL; activation 0 none, 1 ReLU, 2 sigmoid.
+ *   dvmvs_bias_act_inplace: x[b,c,:,:] = act(x[b,c,:,:] + bias[c]) [+ residual]; bias may be NULL; activation 0 none, 1 ReLU,
+ *                           2 sigmoid; residual_mode 0 none, 1 residual [B,C,H,W] (MnasNet shortcut), 2 residual [B,C,H/2,W/2]
+ *                           nearest-up-sampled on the fly (FPN top-down sum, torchvision FeaturePyramidNetwork.forward).
  *   dvmvs_upsample2x_fwd:   torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True);
  *                           in [B,C,H,W] -> out [B,C,2H,2W].
  */
-int dvmvs_bias_act_inplace(float* x, const float* bias, int B, int C, int H, int W, int activation,
-                           dvmvs_stream_t stream);
+int dvmvs_bias_act_inplace(float* x, const float* bias, const float* residual, int residual_mode, int B, int C, int H, int W,
+                           int activation, dvmvs_stream_t stream);
 int dvmvs_upsample2x_fwd(const float* in, float* out, int B, int C, int H, int W, dvmvs_stream_t stream);
 /*
  *   dvmvs_depthwise_conv_fwd: depthwise convolution (groups == C, weight [C,1,k,k], k in {3,5}, padding k/2, stride 1|2)

@@ -426,12 +426,23 @@ def test_bias_activation_epilogue_is_exact(ops, dev):
         x = torch.randn(*shape, generator=g)
         b = torch.randn(shape[1], generator=g)
         for name, fn in (("none", lambda t: t), ("relu", torch.relu), ("sigmoid", torch.sigmoid)):
+            none = torch.empty(0, device=dev)
             y = x.to(dev).clone()
-            ops.bias_act_(y, b.to(dev), ops.ACTIVATIONS[name])
+            ops.bias_act_(y, b.to(dev), ops.ACTIVATIONS[name], none, ops.RESIDUAL_NONE)
             exp = fn(x + b.view(1, -1, 1, 1))
             assert maxerr(y, exp) <= (0.0 if name != "sigmoid" else 2e-7), (shape, name)
+            r = torch.randn(*shape, generator=g)
+            y = x.to(dev).clone()
+            ops.bias_act_(y, b.to(dev), ops.ACTIVATIONS[name], r.to(dev), ops.RESIDUAL_SAME)       # MnasNet shortcut
+            assert maxerr(y, exp + r) <= (0.0 if name != "sigmoid" else 5e-7), (shape, name)
+            if shape[2] % 2 == 0 and shape[3] % 2 == 0:
+                rh = torch.randn(shape[0], shape[1], shape[2] // 2, shape[3] // 2, generator=g)
+                y = x.to(dev).clone()
+                ops.bias_act_(y, b.to(dev), ops.ACTIVATIONS[name], rh.to(dev), ops.RESIDUAL_NEAREST_UP2)   # FPN top-down sum
+                up = torch.nn.functional.interpolate(rh, size=shape[2:], mode="nearest")
+                assert maxerr(y, exp + up) <= (0.0 if name != "sigmoid" else 5e-7), (shape, name)
         y = x.to(dev).clone()
-        ops.bias_act_(y, torch.empty(0, device=dev), ops.ACTIVATIONS["relu"])
+        ops.bias_act_(y, torch.empty(0, device=dev), ops.ACTIVATIONS["relu"], torch.empty(0, device=dev), ops.RESIDUAL_NONE)
         assert maxerr(y, torch.relu(x)) == 0.0
 
 
