@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-fold-bn", action="store_true")
     ap.add_argument("--no-feature-cache", action="store_true", help="recompute measurement features every frame like the reference")
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--no-lstm-channels-last", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-reps", type=int, default=10)
@@ -274,7 +275,8 @@ def main():
     torch.backends.cudnn.benchmark = True   # MIOpen solver search during the warm-up frames
     modules = build_modules()
     engine = DepthEngine(*modules, device=device, fold_bn=not args.no_fold_bn, cache_features=not args.no_feature_cache,
-                         use_graphs=not args.no_graphs, channels_last=args.channels_last)
+                         use_graphs=not args.no_graphs, channels_last=args.channels_last,
+                         lstm_channels_last=not args.no_lstm_channels_last)
     M = args.measurement_frames
     n_images = 32
     total = args.warmup + args.steps

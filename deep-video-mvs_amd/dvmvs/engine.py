@@ -145,7 +145,7 @@ class DepthEngine:
 
     def __init__(self, feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder,
                  device="cuda", min_depth=0.25, max_depth=20.0, n_depth_levels=64, fold_bn=True, cache_features=True,
-                 use_graphs=True, cache_size=None, channels_last=False, fuse=True):
+                 use_graphs=True, cache_size=None, channels_last=False, fuse=True, lstm_channels_last=True):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DepthEngine runs on an MI355X; there is no CPU execution path in this package")
@@ -157,6 +157,12 @@ class DepthEngine:
         if channels_last:
             mods = [None if m is None else m.to(memory_format=torch.channels_last) for m in mods]
         self.fe, self.fs, self.enc, self.lstm, self.dec = mods
+        if lstm_channels_last and self.lstm is not None and not channels_last:
+            # the ConvLSTM convolution (1024 -> 2048 channels on an 8x10 map, 75 MB of weights) is weight-bandwidth bound;
+            # MIOpen's NHWC kernel for it takes 56 us against 88 us for NCHW, which more than pays for the two small layout
+            # copies around it (results are those of a different but equally valid fp32 summation order)
+            conv = self.lstm.lstm_cell.conv
+            conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
         self.channels_last = channels_last
         self.min_depth, self.max_depth, self.n_depth_levels = float(min_depth), float(max_depth), int(n_depth_levels)
         self.cache_features = cache_features
