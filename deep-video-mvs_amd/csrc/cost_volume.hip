@@ -121,51 +121,6 @@ struct TiledConfig {
   static_assert(CCH % 4 == 0 && ((kRec / 4) % 2) == 1, "record stride must be an odd number of 16-byte slots");
 };
 
-// Bounding box of the tile's sample positions over planes [j_lo, j_hi] of measurement frame m, evaluated by the first 8
-// lanes (tile corner x extreme plane) and published through s_box: {x_lo, y_lo, RW, RH, state}.
-//   state 1: box staged through LDS; 2: box entirely outside the image (zeros); 0: does not fit / not well defined.
-template <int TW, int TH, int DP, int CAP>
-__device__ inline void publish_sample_box(const CostVolumeArgs& a, const float* Hm, const float* ktd_m, int tile_x, int tile_y,
-                                          int j_lo, int j_hi, int tid, int* s_box) {
-  if (tid < 64) {
-    float ix = 0.0f, iy = 0.0f, z = 1.0f;
-    if (tid < 8) {
-      const int cx = (tid & 1) ? min(tile_x * TW + TW - 1, a.W - 1) : tile_x * TW;
-      const int cy = (tid & 2) ? min(tile_y * TH + TH - 1, a.H - 1) : tile_y * TH;
-      const int dl = (tid & 4) ? j_hi : j_lo;
-      sweep_position(Hm, ktd_m + dl * 3, static_cast<float>(cx), static_cast<float>(cy), a.W, a.H, &ix, &iy, &z);
-    }
-    float lo_x = ix, hi_x = ix, lo_y = iy, hi_y = iy, lo_z = z;
-#pragma unroll
-    for (int off = 4; off > 0; off >>= 1) {
-      lo_x = fminf(lo_x, __shfl_xor(lo_x, off, 8));
-      hi_x = fmaxf(hi_x, __shfl_xor(hi_x, off, 8));
-      lo_y = fminf(lo_y, __shfl_xor(lo_y, off, 8));
-      hi_y = fmaxf(hi_y, __shfl_xor(hi_y, off, 8));
-      lo_z = fminf(lo_z, __shfl_xor(lo_z, off, 8));
-    }
-    if (tid == 0) {
-      // NaN-safe: every comparison below is false for NaN, which leaves state == 0
-      const bool finite = (lo_x > -1e6f) && (hi_x < 1e6f) && (lo_y > -1e6f) && (hi_y < 1e6f) && (lo_z > 1e-6f);
-      int state = 0, x_lo = 0, y_lo = 0, RW = 0, RH = 0;
-      if (finite) {
-        // 0.05 px of slack for round-off between the corner samples and interior pixels; one apron pixel outside the
-        // image is enough, everything further out is zero as well
-        x_lo = max(-1, static_cast<int>(floorf(lo_x - 0.05f)));
-        y_lo = max(-1, static_cast<int>(floorf(lo_y - 0.05f)));
-        const int x_hi = min(a.W, static_cast<int>(floorf(hi_x + 0.05f)) + 1);
-        const int y_hi = min(a.H, static_cast<int>(floorf(hi_y + 0.05f)) + 1);
-        RW = x_hi - x_lo + 1;
-        RH = y_hi - y_lo + 1;
-        if (RW <= 0 || RH <= 0) state = 2;
-        else if (RW * RH <= CAP) state = 1;
-      }
-      s_box[0] = x_lo; s_box[1] = y_lo; s_box[2] = RW; s_box[3] = RH; s_box[4] = state;
-    }
-  }
-  __syncthreads();
-}
-
 // NHWC: the measurement maps are channels-last ([B,H,W,C] in memory).  A box position's CCH channels are then 4*CCH
 // contiguous bytes (staging = plain 16-byte copies, no transposition through registers) and, more importantly, a gather
 // tap of the spill path is one cache line for all 32 channels instead of 32 lines.

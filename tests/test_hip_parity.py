@@ -258,6 +258,27 @@ def test_cost_volume_gradients(ops, dev, golden_dir):
     assert maxerr(bd.grad, bc.grad) < 5e-4 * max(1.0, bc.grad.abs().max().item())
 
 
+def test_cost_volume_gradients_lds_privatised_scatter(ops, dev):
+    """Feature maps large enough (H*W >= 4096) for the LDS-privatised measurement-gradient kernel, including a pair whose
+    near planes do not fit the box (global-atomic spill) and odd sizes; checked against autograd through the oracle."""
+    g = torch.Generator().manual_seed(9)
+    for (B, C, H, W, D, pairs) in ((2, 8, 64, 80, 16, ((12, (9, 3)), (202, (196, 188)))), (1, 20, 72, 100, 24, ((141, (135,)),))):
+        a = torch.randn(B, C, H, W, generator=g)
+        bs = [torch.randn(B, C, H, W, generator=g) for _ in range(len(pairs[0][1]))]
+        p1 = torch.cat([syn.pose(pairs[b % len(pairs)][0]) for b in range(B)])
+        p2s = [torch.cat([syn.pose(pairs[b % len(pairs)][1][m]) for b in range(B)]) for m in range(len(bs))]
+        K = torch.cat([syn.scaled_K(syn.full_K(), 320.0 / W)] * B)
+        go = torch.randn(B, D, H, W, generator=g)
+        ac, bc = a.clone().requires_grad_(True), [t.clone().requires_grad_(True) for t in bs]
+        orc.cost_volume_fusion(ac, bc, p1, p2s, K, 0.25, 20.0, D, True).backward(go)
+        ad, bd = a.to(dev).requires_grad_(True), [t.to(dev).requires_grad_(True) for t in bs]
+        ops.cost_volume(ad, bd, p1.to(dev), [p.to(dev) for p in p2s], K.to(dev), 0.25, 20.0, D, True, 0).backward(go.to(dev))
+        assert maxerr(ad.grad, ac.grad) < 5e-4 * max(1.0, ac.grad.abs().max().item())
+        for x, y in zip(bd, bc):
+            assert maxerr(x.grad, y.grad) < 5e-4 * max(1.0, y.grad.abs().max().item()), (B, C, H, W)
+            assert (x.grad.cpu() - y.grad).abs().mean().item() < 2e-5 * max(1.0, y.grad.abs().mean().item())
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # depth re-projection
 # ----------------------------------------------------------------------------------------------------------------------
