@@ -205,7 +205,9 @@ def train_mode(args, world, rank, device):
     import synthetic as syn
     from dvmvs.config import Config
     from dvmvs.training import BucketedGradientReducer, train_step
-    torch.backends.cudnn.benchmark = True
+    # no exhaustive MIOpen search here: a training step has ~300 distinct forward / backward-data / backward-weight problems
+    # and searching them all takes many minutes on a fresh box
+    torch.backends.cudnn.benchmark = False
     model = [m.to(device).train() for m in build_modules()]
     params = [p for m in model for p in m.parameters()]
     reducer = BucketedGradientReducer(params)
