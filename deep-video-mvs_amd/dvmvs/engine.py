@@ -297,8 +297,8 @@ class DepthEngine:
         return s["depth"]
 
     def _capture(self, key):
-        """Captures the frame body for ``key``.  Capture executes nothing, but the body mutates state buffers when the
-        graph is replayed, so the state is snapshotted around the (side-effect free) capture itself."""
+        """Captures the frame body for ``key`` into a hipGraph.  Capture only records the launches (nothing executes, no
+        state buffer changes); the caller replays the graph to actually run the frame."""
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):

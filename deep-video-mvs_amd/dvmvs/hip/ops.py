@@ -5,7 +5,7 @@ pointers and the current HIP stream to the ``extern "C"`` launcher.  No op synch
 whole frame can be captured into a hipGraph (``torch.cuda.graph``).  Tensors that are not on the GPU are rejected:
 the CPU restatement lives in ``oracle/`` and is test infrastructure only.
 """
-from typing import List, Sequence, Tuple
+from typing import Sequence, Tuple
 
 import torch
 from torch import Tensor
