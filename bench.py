@@ -263,6 +263,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the plane-sweep path has no CPU fallback")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # host threads: the box's CPU quota is shared by all ranks (weight initialisation and BN folding run on the CPU)
+    torch.set_num_threads(max(1, min(usable_cores() // max(world, 1), 16)))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
