@@ -102,7 +102,9 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
     pose_ptrs = _capi.pointer_array([t.data_ptr() for t in s["meas_pose"][:n_meas]])
     lib = _capi.lib()
     from dvmvs import utils
-    ws_bytes = lib.dvmvs_cost_volume_workspace_bytes(B, n_meas)
+    from dvmvs.hip import ops as _ops
+    ws_bytes = (lib.dvmvs_cost_volume_workspace_bytes_two_pass(B, n_meas, H, W, D) if _ops.COST_VOLUME_TWO_PASS
+                else lib.dvmvs_cost_volume_workspace_bytes(B, n_meas))
     workspace = torch.empty((ws_bytes + 3) // 4, device=ref.device)
 
     def launch():

@@ -306,6 +306,16 @@ __global__ __launch_bounds__(TW* TH) void cost_volume_tiled_kernel(CostVolumeArg
           }
           __syncthreads();
         }
+      } else if (state == 0 && a.spill != nullptr) {
+        // Footprint cannot be staged and the caller provided a spill list: hand the segment to the second pass
+        // (cost_volume_spill_kernel), which spreads such segments over the whole chip instead of leaving a few
+        // workgroups with a long tail.  This workgroup contributes nothing for these planes of frame m.
+        if (tid == 0) {
+          const unsigned int slot = atomicAdd(a.spill, 1u);
+          a.spill[4 + 2 * slot] = (static_cast<unsigned int>(b) << 16) | static_cast<unsigned int>(blockIdx.x);
+          a.spill[5 + 2 * slot] = (static_cast<unsigned int>(d_block / DP) << 16) | (static_cast<unsigned int>(m) << 10) |
+                                  (static_cast<unsigned int>(seg_lo) << 5) | static_cast<unsigned int>(seg_len);
+        }
       } else if (state == 0 && live) {
         // Footprint cannot be staged: taps straight from global memory.  The gathers are scattered (a different cache
         // line per lane and channel), so what matters is memory-level parallelism: two planes x four taps x eight
@@ -426,16 +436,24 @@ int launch_cost_volume_tiled_layout(const CostVolumeArgs& a, hipStream_t stream)
   return launch_status();
 }
 
+template <int TW, int TH, int DP>
+__global__ void cost_volume_spill_kernel(CostVolumeArgs a);
+
 template <int TW, int TH, int DP, int CCH, int CAP>
 int launch_cost_volume_tiled(const CostVolumeArgs& a, hipStream_t stream) {
   if (a.image2_nhwc) return launch_cost_volume_tiled_layout<TW, TH, DP, CCH, CAP, true>(a, stream);
-  return launch_cost_volume_tiled_layout<TW, TH, DP, CCH, CAP, false>(a, stream);
+  const int rc = launch_cost_volume_tiled_layout<TW, TH, DP, CCH, CAP, false>(a, stream);
+  if (rc != 0 || a.spill == nullptr) return rc;
+  static_assert(DP <= 31 && TW * TH <= 1024, "spill item encoding");
+  hipLaunchKernelGGL((cost_volume_spill_kernel<TW, TH, DP>), dim3(1024), dim3(TW * TH), 0, stream, a);
+  return launch_status();
 }
 
 // One thread per (batch, measurement frame): the matrices above into the caller's workspace, so that the sweep
 // kernels (hundreds of workgroups) do not each repeat the fp64 inverse.
-__global__ void sweep_setup_kernel(CostVolumeArgs a, float* setup) {
+__global__ void sweep_setup_kernel(CostVolumeArgs a, float* setup, unsigned int* spill) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && spill != nullptr) spill[0] = 0u;   // empty spill list for the sweep launch that follows on the stream
   if (i >= a.B * a.M) return;
   const int b = i / a.M, m = i - b * a.M;
   float Hm[9], kt[3];
@@ -447,12 +465,107 @@ __global__ void sweep_setup_kernel(CostVolumeArgs a, float* setup) {
   for (int k = 0; k < 3; ++k) out[9 + k] = kt[k];
 }
 
+// Second pass of the tiled sweep: the (tile, measurement frame, plane segment) items whose footprint did not fit in LDS.
+// One workgroup per item (grid-stride over the list), 256 threads = the tile's pixels, gathers straight from global
+// memory with 32 loads in flight, result ADDED to the volume the first pass already wrote (atomicAdd: two measurement
+// frames may spill the same pixel and plane).  Arithmetic per sample is the generic kernel's.
+template <int TW, int TH, int DP>
+__global__ __launch_bounds__(TW* TH) void cost_volume_spill_kernel(CostVolumeArgs a) {
+  const unsigned int count = a.spill[0];
+  const int tid = threadIdx.x;
+  const int HW = a.H * a.W;
+  const int tiles_x = (a.W + TW - 1) / TW;
+  for (unsigned int it = blockIdx.x; it < count; it += gridDim.x) {
+    const unsigned int w0 = a.spill[4 + 2 * it], w1 = a.spill[5 + 2 * it];
+    const int b = static_cast<int>(w0 >> 16), tile = static_cast<int>(w0 & 0xffffu);
+    const int chunk = static_cast<int>(w1 >> 16), m = static_cast<int>((w1 >> 10) & 0x3fu);
+    const int seg_lo = static_cast<int>((w1 >> 5) & 0x1fu), seg_len = static_cast<int>(w1 & 0x1fu);
+    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+    const int x = tile_x * TW + tid % TW, y = tile_y * TH + tid / TW;
+    if (x >= a.W || y >= a.H) continue;
+    const float xf = static_cast<float>(x), yf = static_cast<float>(y);
+    const int pix = y * a.W + x;
+    const float* setup = a.setup + (static_cast<size_t>(b) * a.M + m) * kSetupFloats;   // Hm (9) + kt (3)
+    float Hm[9], kt[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Hm[k] = setup[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) kt[k] = setup[9 + k];
+    const float* meas = a.image2[m] + static_cast<size_t>(b) * a.C * HW;
+    const float* ref = a.image1 + static_cast<size_t>(b) * a.C * HW + pix;
+    const float norm = 1.0f / (static_cast<float>(a.C) * static_cast<float>(a.M));
+    constexpr int kPair = 2, kChan = 4;
+    for (int j0 = seg_lo; j0 < seg_lo + seg_len; j0 += kPair) {
+      int off[kPair][4];
+      float wgt[kPair][4], part[kPair];
+#pragma unroll
+      for (int u = 0; u < kPair; ++u) {
+        const int j = min(j0 + u, seg_lo + seg_len - 1);
+        const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, chunk * DP + j);
+        const float ktd[3] = {kt[0] / depth, kt[1] / depth, kt[2] / depth};   // same expression as sweep_setup's table
+        float ix, iy;
+        sweep_position(Hm, ktd, xf, yf, a.W, a.H, &ix, &iy);
+        const BilinearTaps t = make_taps(ix, iy, a.W, a.H);
+        const int xa = t.in_x0 ? t.x0 : 0, xb = t.in_x1 ? t.x0 + 1 : 0;
+        const int ya = t.in_y0 ? t.y0 : 0, yb = t.in_y1 ? t.y0 + 1 : 0;
+        off[u][0] = ya * a.W + xa; off[u][1] = ya * a.W + xb; off[u][2] = yb * a.W + xa; off[u][3] = yb * a.W + xb;
+        const bool on = j0 + u < seg_lo + seg_len;
+        wgt[u][0] = (on && t.in_x0 && t.in_y0) ? t.w_nw : 0.0f;
+        wgt[u][1] = (on && t.in_x1 && t.in_y0) ? t.w_ne : 0.0f;
+        wgt[u][2] = (on && t.in_x0 && t.in_y1) ? t.w_sw : 0.0f;
+        wgt[u][3] = (on && t.in_x1 && t.in_y1) ? t.w_se : 0.0f;
+        part[u] = 0.0f;
+      }
+      float any_w = 0.0f;
+#pragma unroll
+      for (int u = 0; u < kPair; ++u) any_w += wgt[u][0] + wgt[u][1] + wgt[u][2] + wgt[u][3];
+      if (!__any(any_w != 0.0f)) continue;   // the whole wave samples outside the image for this plane pair
+      for (int c0 = 0; c0 < a.C; c0 += kChan) {
+        float v[kChan][kPair][4], r[kChan];
+#pragma unroll
+        for (int cc = 0; cc < kChan; ++cc) {
+          const int c = min(c0 + cc, a.C - 1);
+          const float* plane = meas + static_cast<size_t>(c) * HW;
+          r[cc] = (c0 + cc < a.C) ? ref[static_cast<size_t>(c) * HW] : 0.0f;
+#pragma unroll
+          for (int u = 0; u < kPair; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[cc][u][t] = plane[off[u][t]];
+        }
+#pragma unroll
+        for (int cc = 0; cc < kChan; ++cc)
+#pragma unroll
+          for (int u = 0; u < kPair; ++u) {
+            float t = v[cc][u][0] * wgt[u][0];
+            t += v[cc][u][1] * wgt[u][1];
+            t += v[cc][u][2] * wgt[u][2];
+            t += v[cc][u][3] * wgt[u][3];
+            part[u] += r[cc] * t;
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < kPair; ++u)
+        if (j0 + u < seg_lo + seg_len && part[u] != 0.0f)
+          atomicAdd(a.out + (static_cast<size_t>(b) * a.D + chunk * DP + j0 + u) * HW + pix, part[u] * norm);
+    }
+  }
+}
 
 }  // namespace dvmvs
 
 extern "C" size_t dvmvs_cost_volume_workspace_bytes(int B, int M) {
   if (B <= 0 || M <= 0) return 0;
   return sizeof(float) * static_cast<size_t>(B) * M * dvmvs::kSetupFloats;
+}
+
+// Workspace that additionally holds the spill list of the two-pass tiled sweep: set-up block (rounded to 16 bytes),
+// 4 header words, then two words per possible item (every (batch, tile, plane chunk, frame) may spill up to 8 segments).
+extern "C" size_t dvmvs_cost_volume_workspace_bytes_two_pass(int B, int M, int H, int W, int D) {
+  if (B <= 0 || M <= 0 || H <= 0 || W <= 0 || D <= 0) return 0;
+  const size_t setup = (dvmvs_cost_volume_workspace_bytes(B, M) + 15) / 16 * 16;
+  const size_t tiles = static_cast<size_t>((W + 31) / 32) * ((H + 7) / 8);
+  const size_t items = static_cast<size_t>(B) * tiles * ((D + 7) / 8) * M * 8;
+  return setup + sizeof(unsigned int) * (4 + 2 * items);
 }
 
 extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, const float* pose1,
@@ -473,7 +586,14 @@ extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* im
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (workspace != nullptr) {
     if (workspace_bytes < dvmvs_cost_volume_workspace_bytes(B, M)) return DVMVS_EINVAL;
-    hipLaunchKernelGGL(sweep_setup_kernel, dim3((B * M + 63) / 64), dim3(64), 0, s, a, workspace);
+    unsigned int* spill = nullptr;
+    // a workspace large enough for the spill list switches the tiled sweep to its two-pass form (NCHW maps, tiles indexable
+    // in 16 bits, batch < 65536)
+    if (workspace_bytes >= dvmvs_cost_volume_workspace_bytes_two_pass(B, M, H, W, D) && !a.image2_nhwc &&
+        static_cast<size_t>((W + 31) / 32) * ((H + 7) / 8) <= 65535)
+      spill = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(workspace) + (dvmvs_cost_volume_workspace_bytes(B, M) + 15) / 16 * 16);
+    hipLaunchKernelGGL(sweep_setup_kernel, dim3((B * M + 63) / 64), dim3(64), 0, s, a, workspace, spill);
+    a.spill = spill;
     const int src = launch_status();
     if (src != 0) return src;
     a.setup = workspace;

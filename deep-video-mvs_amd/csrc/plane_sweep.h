@@ -16,6 +16,7 @@ struct CostVolumeArgs {
   int B, M, C, H, W, D;
   double inv_depth_base, inv_depth_step;
   int image2_nhwc;     // measurement maps are channels-last ([B,H,W,C]); reference map and output stay NCHW
+  unsigned int* spill;   // optional spill list: [0] = item count, [4..] = items (2 words each); nullptr = spill inline
   const float* setup;  // optional [B][M][12]: Hm (9) + kt (3) written by sweep_setup_kernel; nullptr = derive per workgroup
 };
 
@@ -112,6 +113,7 @@ inline int fill_sweep_args(CostVolumeArgs* a, const float* image1, const float* 
   a->inv_depth_base = 1.0 / max_depth;
   a->inv_depth_step = D > 1 ? (1.0 / min_depth - 1.0 / max_depth) / (D - 1) : 0.0;
   a->setup = nullptr;
+  a->spill = nullptr;
   a->image2_nhwc = 0;
   return 0;
 }

@@ -33,6 +33,7 @@ SIGNATURES = {
     "dvmvs_build_arch": (ctypes.c_char_p, []),
     "dvmvs_error_string": (ctypes.c_char_p, [_c_int]),
     "dvmvs_cost_volume_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
+    "dvmvs_cost_volume_workspace_bytes_two_pass": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "dvmvs_cost_volume_fwd": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fpp, _c_fp, _c_fp,
                                        _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                        _c_dbl, _c_dbl, _c_int, _c_int, _c_int, _c_fp, ctypes.c_size_t, _c_stream]),

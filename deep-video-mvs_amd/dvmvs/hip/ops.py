@@ -5,6 +5,7 @@ pointers and the current HIP stream to the ``extern "C"`` launcher.  No op synch
 whole frame can be captured into a hipGraph (``torch.cuda.graph``).  Tensors that are not on the GPU are rejected:
 the CPU restatement lives in ``oracle/`` and is test infrastructure only.
 """
+import os
 from typing import Sequence, Tuple
 
 import torch
@@ -14,6 +15,10 @@ from dvmvs.hip import _capi
 
 __all__ = ["cost_volume", "hidden_warp", "relative_pose", "lstm_gates", "depth_reproject", "depth_reproject_lowres",
            "bias_act_", "upsample2x", "depthwise_conv"]
+
+
+# two-pass tiled sweep (spill list in the workspace): see dvmvs_cost_volume_workspace_bytes_two_pass in the header
+COST_VOLUME_TWO_PASS = os.environ.get("DVMVS_COST_VOLUME_TWO_PASS", "1") == "1"
 
 
 def _no_cpu(op):
@@ -62,7 +67,8 @@ def cost_volume(image1: Tensor, image2s: Sequence[Tensor], pose1: Tensor, pose2s
     K = K.contiguous()
     out = torch.empty((B, n_depth_levels, H, W), dtype=torch.float32, device=image1.device)
     lib = _capi.lib()
-    ws_bytes = lib.dvmvs_cost_volume_workspace_bytes(B, M)
+    ws_bytes = (lib.dvmvs_cost_volume_workspace_bytes_two_pass(B, M, H, W, n_depth_levels) if COST_VOLUME_TWO_PASS and not nhwc
+                else lib.dvmvs_cost_volume_workspace_bytes(B, M))
     workspace = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=image1.device)
     with torch.cuda.device(image1.device):
         rc = lib.dvmvs_cost_volume_fwd(

@@ -66,6 +66,10 @@ const char* dvmvs_error_string(int code);
  *               launch, slightly longer).  Either way they are computed on the device from the poses (fp64).
  */
 size_t dvmvs_cost_volume_workspace_bytes(int B, int M);
+/* Larger workspace that also holds a spill list: given at least this many bytes, the LDS-tiled sweep runs in two passes --
+ * tiles whose sample footprint does not fit in LDS are queued by the first launch and processed by a second, finely
+ * grained gather launch spread over the whole chip (no long tail on wide-baseline / forward-motion pairs). */
+size_t dvmvs_cost_volume_workspace_bytes_two_pass(int B, int M, int H, int W, int D);
 int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, const float* pose1,
                           const float* const* pose2s, const float* K, float* cost_volume,
                           int B, int M, int C, int H, int W, int D,

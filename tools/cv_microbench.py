@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--no-workspace", action="store_true")
     ap.add_argument("--baseline-step", type=int, default=1, help="measurement frame m is keyframe k-(m+1)*step")
     ap.add_argument("--keyframe", type=int, default=8, help="position along the synthetic trajectory (changes the epipolar geometry)")
+    ap.add_argument("--two-pass", action="store_true", help="give the sweep the large workspace (spill list, second gather pass)")
     ap.add_argument("--nhwc", action="store_true", help="measurement maps channels-last (DVMVS_LAYOUT_NHWC)")
     ap.add_argument("--real-line", type=int, default=-1, help="use the poses of this line of the sample scene's nmeas+2 keyframe index")
     args = ap.parse_args()
@@ -49,7 +50,7 @@ def main():
     K = syn.scaled_K(syn.full_K(), 2.0).repeat(B, 1, 1).to(dev)
     out = torch.empty(B, D, H, W, device=dev)
     ref_out = torch.empty_like(out)
-    ws_bytes = lib.dvmvs_cost_volume_workspace_bytes(B, M)
+    ws_bytes = lib.dvmvs_cost_volume_workspace_bytes_two_pass(B, M, H, W, D) if args.two_pass else lib.dvmvs_cost_volume_workspace_bytes(B, M)
     ws = torch.empty((ws_bytes + 3) // 4, device=dev)
     layout = 1 if args.nhwc else 0
     meas = [t.contiguous(memory_format=torch.channels_last) if args.nhwc else t for t in feats[1:]]
