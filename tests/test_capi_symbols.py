@@ -58,6 +58,14 @@ def test_argument_validation_without_gpu(library):
     assert lib.dvmvs_cost_volume_workspace_bytes(2, 3) == 2 * 3 * 12 * 4
 
 
+def test_workspace_sizes(library):
+    lib = library.lib()
+    assert lib.dvmvs_cost_volume_workspace_bytes(1, 2) == 96
+    # set-up block (96 B) + 4 header words + 2 words for each of 1 * (5 * 16 tiles) * 8 plane chunks * 2 frames * 8 segments
+    assert lib.dvmvs_cost_volume_workspace_bytes_two_pass(1, 2, 128, 160, 64) == 96 + 4 * (4 + 2 * 80 * 8 * 2 * 8)
+    assert lib.dvmvs_cost_volume_workspace_bytes_two_pass(0, 2, 128, 160, 64) == 0
+
+
 def test_code_object_is_gfx950(library):
     blob = open(library.LIB_PATH, "rb").read()
     assert b"gfx950" in blob and b"gfx942" not in blob and b"sm_" not in blob
