@@ -99,3 +99,25 @@ class SimpleBuffer(_PoseBuffer):
 
     def get_measurement_frames(self):
         return list(self.buffer)[:-1]
+
+
+def simulate_keyframe_index(poses, image_names, n_measurement_frames, buffer_size=30, keyframe_pose_distance=0.1,
+                            optimal_t_measure=0.15, optimal_R_measure=0.0):
+    """Offline keyframe selection over a whole pose list: the lines of a ``keyframe+<dataset>+<scene>+nmeas+<n>`` index file
+    ("ref meas1 meas2 ..." per accepted keyframe, "TRACKING LOST" where the buffer was cleared), as produced by
+    /root/reference/dvmvs/simulate_keyframe_buffer.py:7-51 with the same defaults."""
+    buffer = KeyframeBuffer(buffer_size, keyframe_pose_distance, optimal_t_measure, optimal_R_measure, store_return_indices=True)
+    lines = []
+    for i, pose in enumerate(poses):
+        response = buffer.try_new_keyframe(pose, None, index=i)
+        if response == 3:
+            lines.append("TRACKING LOST")
+        elif response == 1:
+            measurement_frames = buffer.get_best_measurement_frames(n_measurement_frames)
+            lines.append(" ".join([image_names[i]] + [image_names[frame[2]] for frame in measurement_frames]))
+    return lines
+
+
+def write_keyframe_index(path, lines):
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")

@@ -8,19 +8,8 @@ import synthetic as syn
 
 
 def replay(n_measurement_frames):
-    from dvmvs.keyframe_buffer import KeyframeBuffer
-    poses = syn.sample_poses()
-    names = syn.sample_image_names()
-    buf = KeyframeBuffer(buffer_size=30, keyframe_pose_distance=0.1, optimal_t_score=0.15, optimal_R_score=0.0, store_return_indices=True)
-    lines = []
-    for i in range(len(poses)):
-        code = buf.try_new_keyframe(poses[i], None, index=i)
-        if code == 3:
-            lines.append("TRACKING LOST")
-        elif code == 1:
-            meas = buf.get_best_measurement_frames(n_measurement_frames)
-            lines.append(" ".join([names[i]] + [names[m[2]] for m in meas]))
-    return lines
+    from dvmvs.keyframe_buffer import simulate_keyframe_index
+    return simulate_keyframe_index(syn.sample_poses(), syn.sample_image_names(), n_measurement_frames)
 
 
 def test_replay_reproduces_the_shipped_index_files(golden_dir):
@@ -29,6 +18,19 @@ def test_replay_reproduces_the_shipped_index_files(golden_dir):
         got = replay(n)
         assert len(got) == len(shipped) == 286
         assert got == shipped, next((a, b) for a, b in zip(got, shipped) if a != b)
+
+
+def test_index_file_round_trip(tmp_path):
+    from dvmvs.keyframe_buffer import simulate_keyframe_index, write_keyframe_index
+    poses = syn.sample_poses().copy()
+    poses[100:140] = np.nan                       # 40 frames without a pose: tracking is declared lost after 30
+    lines = simulate_keyframe_index(poses, syn.sample_image_names(), 2)
+    assert lines.count("TRACKING LOST") == 1
+    lost = lines.index("TRACKING LOST")
+    assert len(lines[lost + 1].split(" ")) == 2    # the buffer restarts: first keyframe after the loss has one measurement frame
+    path = os.path.join(str(tmp_path), "keyframe+test+000+nmeas+2")
+    write_keyframe_index(path, lines)
+    assert [l for l in open(path).read().split("\n") if l] == lines
 
 
 def test_response_codes_and_tracking_loss():
