@@ -206,6 +206,31 @@ def test_cost_volume_channels_last_measurement_maps(ops, dev):
         as_accurate_as_reference(nhwc[:1], exp, exp64, floor=1e-5)
 
 
+def test_cost_volume_limits(ops, dev):
+    """Maximum measurement-frame and plane counts the ABI accepts (8 and 256), one step beyond, and degenerate arguments."""
+    g = torch.Generator().manual_seed(31)
+    B, C, H, W, D, M = 1, 4, 64, 64, 256, 8
+    f1 = torch.randn(B, C, H, W, generator=g)
+    f2s = [torch.randn(B, C, H, W, generator=g) for _ in range(M)]
+    p1 = syn.pose(20)
+    p2s = [syn.pose(20 - 1 - m) for m in range(M)]
+    K = syn.scaled_K(syn.full_K(), 320.0 / W)
+    exp = orc.cost_volume_fusion(f1, f2s, p1, p2s, K, 0.25, 20.0, D, True)
+    for variant in (1, 2):
+        got = run_cv(ops, dev, f1, f2s, p1, p2s, K, 0.25, 20.0, D, True, variant)
+        assert maxerr(got, exp) < 5e-4 * max(1.0, exp.abs().max().item()), variant
+    with pytest.raises(RuntimeError, match="not supported"):      # 9 measurement frames
+        run_cv(ops, dev, f1, f2s + [f2s[0]], p1, p2s + [p2s[0]], K, 0.25, 20.0, 16, True, 0)
+    with pytest.raises(RuntimeError, match="not supported"):      # 257 planes
+        run_cv(ops, dev, f1, f2s[:1], p1, p2s[:1], K, 0.25, 20.0, 257, True, 0)
+    with pytest.raises(RuntimeError, match="invalid argument"):   # non-positive depth range
+        run_cv(ops, dev, f1, f2s[:1], p1, p2s[:1], K, 0.0, 20.0, 16, True, 0)
+    with pytest.raises(ValueError):                                # no measurement frame at all
+        run_cv(ops, dev, f1, [], p1, [], K, 0.25, 20.0, 16, True, 0)
+    with pytest.raises(RuntimeError, match="not supported"):      # SAD has no tiled kernel
+        run_cv(ops, dev, f1, f2s[:1], p1, p2s[:1], K, 0.25, 20.0, 16, False, 2)
+
+
 def test_cost_volume_surface_and_errors(utils, dev):
     halfK = syn.scaled_K(syn.full_K(), 2.0)
     f = [syn.analytic_features(s, 8, 32, 40) for s in range(2)]
