@@ -131,6 +131,15 @@ def test_bn_folding_is_exact_enough():
     assert list(enc.state_dict().keys())[0] == "aggregator0.0.weight"   # the original module is untouched
 
 
+def test_error_metrics_match_the_reference(golden_dir):
+    import numpy as np
+    from dvmvs.errors import compute_errors
+    z = np.load(os.path.join(golden_dir, "error_metrics.npz"))
+    np.testing.assert_allclose(compute_errors(z["gt"], z["pred"]), z["all_pixels"], rtol=1e-12)
+    np.testing.assert_allclose(compute_errors(z["gt"], z["pred"], 2.0), z["max_depth_2"], rtol=1e-12)
+    assert np.isnan(z["nothing_valid"]).all() and all(np.isnan(v) for v in compute_errors(np.zeros((4, 4)), np.ones((4, 4))))
+
+
 def test_errors_module():
     import numpy as np
     from dvmvs.errors import compute_errors
