@@ -342,11 +342,8 @@ def keyframe_goldens(ref):
 
 def error_metric_goldens(ref):
     """The eight depth metrics of dvmvs/errors.py:4-28 on deterministic maps (incl. invalid pixels and a max_depth cut)."""
-    gt = syn.analytic_depth().numpy()[0, 0].astype(np.float64)
-    gt[:20, :30] = 0.0                                     # below the 0.5 m validity threshold
-    pred = gt * (1.0 + 0.1 * np.sin(np.arange(320) / 17.0))[None, :] + 0.05
-    pred[:20, :30] = 1.0
-    save("error_metrics", gt=gt, pred=pred, all_pixels=np.array(ref.errors.compute_errors(gt, pred)),
+    gt, pred = syn.error_metric_inputs()
+    save("error_metrics", all_pixels=np.array(ref.errors.compute_errors(gt, pred)),
          max_depth_2=np.array(ref.errors.compute_errors(gt, pred, 2.0)),
          nothing_valid=np.array(ref.errors.compute_errors(np.zeros((4, 4)), np.ones((4, 4)))))
 

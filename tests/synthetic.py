@@ -228,3 +228,12 @@ def sample_image_name(pose_index):
 
 def e2e_image(index):
     return smooth_noise((1, 3, 256, 320), seed=2000 + index)
+
+
+def error_metric_inputs():
+    """Deterministic (ground truth, prediction) pair for the evaluation-metric golden: invalid pixels (< 0.5 m) included."""
+    gt = analytic_depth().numpy()[0, 0].astype(np.float64)
+    gt[:20, :30] = 0.0
+    pred = gt * (1.0 + 0.1 * np.sin(np.arange(320) / 17.0))[None, :] + 0.05
+    pred[:20, :30] = 1.0
+    return gt, pred
