@@ -551,6 +551,11 @@ __global__ __launch_bounds__(TW* TH) void cost_volume_spill_kernel(CostVolumeArg
   }
 }
 
+// sweep_tiled.hip
+size_t sweep_spill_words(int B, int M, int H, int W, int D);
+int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream);
+int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream);
+
 }  // namespace dvmvs
 
 extern "C" size_t dvmvs_cost_volume_workspace_bytes(int B, int M) {
@@ -565,7 +570,9 @@ extern "C" size_t dvmvs_cost_volume_workspace_bytes_two_pass(int B, int M, int H
   const size_t setup = (dvmvs_cost_volume_workspace_bytes(B, M) + 15) / 16 * 16;
   const size_t tiles = static_cast<size_t>((W + 31) / 32) * ((H + 7) / 8);
   const size_t items = static_cast<size_t>(B) * tiles * ((D + 7) / 8) * M * 8;
-  return setup + sizeof(unsigned int) * (4 + 2 * items);
+  const size_t legacy_words = 4 + 2 * items;
+  const size_t words = dvmvs::sweep_spill_words(B, M, H, W, D);
+  return setup + sizeof(unsigned int) * (words > legacy_words ? words : legacy_words);
 }
 
 extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, const float* pose1,
@@ -575,8 +582,8 @@ extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* im
                                      float* workspace, size_t workspace_bytes, dvmvs_stream_t stream) {
   using namespace dvmvs;
   if (image2_layout != DVMVS_LAYOUT_NCHW && image2_layout != DVMVS_LAYOUT_NHWC) return DVMVS_EINVAL;
-  if (variant < 0 || (variant > 2 && variant < 16) || variant > 31) return DVMVS_EINVAL;
-  if (variant == 2 && !dot_product) return DVMVS_EUNSUPPORTED;
+  if (variant < 0 || (variant > 3 && variant < 16) || variant > 63) return DVMVS_EINVAL;
+  if ((variant == 2 || variant == 3) && !dot_product) return DVMVS_EUNSUPPORTED;
   CostVolumeArgs a;
   const int rc = fill_sweep_args(&a, image1, image2s, pose1, pose2s, K, cost_volume, B, M, C, H, W, D, min_depth, max_depth, true);
   if (rc != 0) return rc;
@@ -589,14 +596,19 @@ extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* im
     unsigned int* spill = nullptr;
     // a workspace large enough for the spill list switches the tiled sweep to its two-pass form (NCHW maps, tiles indexable
     // in 16 bits, batch < 65536)
-    if (workspace_bytes >= dvmvs_cost_volume_workspace_bytes_two_pass(B, M, H, W, D) && !a.image2_nhwc &&
-        static_cast<size_t>((W + 31) / 32) * ((H + 7) / 8) <= 65535)
+    const bool legacy = variant == 3 || (variant >= 16 && variant < 32);
+    if (workspace_bytes >= dvmvs_cost_volume_workspace_bytes_two_pass(B, M, H, W, D) &&
+        (!legacy || (!a.image2_nhwc && static_cast<size_t>((W + 31) / 32) * ((H + 7) / 8) <= 65535)))
       spill = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(workspace) + (dvmvs_cost_volume_workspace_bytes(B, M) + 15) / 16 * 16);
     hipLaunchKernelGGL(sweep_setup_kernel, dim3((B * M + 63) / 64), dim3(64), 0, s, a, workspace, spill);
     a.spill = spill;
     const int src = launch_status();
     if (src != 0) return src;
     a.setup = workspace;
+  }
+  if (variant >= 32) {
+    if (!dot_product) return DVMVS_EUNSUPPORTED;
+    return launch_sweep_tuning(variant - 32, a, s);
   }
   if (variant >= 16) {
     // tuning configurations for tools/cv_microbench.py (TW, TH, DP, CCH, CAP); not part of the stable interface
@@ -617,7 +629,8 @@ extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* im
       default: return DVMVS_EINVAL;
     }
   }
+  if (variant == 3) return launch_cost_volume_tiled<32, 8, 8, 16, 640>(a, s);   // round-1 kernel, kept for A/B timing
   const bool tiled = dot_product && (variant == 2 || a.image2_nhwc || (variant == 0 && H * W >= 64 * 64));
-  if (tiled) return launch_cost_volume_tiled<32, 8, 8, 16, 640>(a, s);
+  if (tiled) return launch_sweep_default(a, s);
   return launch_cost_volume_generic(a, dot_product != 0, s);
 }

@@ -11,6 +11,17 @@ namespace dvmvs {
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// Pointers that reach a kernel inside a by-value argument struct are generic ("flat") to the compiler: every access
+// becomes a flat_load / flat_store, which is counted on BOTH vmcnt and lgkmcnt and therefore serialises against the
+// ds_read waits of the LDS-bound sweep kernels.  Hot paths re-type them as global (address space 1) once, at the top.
+#define DVMVS_GLOBAL __attribute__((address_space(1)))
+typedef const float DVMVS_GLOBAL* gcfloat_p;
+typedef float DVMVS_GLOBAL* gfloat_p;
+typedef unsigned int DVMVS_GLOBAL* guint_p;
+__device__ inline gcfloat_p as_global(const float* p) { return (gcfloat_p)p; }
+__device__ inline gfloat_p as_global(float* p) { return (gfloat_p)p; }
+__device__ inline guint_p as_global(unsigned int* p) { return (guint_p)p; }
+
 #define DVMVS_RETURN_IF_HIP(expr)                      \
   do {                                                 \
     hipError_t _e = (expr);                            \

@@ -1,0 +1,707 @@
+// LDS-staged plane sweep (dot-product mode) for gfx950: the fused warp + correlation kernel of the hot path.
+// Semantics: /root/reference/dvmvs/utils.py:45-107; CPU restatement: oracle/dvmvs_oracle.py.
+//
+// A workgroup owns a TW x TH tile of reference pixels and DP consecutive sweep planes, one thread per pixel.  For one
+// measurement frame the samples of the tile over a run of planes ("segment") lie inside the bounding box of 8 points
+// (4 tile corners x first / last plane of the run): a plane-induced homography maps the tile to a convex quadrilateral
+// and the position moves monotonically along the epipolar line with inverse depth while Z stays positive.  That box,
+// with a zero apron that implements grid_sample's zeros padding, is copied once from the measurement map into LDS as
+// channel-interleaved records of CCH floats (+4 floats of padding: a record stride of an odd number of 16-byte slots
+// keeps the 16 lanes of a ds_read_b128 service group on different banks).
+//
+// What is different from a generic "gather" formulation, and why (MI355X_MICROARCH.md, LDS section):
+//   * the binding resource is the LDS read pipe (4 taps x C channels x 4 B per sample = 1.3 GB per frame against
+//     ~150 TB/s of ds_read_b128 bandwidth), so everything else is arranged to stay out of its way;
+//   * the box is found by every wave on its own (8 lanes evaluate the corners, three xor-shuffles reduce, readfirstlane
+//     makes it scalar): no LDS round trip and no barrier per segment attempt, and the segment length adapts per tile
+//     (DP planes, halved down to MINSEG while the box does not fit in CAP records);
+//   * per sample the set-up is one v_rcp_f32 (+ one Newton step) instead of two IEEE divisions, the
+//     normalise/un-normalise pair of grid_sample folded into one multiply, clamping instead of per-tap bounds tests
+//     (the apron supplies the zeros), and the tap accumulation is "dot per tap" (4 FMAs per channel, 4 more per sample)
+//     instead of "interpolate, then multiply" (5 per channel);
+//   * workgroups are numbered so that the 8 plane chunks of a tile AND neighbouring tiles land on the same XCD
+//     (blockIdx % 8 selects the XCD): a measurement footprint is then fetched into one L2 instead of up to eight;
+//   * segments that cannot be staged even at MINSEG planes (magnified / behind-camera footprints) are queued per
+//     workgroup ("spill group") and finished by sweep_spill_kernel, which walks whole groups in a fixed order with plain
+//     read-modify-writes: the volume is bit-reproducible run to run for any M.
+#include "plane_sweep.h"
+
+namespace dvmvs {
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// Raw buffer descriptors for the feature maps: a load whose byte offset is >= num_records returns 0 without touching
+// memory, which is exactly the zero apron of grid_sample(padding_mode='zeros') -- no exec-mask branches around the
+// staging loads -- and the channel-plane offset rides in the scalar offset operand, so a staged element costs no VALU
+// address arithmetic at all.
+constexpr unsigned int kBufferOutOfRange = 0x80000000u;   // > any offset inside a map (maps are < 2 GiB, checked on the host)
+__device__ inline __amdgpu_buffer_rsrc_t map_resource(gcfloat_p base, unsigned int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, static_cast<int>(bytes), 0x00020000);
+}
+__device__ inline float buffer_f32(__amdgpu_buffer_rsrc_t r, unsigned int voffset, unsigned int soffset) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, static_cast<int>(voffset), static_cast<int>(soffset), 0));
+}
+__device__ inline float4v buffer_f32x4(__amdgpu_buffer_rsrc_t r, unsigned int voffset, unsigned int soffset) {
+  return __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(voffset), static_cast<int>(soffset), 0));
+}
+__device__ inline float2v fma2(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
+
+// ---- geometry of one sample --------------------------------------------------------------------------------------------
+// [X0, Y0, Z0] = Hm * [x, y, 1] in the reference's op order (utils.py:68); per plane [X, Y, Z] = [X0, Y0, Z0] + K t / depth.
+struct SweepRay {
+  float X0, Y0, Z0;
+};
+
+__device__ inline SweepRay sweep_ray(const float* Hm, float xf, float yf) {
+  SweepRay r;
+  r.X0 = fmaf(Hm[2], 1.0f, fmaf(Hm[1], yf, Hm[0] * xf));
+  r.Y0 = fmaf(Hm[5], 1.0f, fmaf(Hm[4], yf, Hm[3] * xf));
+  r.Z0 = fmaf(Hm[8], 1.0f, fmaf(Hm[7], yf, Hm[6] * xf));
+  return r;
+}
+
+struct SweepScale {
+  float cW, cH;   // (W-1)/W, (H-1)/H: ((u - W/2)/(W/2) + 1)/2 * (W-1) == u * (W-1)/W
+  float Wf, Hf;
+};
+
+__device__ inline SweepScale sweep_scale(int W, int H) {
+  SweepScale s;
+  s.Wf = static_cast<float>(W);
+  s.Hf = static_cast<float>(H);
+  s.cW = static_cast<float>(W - 1) / s.Wf;
+  s.cH = static_cast<float>(H - 1) / s.Hf;
+  return s;
+}
+
+// Sample position in measurement-image pixels, clamped to [-1, W] x [-1, H]: everything at or beyond those bounds has
+// all four taps outside the image (zeros padding), and v_max/v_min return the non-NaN operand, so NaN (Z + 1e-8 == 0)
+// lands on -1 as well, where both taps are zero -- ATen's "non-finite coordinates fail the bounds test".
+__device__ inline void sweep_sample(const SweepRay& r, float kx, float ky, float kz, const SweepScale& s, float* ix, float* iy,
+                                    float* denom_out = nullptr) {
+  const float X = r.X0 + kx, Y = r.Y0 + ky, Z = r.Z0 + kz;
+  const float denom = Z + 1e-8f;
+  float rcp = __builtin_amdgcn_rcpf(denom);
+  rcp = fmaf(fmaf(-denom, rcp, 1.0f), rcp, rcp);   // one Newton step: <= 1 ulp, NaN/Inf propagate
+  if (denom_out) *denom_out = denom;
+  *ix = fminf(fmaxf((X * rcp) * s.cW, -1.0f), s.Wf);
+  *iy = fminf(fmaxf((Y * rcp) * s.cH, -1.0f), s.Hf);
+}
+
+// ---- wave-uniform sample box -------------------------------------------------------------------------------------------
+struct SampleBox {
+  int x_lo, y_lo, RW, RH;
+  int pitch;   // records per staged row: >= RW, congruent to 0 or +-1 mod 16 (see sweep_pitch_residue)
+  int state;   // 1: stage through LDS; 2: entirely outside the image (zeros); 0: does not fit / not well defined
+};
+
+// LDS bank conflicts of the tap reads (tools/lds_conflict_sim.py is the CPU model of what follows; numbers from it and from
+// SQ_LDS_BANK_CONFLICT agree).  A wave64 ds_read_b128 is served in four groups of 16 lanes ({0-3,12-15,20-27},
+// {4-11,16-19,28-31}, + 32), one LDS cycle per group when the 16 addresses fall on 16 different 16-byte slots
+// (slot = byte address / 16 mod 16), one more cycle per extra distinct address on a slot.  With an odd number of slots per
+// record, slot is a permutation of (record index mod 16), so a group is conflict-free iff its 16 record indices
+// rx + pitch * ry are distinct mod 16 (identical records broadcast).  Two things make that the common case:
+//   * sweep_lane_pixel: lanes are mapped to pixels so that each service group owns 16 CONSECUTIVE pixels of a tile row
+//     (the natural mapping spreads a group over 28 pixels, and any scale != 1 then wraps mod 16);
+//   * the row pitch of the staged box is chosen per box, congruent to 0, +1 or -1 (mod 16), from the direction in which
+//     consecutive pixels move through the measurement image: pitch = 0 makes the slot a function of the column only
+//     (right when every pixel step advances a column), pitch = +-1 makes column + row monotone along the run (right when
+//     rows change while a column repeats, i.e. under in-plane rotation with scale < 1).
+// Measured on the sample scene's keyframe pairs: 6.3-8.5 LDS cycles per ds_read_b128 -> 4.0-5.5 (4 = conflict-free).
+__device__ inline int sweep_lane_pixel(int lane32) {
+  // lanes {0-3,12-15,20-27} -> pixels 0-15, lanes {4-11,16-19,28-31} -> pixels 16-31
+  return lane32 < 4 ? lane32 : lane32 < 12 ? lane32 + 12 : lane32 < 16 ? lane32 - 8 : lane32 < 20 ? lane32 + 8 : lane32 < 28 ? lane32 - 12 : lane32;
+}
+
+__device__ inline int sweep_pitch_residue(float ax, float ay) {
+  const float aax = fabsf(ax), aay = fabsf(ay);
+  const float c = ceilf(15.0f * aax), r = ceilf(15.0f * aay);
+  const float cost0 = 15.0f * aay * fmaxf(0.0f, 1.0f - aax) + fmaxf(0.0f, c - 15.0f);   // rows change while a column repeats
+  const float cost1 = fmaxf(0.0f, c + r - 15.0f);                                         // column + row wraps past 16
+  if (!(cost1 < cost0)) return 0;
+  return ((ax < 0.0f) != (ay < 0.0f)) ? 15 : 1;
+}
+
+// Every lane evaluates corner (lane & 7) -- bit 0: right edge, bit 1: bottom edge, bit 2: last plane of the run -- so that
+// three xor-shuffles leave the extrema in all lanes; readfirstlane then moves them to SGPRs.  All waves of a workgroup
+// execute this on identical inputs and therefore agree.
+template <int TW, int TH, int CAP>
+__device__ inline SampleBox wave_sample_box(const CostVolumeArgs& a, const float* Hm, const float4v* ktd_m, int tile_x, int tile_y,
+                                            int j_lo, int j_hi, const SweepScale& sc, int lane) {
+  const int cx = (lane & 1) ? min(tile_x * TW + TW - 1, a.W - 1) : tile_x * TW;
+  const int cy = (lane & 2) ? min(tile_y * TH + TH - 1, a.H - 1) : tile_y * TH;
+  const float4v k = ktd_m[(lane & 4) ? j_hi : j_lo];
+  const SweepRay ray = sweep_ray(Hm, static_cast<float>(cx), static_cast<float>(cy));
+  // un-clamped position (the box test has to see how far outside the image the corner is)
+  const float denom = (ray.Z0 + k.z) + 1e-8f;
+  const float ux = ((ray.X0 + k.x) / denom) * sc.cW;
+  const float uy = ((ray.Y0 + k.y) / denom) * sc.cH;
+  // direction of a one-pixel step along the tile's top edge (lanes 0 and 1 hold its two ends on plane j_lo)
+  const float edge = static_cast<float>(max(1, min(tile_x * TW + TW - 1, a.W - 1) - tile_x * TW));
+  const float step_x = (__shfl(ux, 1) - __shfl(ux, 0)) / edge, step_y = (__shfl(uy, 1) - __shfl(uy, 0)) / edge;
+  float lo_x = ux, hi_x = ux, lo_y = uy, hi_y = uy;
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    lo_x = fminf(lo_x, __shfl_xor(lo_x, off));
+    hi_x = fmaxf(hi_x, __shfl_xor(hi_x, off));
+    lo_y = fminf(lo_y, __shfl_xor(lo_y, off));
+    hi_y = fmaxf(hi_y, __shfl_xor(hi_y, off));
+  }
+  // NaN-safe: v_min/v_max drop NaNs, so test the corner values themselves as well
+  const bool corner_ok = (ux > -1e6f) && (ux < 1e6f) && (uy > -1e6f) && (uy < 1e6f) && (denom > 1e-6f);
+  const bool finite = __all(corner_ok);
+  SampleBox box;
+  box.x_lo = box.y_lo = box.RW = box.RH = box.pitch = 0;
+  box.state = 0;
+  if (finite) {
+    const float Wf = sc.Wf, Hf = sc.Hf;
+    // 0.05 px of slack for round-off between the corner samples and interior pixels
+    const bool outside = (hi_x + 0.05f <= -1.0f) || (lo_x - 0.05f >= Wf) || (hi_y + 0.05f <= -1.0f) || (lo_y - 0.05f >= Hf);
+    if (outside) {
+      box.state = 2;
+    } else {
+      const int x_lo = max(-1, static_cast<int>(floorf(fmaxf(lo_x - 0.05f, -1.0f))));
+      const int y_lo = max(-1, static_cast<int>(floorf(fmaxf(lo_y - 0.05f, -1.0f))));
+      const int x_hi = min(a.W, static_cast<int>(floorf(fminf(hi_x + 0.05f, Wf)))) + 1;
+      const int y_hi = min(a.H, static_cast<int>(floorf(fminf(hi_y + 0.05f, Hf)))) + 1;
+      box.x_lo = __builtin_amdgcn_readfirstlane(x_lo);
+      box.y_lo = __builtin_amdgcn_readfirstlane(y_lo);
+      box.RW = __builtin_amdgcn_readfirstlane(x_hi - x_lo + 1);
+      box.RH = __builtin_amdgcn_readfirstlane(y_hi - y_lo + 1);
+      const int residue = __builtin_amdgcn_readfirstlane(sweep_pitch_residue(step_x, step_y));
+      box.pitch = box.RW + ((residue - box.RW) & 15);
+      box.state = (box.pitch * box.RH <= CAP) ? 1 : 0;
+    }
+  }
+  box.state = __builtin_amdgcn_readfirstlane(box.state);
+  return box;
+}
+
+// ---- gather path (no staging): taps straight from global memory ----------------------------------------------------------
+// One plane of one measurement frame for this thread's pixel: sum_c ref[c] * warped[c].  Used for runs of planes whose
+// footprint cannot be staged: by sweep_spill_kernel (second pass) and, when the caller gave no spill workspace, inline.
+// Eight channels x four taps = 32 independent loads are in flight before the first use.
+template <bool NHWC>
+__device__ inline float gather_plane(const CostVolumeArgs& a, gcfloat_p meas, gcfloat_p ref, int HW, const SweepRay& ray,
+                                     float kx, float ky, float kz, const SweepScale& sc) {
+  float ix, iy;
+  sweep_sample(ray, kx, ky, kz, sc, &ix, &iy);
+  const BilinearTaps t = make_taps(ix, iy, a.W, a.H);
+  const int xa = t.in_x0 ? t.x0 : 0, xb = t.in_x1 ? t.x0 + 1 : 0;
+  const int ya = t.in_y0 ? t.y0 : 0, yb = t.in_y1 ? t.y0 + 1 : 0;
+  const int es = NHWC ? a.C : 1;
+  const int off[4] = {(ya * a.W + xa) * es, (ya * a.W + xb) * es, (yb * a.W + xa) * es, (yb * a.W + xb) * es};
+  const float wgt[4] = {(t.in_x0 && t.in_y0) ? t.w_nw : 0.0f, (t.in_x1 && t.in_y0) ? t.w_ne : 0.0f,
+                        (t.in_x0 && t.in_y1) ? t.w_sw : 0.0f, (t.in_x1 && t.in_y1) ? t.w_se : 0.0f};
+  float sum = 0.0f;
+  // under strong magnification most pixels sample outside the image: a wave whose 64 pixels are all dead for this plane
+  // skips its channel loop (wave-uniform branch)
+  if (!__any((wgt[0] + wgt[1] + wgt[2] + wgt[3]) != 0.0f)) return 0.0f;
+  constexpr int kChan = 8;
+  for (int c0 = 0; c0 < a.C; c0 += kChan) {
+    float r[kChan], v[kChan][4];
+    if (NHWC) {
+      float4v q[kChan / 4][4];
+#pragma unroll
+      for (int h = 0; h < kChan / 4; ++h)
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp)
+          q[h][tp] = (c0 + 4 * h < a.C) ? *(const float4v DVMVS_GLOBAL*)(meas + off[tp] + c0 + 4 * h) : float4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int cc = 0; cc < kChan; ++cc)
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) v[cc][tp] = q[cc / 4][tp][cc % 4];
+    } else {
+#pragma unroll
+      for (int cc = 0; cc < kChan; ++cc) {
+        gcfloat_p plane = meas + static_cast<size_t>(min(c0 + cc, a.C - 1)) * HW;
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) v[cc][tp] = plane[off[tp]];
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < kChan; ++cc) r[cc] = (c0 + cc < a.C) ? ref[static_cast<size_t>(min(c0 + cc, a.C - 1)) * HW] : 0.0f;
+#pragma unroll
+    for (int cc = 0; cc < kChan; ++cc) {
+      float w = v[cc][0] * wgt[0];
+      w += v[cc][1] * wgt[1];
+      w += v[cc][2] * wgt[2];
+      w += v[cc][3] * wgt[3];
+      sum += r[cc] * w;
+    }
+  }
+  return sum;
+}
+
+// ---- spill groups ------------------------------------------------------------------------------------------------------
+// Workspace words after the set-up block: [0] = number of registered groups, [1..3] unused, then `groups` group ids, then
+// one slot per workgroup of (1 + M * DP) words: item count, items.  An item packs (m, seg_lo, seg_len); a workgroup
+// queues its items in (measurement frame, plane) order.
+constexpr int kSpillHeaderWords = 4;
+
+__host__ __device__ inline int spill_slot_words(int M, int DP) { return 1 + M * DP; }
+__device__ inline unsigned int spill_pack(int m, int seg_lo, int seg_len) {
+  return (static_cast<unsigned int>(m) << 16) | (static_cast<unsigned int>(seg_lo) << 8) | static_cast<unsigned int>(seg_len);
+}
+
+// ---- the kernel ----------------------------------------------------------------------------------------------------------
+template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, bool XCD_ = true, int DBG_ = 0>
+struct SweepConfig {
+  static constexpr int DBG = DBG_;   // timing experiments only (wrong results): 1 = no staging loads, 2 = no tap compute, 3 = neither
+  static constexpr int TW = TW_, TH = TH_, DP = DP_, CCH = CCH_, CAP = CAP_, MINSEG = MINSEG_;
+  static constexpr int WAVES = WAVES_;   // waves per SIMD the register allocation is held to
+  static constexpr bool XCD = XCD_;      // XCD-aware workgroup numbering
+  static constexpr int NT = TW * TH;
+  static constexpr int REC = CCH + 4;                                  // floats per LDS record
+  static constexpr size_t kLdsBytes = sizeof(float) * static_cast<size_t>(REC) * CAP;
+  static_assert(CCH % 4 == 0 && ((REC / 4) % 2) == 1, "record stride must be an odd number of 16-byte slots");
+  static_assert(NT % 64 == 0 && MINSEG >= 1 && MINSEG <= DP && DP <= 32, "workgroup shape");
+};
+
+// Decodes the linear workgroup number.  XCD-aware: XCD = blockIdx % 8 gets a contiguous range of (batch, tile, chunk) work
+// items, tile-major, so the chunks of a tile and its row neighbours share one L2.  Near chunks first within a tile (their
+// footprints are the large ones).  `group` is the work item's number in (batch, tile, chunk) order.
+struct SweepWork {
+  int b, tile, chunk, group;
+  bool valid;
+};
+
+template <bool XCD>
+__device__ inline SweepWork decode_work(int block, int tiles, int chunks, int B) {
+  SweepWork w;
+  const int per_b = tiles * chunks, total = per_b * B;
+  int v = block;
+  if (XCD) {
+    const int per_xcd = (total + 7) / 8;
+    v = (block & 7) * per_xcd + (block >> 3);
+  }
+  w.valid = v < total;
+  w.group = v;
+  w.b = v / per_b;
+  const int rem = v - w.b * per_b;
+  w.tile = rem / chunks;
+  w.chunk = chunks - 1 - (rem - w.tile * chunks);
+  return w;
+}
+
+// GATHER: the caller gave no spill workspace, so runs of planes that cannot be staged are gathered inline (slow path,
+// compiled into its own instantiation so that the two-pass kernel carries none of its registers).
+template <class Cfg, bool NHWC, bool GATHER>
+__global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_kernel(CostVolumeArgs a) {
+  constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP, CCH = Cfg::CCH, CAP = Cfg::CAP, NT = Cfg::NT, REC = Cfg::REC;
+  constexpr int QPR = CCH / 4;   // 16-byte quads per record
+  extern __shared__ __attribute__((aligned(16))) float s_tile[];   // [CAP][REC]
+  __shared__ float s_H[DVMVS_MAX_MEASUREMENTS * 9];
+  __shared__ float s_kt[DVMVS_MAX_MEASUREMENTS * 3];
+  __shared__ float4v s_ktd[DVMVS_MAX_MEASUREMENTS * DP];
+
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  const int chunks = (a.D + DP - 1) / DP;
+  const SweepWork work = decode_work<Cfg::XCD>(blockIdx.x, tiles_x * tiles_y, chunks, a.B);
+  if (!work.valid) return;
+  const int b = work.b;
+  const int tile_y = work.tile / tiles_x, tile_x = work.tile - tile_y * tiles_x;
+  const int d_block = work.chunk * DP;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int planes = min(DP, a.D - d_block);
+
+  // ---- per-workgroup tables: Hm, kt (from the set-up launch or derived here), K t / depth per plane ----
+  if (a.setup != nullptr) {
+    for (int i = tid; i < a.M * kSetupFloats; i += NT) {
+      const float v = as_global(a.setup)[static_cast<size_t>(b) * a.M * kSetupFloats + i];
+      const int m = i / kSetupFloats, k = i - m * kSetupFloats;
+      if (k < 9) s_H[m * 9 + k] = v;
+      else s_kt[m * 3 + (k - 9)] = v;
+    }
+  } else if (tid < a.M) {
+    sweep_matrices(a.pose1 + b * 16, a.pose2[tid] + b * 16, a.K + b * 9, s_H + tid * 9, s_kt + tid * 3);
+  }
+  __syncthreads();
+  for (int i = tid; i < a.M * DP; i += NT) {
+    const int m = i / DP, j = i - m * DP;
+    float4v k = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (j < planes) {
+      const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j);
+      k.x = s_kt[m * 3 + 0] / depth;
+      k.y = s_kt[m * 3 + 1] / depth;
+      k.z = s_kt[m * 3 + 2] / depth;
+    }
+    s_ktd[i] = k;
+  }
+  __syncthreads();
+
+  const int HW = a.H * a.W;
+  const int x = tile_x * TW + (TW == 32 ? sweep_lane_pixel(tid & 31) : tid % TW), y = tile_y * TH + tid / TW;
+  const bool live = x < a.W && y < a.H;
+  const float xf = static_cast<float>(x), yf = static_cast<float>(y);
+  const int pix = live ? y * a.W + x : 0;
+  gcfloat_p ref = as_global(a.image1) + static_cast<size_t>(b) * a.C * HW + pix;
+  const SweepScale sc = sweep_scale(a.W, a.H);
+  const char* tile_bytes = reinterpret_cast<const char*>(s_tile);
+  const unsigned int plane_bytes = static_cast<unsigned int>(HW) * 4u;
+  const unsigned int map_bytes = static_cast<unsigned int>(a.C) * plane_bytes;
+  const __amdgpu_buffer_rsrc_t ref_rsrc = map_resource(as_global(a.image1) + static_cast<size_t>(b) * a.C * HW, map_bytes);
+  const unsigned int ref_voffset = static_cast<unsigned int>(pix) * 4u;
+
+  guint_p slot = nullptr;   // this workgroup's spill slot
+  if (!GATHER) {
+    const size_t groups = static_cast<size_t>(tiles_x) * tiles_y * chunks * a.B;
+    slot = as_global(a.spill) + kSpillHeaderWords + groups + static_cast<size_t>(work.group) * spill_slot_words(a.M, DP);
+  }
+  int n_spilled = 0;      // workgroup-uniform
+  int violated = 0;       // this thread saw a tap outside its staged box (round-off beyond the slack: not expected)
+
+  // even- and odd-channel partial sums of sum_m sum_c ref[c] * warped_m[c]: one accumulator over all measurement frames
+  // (sum over frames, then / C, then / M; for the usual power-of-two C this is bit-identical to the reference's
+  // per-frame / C followed by the sum, otherwise it is one rounding closer to exact)
+  float2v acc2[DP];
+#pragma unroll
+  for (int j = 0; j < DP; ++j) acc2[j] = float2v{0.0f, 0.0f};
+
+  for (int m = 0; m < a.M; ++m) {
+    const float* Hm = s_H + m * 9;
+    const float4v* ktd_m = s_ktd + m * DP;
+    gcfloat_p meas = as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW;
+    const SweepRay ray = sweep_ray(Hm, xf, yf);
+    int seg_hint = DP;   // planes per segment that fitted last time: parallax per plane is uniform along the sweep
+    int seg_lo = 0;
+    while (seg_lo < planes) {
+      int seg_len = min(planes - seg_lo, seg_hint);
+      SampleBox box;
+      for (;;) {
+        box = wave_sample_box<TW, TH, CAP>(a, Hm, ktd_m, tile_x, tile_y, seg_lo, seg_lo + seg_len - 1, sc, lane);
+        if (box.state != 0 || seg_len <= Cfg::MINSEG) break;
+        seg_len = max((seg_len + 1) / 2, Cfg::MINSEG);
+      }
+      seg_hint = max(seg_len, Cfg::MINSEG);
+      const int seg_hi = seg_lo + seg_len;
+
+      if (box.state == 1) {
+        const int P = box.pitch, RS = box.pitch * box.RH;
+        const int row_bytes = P * REC * 4;
+        // ---- this thread's taps: byte address of the north-west record and the four weights, per plane ----
+        // (weights as register pairs {nw, ne}, {sw, se}: v_pk_fma_f32 broadcasts either half through op_sel)
+        int addr[DP];
+        float2v w_n[DP], w_s[DP];
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+          addr[j] = 0;
+          w_n[j] = w_s[j] = float2v{0.0f, 0.0f};
+          if (j >= seg_lo && j < seg_hi) {   // workgroup-uniform
+            const float4v k = ktd_m[j];
+            float ix, iy;
+            sweep_sample(ray, k.x, k.y, k.z, sc, &ix, &iy);
+            const float fx = floorf(ix), fy = floorf(iy);
+            const float ex = (fx + 1.0f) - ix, wx = ix - fx;   // ATen's order: (ix_se - ix), (ix - ix_nw)
+            const float ey = (fy + 1.0f) - iy, wy = iy - fy;
+            int rx = static_cast<int>(fx) - box.x_lo, ry = static_cast<int>(fy) - box.y_lo;
+            if (live) violated |= (static_cast<unsigned int>(rx) > static_cast<unsigned int>(box.RW - 2)) |
+                                  (static_cast<unsigned int>(ry) > static_cast<unsigned int>(box.RH - 2));
+            rx = min(max(rx, 0), box.RW - 2);
+            ry = min(max(ry, 0), box.RH - 2);
+            addr[j] = (ry * P + rx) * (REC * 4);
+            w_n[j] = float2v{ex * ey, wx * ey};
+            w_s[j] = float2v{ex * wy, wx * wy};
+          }
+        }
+        // ---- staging plan: byte offset into the measurement map of each of this thread's LDS pieces ----
+        // NHWC: a piece is one 16-byte channel quad of one box position; NCHW: a piece is one box position (CCH dword loads).
+        // Positions outside the image (zero apron), pad columns and pieces past the box get kBufferOutOfRange: the load
+        // then returns zeros by itself.
+        constexpr int kPieces = NHWC ? (CAP * QPR + NT - 1) / NT : (CAP + NT - 1) / NT;
+        const unsigned int magic = 0xffffffffu / static_cast<unsigned int>(P) + 1u;   // r / P == mulhi(r, magic) for r < 2^16
+        const int n_pieces = NHWC ? RS * QPR : RS;
+        unsigned int goff[kPieces];
+#pragma unroll
+        for (int k = 0; k < kPieces; ++k) {
+          const int piece = tid + k * NT;
+          const int r = NHWC ? piece / QPR : piece;
+          const int ry = static_cast<int>(__umulhi(static_cast<unsigned int>(r), magic));
+          const int rx = r - ry * P;
+          const int gx = box.x_lo + rx, gy = box.y_lo + ry;
+          const bool in = (piece < n_pieces) && (rx < box.RW) && (gx >= 0) && (gx < a.W) && (gy >= 0) && (gy < a.H);
+          goff[k] = in ? static_cast<unsigned int>(NHWC ? (gy * a.W + gx) * a.C + (piece % QPR) * 4 : gy * a.W + gx) * 4u : kBufferOutOfRange;
+        }
+        const __amdgpu_buffer_rsrc_t meas_rsrc = map_resource(meas, map_bytes);
+
+        for (int c0 = 0; c0 < a.C; c0 += CCH) {
+          // reference features of this pass first: their latency overlaps the copy.  Channels beyond C (last pass of a
+          // ragged channel count) re-read channel C-1 on both sides and are cancelled by rv = 0.
+          float2v rv[CCH / 2];
+#pragma unroll
+          for (int c = 0; c < CCH; ++c) {
+            const float v = buffer_f32(ref_rsrc, ref_voffset, static_cast<unsigned int>(min(c0 + c, a.C - 1)) * plane_bytes);
+            rv[c / 2][c % 2] = (c0 + c < a.C) ? v : 0.0f;
+          }
+          if (NHWC) {
+            const bool ragged = c0 + CCH > a.C;   // workgroup-uniform
+            constexpr int kBatch = 4;             // 16-byte loads in flight per thread before their ds_write_b128s
+#pragma unroll
+            for (int k0 = 0; k0 < kPieces; k0 += kBatch) {
+              if (k0 * NT < n_pieces) {   // workgroup-uniform
+                float4v v[kBatch];
+#pragma unroll
+                for (int kk = 0; kk < kBatch; ++kk) {
+                  const int k = k0 + kk < kPieces ? k0 + kk : kPieces - 1;
+                  const int piece = tid + k * NT;
+                  unsigned int vo = goff[k];
+                  if (ragged && c0 + (piece % QPR) * 4 >= a.C) vo = kBufferOutOfRange;
+                  v[kk] = (Cfg::DBG & 1) ? float4v{0.0f, 0.0f, 0.0f, 0.0f} : buffer_f32x4(meas_rsrc, vo, static_cast<unsigned int>(c0) * 4u);
+                }
+#pragma unroll
+                for (int kk = 0; kk < kBatch; ++kk) {
+                  const int piece = tid + (k0 + kk) * NT;
+                  if (k0 + kk < kPieces && piece < n_pieces)
+                    *reinterpret_cast<float4v*>(s_tile + (piece / QPR) * REC + (piece % QPR) * 4) = v[kk];
+                }
+              }
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < kPieces; ++k) {
+              if (k * NT < n_pieces) {   // workgroup-uniform
+                const int r = tid + k * NT;
+                float4v v[QPR];
+#pragma unroll
+                for (int c = 0; c < CCH; ++c)
+                  v[c / 4][c % 4] = (Cfg::DBG & 1) ? 0.0f : buffer_f32(meas_rsrc, goff[k], static_cast<unsigned int>(min(c0 + c, a.C - 1)) * plane_bytes);
+                if (r < RS) {
+#pragma unroll
+                  for (int q = 0; q < QPR; ++q) *reinterpret_cast<float4v*>(s_tile + r * REC + q * 4) = v[q];
+                }
+              }
+            }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < DP; ++j) {
+            if (j >= seg_lo && j < seg_hi && !(Cfg::DBG & 2)) {   // workgroup-uniform
+              const char* row0 = tile_bytes + addr[j];
+              const char* row1 = row0 + row_bytes;
+              float2v t_nw = {0.0f, 0.0f}, t_ne = {0.0f, 0.0f}, t_sw = {0.0f, 0.0f}, t_se = {0.0f, 0.0f};
+#pragma unroll
+              for (int q = 0; q < QPR; ++q) {
+                const float4v nw = *reinterpret_cast<const float4v*>(row0 + q * 16);
+                const float4v ne = *reinterpret_cast<const float4v*>(row0 + REC * 4 + q * 16);
+                const float4v sw = *reinterpret_cast<const float4v*>(row1 + q * 16);
+                const float4v se = *reinterpret_cast<const float4v*>(row1 + REC * 4 + q * 16);
+                // dot per tap, two channels per v_pk_fma_f32 (rv is 0 for channels beyond C)
+                t_nw = fma2(rv[q * 2], nw.lo, t_nw); t_nw = fma2(rv[q * 2 + 1], nw.hi, t_nw);
+                t_ne = fma2(rv[q * 2], ne.lo, t_ne); t_ne = fma2(rv[q * 2 + 1], ne.hi, t_ne);
+                t_sw = fma2(rv[q * 2], sw.lo, t_sw); t_sw = fma2(rv[q * 2 + 1], sw.hi, t_sw);
+                t_se = fma2(rv[q * 2], se.lo, t_se); t_se = fma2(rv[q * 2 + 1], se.hi, t_se);
+              }
+              float2v f = acc2[j];
+              f = fma2(t_nw, __builtin_shufflevector(w_n[j], w_n[j], 0, 0), f);
+              f = fma2(t_ne, __builtin_shufflevector(w_n[j], w_n[j], 1, 1), f);
+              f = fma2(t_sw, __builtin_shufflevector(w_s[j], w_s[j], 0, 0), f);
+              f = fma2(t_se, __builtin_shufflevector(w_s[j], w_s[j], 1, 1), f);
+              acc2[j] = f;
+            }
+          }
+          __syncthreads();
+        }
+      } else if (box.state == 0 && !GATHER) {
+        // cannot be staged: queue the run for the second pass (this workgroup contributes nothing for it)
+        if (tid == 0) slot[1 + n_spilled] = spill_pack(m, seg_lo, seg_len);
+        ++n_spilled;
+      } else if (box.state == 0) {
+        const float* kt = s_kt + m * 3;
+#pragma unroll
+        for (int j = 0; j < DP; ++j)
+          if (j >= seg_lo && j < seg_hi) {
+            const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j);
+            acc2[j].x += live ? gather_plane<NHWC>(a, meas, ref, HW, ray, kt[0] / depth, kt[1] / depth, kt[2] / depth, sc) : 0.0f;
+          }
+      }
+      // state 2: the whole footprint of the run lies outside the image -> zeros
+      seg_lo = seg_hi;
+    }
+  }
+
+  // A tap outside its staged box can only come from round-off beyond the 0.05 px slack of the corner test.  It has never
+  // been observed, but the result must not depend on it: the whole workgroup is redone through the gather path (second
+  // pass, or inline when there is none).
+  if (__syncthreads_or(violated)) {
+#pragma unroll
+    for (int j = 0; j < DP; ++j) acc2[j] = float2v{0.0f, 0.0f};
+    n_spilled = 0;
+    for (int m = 0; m < a.M; ++m) {
+      if (!GATHER) {
+        if (tid == 0) slot[1 + n_spilled] = spill_pack(m, 0, planes);
+        ++n_spilled;
+      } else {
+        const SweepRay ray = sweep_ray(s_H + m * 9, xf, yf);
+        const float* kt = s_kt + m * 3;
+        gcfloat_p meas = as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW;
+#pragma unroll
+        for (int j = 0; j < DP; ++j)
+          if (j < planes && live) {
+            const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j);
+            acc2[j].x += gather_plane<NHWC>(a, meas, ref, HW, ray, kt[0] / depth, kt[1] / depth, kt[2] / depth, sc);
+          }
+      }
+    }
+  }
+
+  if (live) {
+    gfloat_p out = as_global(a.out) + (static_cast<size_t>(b) * a.D + d_block) * HW + pix;
+#pragma unroll
+    for (int j = 0; j < DP; ++j)
+      if (j < planes) out[static_cast<size_t>(j) * HW] = ((acc2[j].x + acc2[j].y) / static_cast<float>(a.C)) / static_cast<float>(a.M);
+  }
+  if (!GATHER && tid == 0 && n_spilled > 0) {
+    slot[0] = static_cast<unsigned int>(n_spilled);
+    const unsigned int at = atomicAdd(a.spill, 1u);
+    as_global(a.spill)[kSpillHeaderWords + at] = static_cast<unsigned int>(work.group);
+  }
+}
+
+// Second pass.  A unit of work is one plane of one registered spill group: the workgroup's 256 threads are the tile's
+// pixels, and each walks the group's items in the order the first pass queued them (measurement frame order), adding the
+// frames whose queued run contains this plane with plain read-modify-writes.  A (pixel, plane) output has exactly one
+// writer that applies its contributions in a fixed order, so the volume does not depend on scheduling, while the critical
+// path of a unit is at most M single-plane gathers.
+template <class Cfg, bool NHWC>
+__global__ __launch_bounds__(Cfg::NT) void sweep_spill_kernel(CostVolumeArgs a) {
+  constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP;
+  const guint_p spill = as_global(a.spill);
+  const unsigned int units = spill[0] * DP;
+  const int tid = threadIdx.x;
+  const int HW = a.H * a.W;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  const int chunks = (a.D + DP - 1) / DP;
+  const int per_b = tiles_x * tiles_y * chunks;
+  const size_t groups = static_cast<size_t>(per_b) * a.B;
+  const SweepScale sc = sweep_scale(a.W, a.H);
+  for (unsigned int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int j = static_cast<int>(u % DP);
+    const int group = static_cast<int>(spill[kSpillHeaderWords + u / DP]);
+    const guint_p slot = spill + kSpillHeaderWords + groups + static_cast<size_t>(group) * spill_slot_words(a.M, DP);
+    const int b = group / per_b, rem = group - b * per_b;
+    const int tile = rem / chunks, chunk = chunks - 1 - (rem - tile * chunks);
+    const int d = chunk * DP + j;
+    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
+    const int x = tile_x * TW + tid % TW, y = tile_y * TH + tid / TW;
+    if (d >= a.D || x >= a.W || y >= a.H) continue;
+    const float xf = static_cast<float>(x), yf = static_cast<float>(y);
+    const int pix = y * a.W + x;
+    gcfloat_p ref = as_global(a.image1) + static_cast<size_t>(b) * a.C * HW + pix;
+    gfloat_p out = as_global(a.out) + (static_cast<size_t>(b) * a.D + d) * HW + pix;
+    const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d);
+    const int n_items = static_cast<int>(slot[0]);
+    float value = 0.0f;
+    bool touched = false;
+    for (int it = 0; it < n_items; ++it) {
+      const unsigned int w = slot[1 + it];
+      const int m = static_cast<int>(w >> 16), seg_lo = static_cast<int>((w >> 8) & 0xffu), seg_len = static_cast<int>(w & 0xffu);
+      if (j < seg_lo || j >= seg_lo + seg_len) continue;   // workgroup-uniform
+      gcfloat_p setup = as_global(a.setup) + (static_cast<size_t>(b) * a.M + m) * kSetupFloats;   // Hm (9) + kt (3)
+      float Hm[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Hm[k] = setup[k];
+      const SweepRay ray = sweep_ray(Hm, xf, yf);
+      const float part = gather_plane<NHWC>(a, as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW, ref, HW, ray,
+                                            setup[9] / depth, setup[10] / depth, setup[11] / depth, sc);
+      if (!touched) value = *out;
+      touched = true;
+      value += (part / static_cast<float>(a.C)) / static_cast<float>(a.M);   // same scaling order as the first pass
+    }
+    if (touched) *out = value;
+  }
+}
+
+// ---- launch ------------------------------------------------------------------------------------------------------------
+constexpr int kMaxDevices = 64;
+
+template <class Kernel>
+int raise_dynamic_lds_limit(Kernel kernel, size_t bytes, bool* configured) {
+  // the limit is a per-device function attribute; setting it is idempotent, racing threads write the same value
+  int device = 0;
+  DVMVS_RETURN_IF_HIP(hipGetDevice(&device));
+  const bool tracked = device >= 0 && device < kMaxDevices;
+  if (!tracked || !configured[device]) {
+    DVMVS_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            static_cast<int>(bytes)));
+    if (tracked) configured[device] = true;
+  }
+  return 0;
+}
+
+template <class Cfg, bool NHWC>
+int launch_sweep_tiled_layout(const CostVolumeArgs& a, hipStream_t stream) {
+  const long long tiles = static_cast<long long>((a.W + Cfg::TW - 1) / Cfg::TW) * ((a.H + Cfg::TH - 1) / Cfg::TH);
+  const long long total = tiles * ((a.D + Cfg::DP - 1) / Cfg::DP) * a.B;
+  if (total > (1LL << 30)) return DVMVS_EUNSUPPORTED;
+  const unsigned int grid = static_cast<unsigned int>(Cfg::XCD ? (total + 7) / 8 * 8 : total);
+  if (a.spill == nullptr) {
+    static bool configured[kMaxDevices] = {};
+    auto kernel = sweep_tiled_kernel<Cfg, NHWC, true>;
+    const int rc = raise_dynamic_lds_limit(kernel, Cfg::kLdsBytes, configured);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(Cfg::NT), Cfg::kLdsBytes, stream, a);
+    return launch_status();
+  }
+  static bool configured[kMaxDevices] = {};
+  auto kernel = sweep_tiled_kernel<Cfg, NHWC, false>;
+  const int rc = raise_dynamic_lds_limit(kernel, Cfg::kLdsBytes, configured);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(Cfg::NT), Cfg::kLdsBytes, stream, a);
+  const int rc2 = launch_status();
+  if (rc2 != 0) return rc2;
+  hipLaunchKernelGGL((sweep_spill_kernel<Cfg, NHWC>), dim3(2048), dim3(Cfg::NT), 0, stream, a);
+  return launch_status();
+}
+
+template <class Cfg>
+int launch_sweep_tiled(const CostVolumeArgs& a, hipStream_t stream) {
+  return a.image2_nhwc ? launch_sweep_tiled_layout<Cfg, true>(a, stream) : launch_sweep_tiled_layout<Cfg, false>(a, stream);
+}
+
+// the shipped configuration; the spill workspace is sized for it
+using SweepDefault = SweepConfig<32, 8, 8, 8, 1024, 2>;
+
+size_t sweep_spill_words(int B, int M, int H, int W, int D) {
+  using Cfg = SweepDefault;
+  const size_t tiles = static_cast<size_t>((W + Cfg::TW - 1) / Cfg::TW) * ((H + Cfg::TH - 1) / Cfg::TH);
+  const size_t groups = tiles * ((D + Cfg::DP - 1) / Cfg::DP) * B;
+  return kSpillHeaderWords + groups + groups * spill_slot_words(M, Cfg::DP);
+}
+
+int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream) { return launch_sweep_tiled<SweepDefault>(a, stream); }
+
+// tuning configurations for tools/cv_microbench.py (TW, TH, DP, CCH, CAP, MINSEG, WAVES, XCD); the spill workspace layout
+// depends on (TW, TH, DP), so configurations with another tile shape run single-pass (inline gather)
+int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream) {
+  CostVolumeArgs b = a;
+  b.spill = nullptr;
+  switch (which) {
+    case 0: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true>>(a, stream);    // 48 KB: 3 workgroups / CU
+    case 1: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, false>>(a, stream);   // ... plain numbering
+    case 2: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 4, 3, true>>(a, stream);
+    case 3: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 1, 3, true>>(a, stream);
+    case 4: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1280, 2, 2, true>>(a, stream);    // 60 KB: 2 / CU
+    case 5: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 768, 2, 4, true>>(a, stream);     // 36 KB: 4 / CU, <= 128 VGPRs
+    case 6: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 640, 2, 3, true>>(a, stream);     // 30 KB
+    case 7: return launch_sweep_tiled<SweepConfig<32, 8, 8, 16, 640, 2, 3, true>>(a, stream);    // 80-byte records, 50 KB
+    case 8: return launch_sweep_tiled<SweepConfig<32, 8, 8, 16, 640, 2, 2, true>>(a, stream);    // ... 2 waves / SIMD of registers
+    case 9: return launch_sweep_tiled<SweepConfig<32, 8, 8, 16, 1024, 2, 2, true>>(a, stream);   // 80 KB: 2 / CU
+    case 10: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true>>(a, stream);
+    case 11: return launch_sweep_tiled<SweepConfig<16, 16, 8, 8, 1024, 2, 3, true>>(b, stream);
+    case 12: return launch_sweep_tiled<SweepConfig<32, 8, 4, 8, 768, 2, 4, true>>(b, stream);    // 4 planes / workgroup
+    case 13: return launch_sweep_tiled<SweepConfig<32, 8, 16, 8, 1536, 2, 2, true>>(b, stream);  // 16 planes, 72 KB
+    case 14: return launch_sweep_tiled<SweepConfig<32, 4, 8, 8, 640, 2, 4, true>>(b, stream);    // 128 threads, 30 KB
+    case 15: return launch_sweep_tiled<SweepConfig<16, 8, 8, 8, 512, 2, 4, true>>(b, stream);    // 128 threads, 24 KB
+    case 16: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 1>>(a, stream);   // timing skeletons
+    case 17: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 2>>(a, stream);
+    case 18: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 3>>(a, stream);
+    case 19: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true, 0>>(a, stream);
+    case 20: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true, 1>>(a, stream);
+    case 21: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true, 2>>(a, stream);
+    case 22: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true, 3>>(a, stream);
+    default: return DVMVS_EINVAL;
+  }
+}
+
+}  // namespace dvmvs

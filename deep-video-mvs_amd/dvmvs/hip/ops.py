@@ -67,7 +67,7 @@ def cost_volume(image1: Tensor, image2s: Sequence[Tensor], pose1: Tensor, pose2s
     K = K.contiguous()
     out = torch.empty((B, n_depth_levels, H, W), dtype=torch.float32, device=image1.device)
     lib = _capi.lib()
-    ws_bytes = (lib.dvmvs_cost_volume_workspace_bytes_two_pass(B, M, H, W, n_depth_levels) if COST_VOLUME_TWO_PASS and not nhwc
+    ws_bytes = (lib.dvmvs_cost_volume_workspace_bytes_two_pass(B, M, H, W, n_depth_levels) if COST_VOLUME_TWO_PASS
                 else lib.dvmvs_cost_volume_workspace_bytes(B, M))
     workspace = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=image1.device)
     with torch.cuda.device(image1.device):
@@ -112,7 +112,8 @@ def _cost_volume_backward(ctx, grad):
     image2c = [t.contiguous() for t in image2s]
     pose2c = [t.contiguous() for t in pose2s]
     g1 = torch.empty_like(image1c)
-    need2 = ctx.needs_input_grad[1]
+    flags = ctx.needs_input_grad[1]   # a tensor-list input: one flag per measurement map
+    need2 = any(flags) if isinstance(flags, (list, tuple)) else bool(flags)
     g2 = [torch.zeros_like(t) for t in image2c] if need2 else []
     with torch.cuda.device(image1.device):
         rc = _capi.lib().dvmvs_cost_volume_bwd(

@@ -1,11 +1,15 @@
-"""Times the cost-volume kernel variants on the BASELINE.json shape (B=1, C=32, 128x160, D=64) with realistic geometry
-and cross-checks every variant against the generic kernel.  Run on the GPU box:
+"""Times the cost-volume kernel variants on the BASELINE.json shape (B=1, C=32, 128x160, D=64, M=2) on real keyframe
+geometry (lines of the sample scene's nmeas+2 index) and cross-checks every variant against the generic kernel.
+Run on the GPU box:
 
-    python tools/cv_microbench.py [--m 2] [--variants 1,2,16,17,...] [--batch 1]
+    python tools/cv_microbench.py [--lines 0,40,117,202] [--variants 3,2,32,33] [--layouts nchw,nhwc] [--batch 1]
 
-Each variant is captured into a hipGraph of REPS back-to-back launches and timed with HIP events (no host gaps).
+Each (geometry, layout, variant) is captured into a hipGraph of REPS back-to-back launches and timed with HIP events
+(no host gaps).  Variant numbers: include/dvmvs_hip.h (0-3) and the tuning tables in csrc/ (16.. legacy, 32.. sweep).
+Prints one table (us per launch) and writes it as JSON when --out is given.
 """
 import argparse
+import json
 import os
 import sys
 
@@ -19,82 +23,103 @@ import synthetic as syn  # noqa: E402
 from dvmvs.hip import _capi  # noqa: E402
 
 
+def index_lines(nmeas=2):
+    names = {n: i for i, n in enumerate(syn.sample_image_names())}
+    path = os.path.join(ROOT, "tests", "golden", "indices", f"keyframe+hololens-dataset+000+nmeas+{nmeas}")
+    out = []
+    for line in open(path):
+        parts = line.split()
+        if len(parts) == nmeas + 1 and all(p in names for p in parts):
+            out.append([names[p] for p in parts])
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--variants", default="1,2,16,17,18,19,20,21,22,23,24,25")
+    ap.add_argument("--variants", default="3,2")
+    ap.add_argument("--layouts", default="nchw")
+    ap.add_argument("--lines", default="0,40,80,117,170,202,250", help="index lines; -1 = the synthetic sideways trajectory")
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--no-workspace", action="store_true")
-    ap.add_argument("--baseline-step", type=int, default=1, help="measurement frame m is keyframe k-(m+1)*step")
-    ap.add_argument("--keyframe", type=int, default=8, help="position along the synthetic trajectory (changes the epipolar geometry)")
-    ap.add_argument("--two-pass", action="store_true", help="give the sweep the large workspace (spill list, second gather pass)")
-    ap.add_argument("--nhwc", action="store_true", help="measurement maps channels-last (DVMVS_LAYOUT_NHWC)")
-    ap.add_argument("--real-line", type=int, default=-1, help="use the poses of this line of the sample scene's nmeas+2 keyframe index")
+    ap.add_argument("--small-workspace", action="store_true", help="set-up block only: no spill list (single-pass sweep)")
+    ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _capi.lib()
     B, C, H, W, D, M = args.batch, 32, 128, 160, 64, args.m
+    variants = [int(v) for v in args.variants.split(",")]
+    layouts = args.layouts.split(",")
     feats = [torch.cat([syn.smooth_noise((1, C, H, W), seed=300 + 10 * b + i) for b in range(B)]).to(dev) for i in range(M + 1)]
-    k = args.keyframe
-    traj = torch.from_numpy(syn.synthetic_trajectory(k + 2, seed=1000)).float()
-    pose1 = traj[k:k + 1].repeat(B, 1, 1).to(dev)
-    pose2s = [traj[k - (i + 1) * args.baseline_step:k - (i + 1) * args.baseline_step + 1].repeat(B, 1, 1).to(dev) for i in range(M)]
-    if args.real_line >= 0:
-        names = {n: i for i, n in enumerate(syn.sample_image_names())}
-        lines = [l.split() for l in open(os.path.join(ROOT, "tests", "golden", "indices", "keyframe+hololens-dataset+000+nmeas+2"))]
-        ids = [names[x] for x in [l for l in lines if len(l) == 3][args.real_line]]
-        allp = torch.from_numpy(syn.sample_poses()).float()
-        pose1 = allp[ids[0]:ids[0] + 1].repeat(B, 1, 1).to(dev)
-        pose2s = [allp[i:i + 1].repeat(B, 1, 1).to(dev) for i in (ids[1:] * M)[:M]]
+    feats_cl = [t.contiguous(memory_format=torch.channels_last) for t in feats[1:]]
     K = syn.scaled_K(syn.full_K(), 2.0).repeat(B, 1, 1).to(dev)
+    allp = torch.from_numpy(syn.sample_poses()).float()
+    lines = index_lines(2)
+    ws_bytes = lib.dvmvs_cost_volume_workspace_bytes(B, M) if args.small_workspace else lib.dvmvs_cost_volume_workspace_bytes_two_pass(B, M, H, W, D)
+    ws = torch.empty((ws_bytes + 3) // 4, device=dev)
     out = torch.empty(B, D, H, W, device=dev)
     ref_out = torch.empty_like(out)
-    ws_bytes = lib.dvmvs_cost_volume_workspace_bytes_two_pass(B, M, H, W, D) if args.two_pass else lib.dvmvs_cost_volume_workspace_bytes(B, M)
-    ws = torch.empty((ws_bytes + 3) // 4, device=dev)
-    layout = 1 if args.nhwc else 0
-    meas = [t.contiguous(memory_format=torch.channels_last) if args.nhwc else t for t in feats[1:]]
-    img_ptrs = _capi.pointer_array([t.data_ptr() for t in meas])
-    pose_ptrs = _capi.pointer_array([t.data_ptr() for t in pose2s])
-
-    def launch(variant, dst):
-        rc = lib.dvmvs_cost_volume_fwd(feats[0].data_ptr(), img_ptrs, pose1.data_ptr(), pose_ptrs, K.data_ptr(), dst.data_ptr(),
-                                       B, M, C, H, W, D, 0.25, 20.0, 1, variant, layout, None if args.no_workspace else ws.data_ptr(),
-                                       0 if args.no_workspace else ws_bytes, torch.cuda.current_stream().cuda_stream)
-        _capi.check(rc, f"variant {variant}")
-
-    layout_saved, layout = layout, 0
-    img_ptrs_saved, img_ptrs = img_ptrs, _capi.pointer_array([t.data_ptr() for t in feats[1:]])
-    launch(1, ref_out)      # generic kernel on NCHW maps = the cross-check
-    torch.cuda.synchronize()
-    layout, img_ptrs = layout_saved, img_ptrs_saved
     alg_bytes = (1 + M) * B * C * H * W * 4 + B * D * H * W * 4
-    print(f"shape B={B} C={C} {H}x{W} D={D} M={M}; algorithmic bytes {alg_bytes}; |cv| mean {ref_out.abs().mean().item():.4f}")
-    for variant in [int(v) for v in args.variants.split(",")]:
-        out.zero_()
-        try:
-            launch(variant, out)
-        except RuntimeError as e:
-            print(f"variant {variant:3d}: {e}")
-            continue
+    print(f"shape B={B} C={C} {H}x{W} D={D} M={M}; algorithmic bytes {alg_bytes}")
+    results = {}
+    for li in [int(v) for v in args.lines.split(",")]:
+        if li < 0:
+            traj = torch.from_numpy(syn.synthetic_trajectory(10, seed=1000)).float()
+            ids, pose_src = [8, 7, 6], traj
+        else:
+            ids, pose_src = lines[li], allp
+        pose1 = pose_src[ids[0]:ids[0] + 1].repeat(B, 1, 1).to(dev)
+        pose2s = [pose_src[i:i + 1].repeat(B, 1, 1).to(dev) for i in (ids[1:] * M)[:M]]
+        pose_ptrs = _capi.pointer_array([t.data_ptr() for t in pose2s])
+
+        def launch(variant, dst, layout):
+            meas = feats_cl if layout == "nhwc" else feats[1:]
+            img_ptrs = _capi.pointer_array([t.data_ptr() for t in meas])
+            rc = lib.dvmvs_cost_volume_fwd(feats[0].data_ptr(), img_ptrs, pose1.data_ptr(), pose_ptrs, K.data_ptr(), dst.data_ptr(),
+                                           B, M, C, H, W, D, 0.25, 20.0, 1, variant, 1 if layout == "nhwc" else 0,
+                                           ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
+            _capi.check(rc, f"variant {variant}")
+
+        launch(1, ref_out, "nchw")      # generic kernel on NCHW maps = the cross-check
         torch.cuda.synchronize()
-        err = (out - ref_out).abs().max().item()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(args.reps):
-                launch(variant, out)
-        g.replay()
-        torch.cuda.synchronize()
-        best = 1e9
-        for _ in range(5):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            g.replay()
-            e.record()
-            torch.cuda.synchronize()
-            best = min(best, s.elapsed_time(e) * 1e3 / args.reps)
-        print(f"variant {variant:3d}: {best:8.2f} us/launch  {alg_bytes / best / 1e3:8.1f} GB/s  ({100 * alg_bytes / best / 1e3 / 8000:5.2f} % of 8 TB/s)  "
-              f"max|diff vs generic| {err:.2e}")
+        for layout in layouts:
+            for variant in variants:
+                out.fill_(float("nan"))
+                try:
+                    launch(variant, out, layout)
+                except RuntimeError as e:
+                    print(f"line {li:3d} {layout} variant {variant:3d}: {e}")
+                    continue
+                torch.cuda.synchronize()
+                err = (out - ref_out).abs().max().item()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(args.reps):
+                        launch(variant, out, layout)
+                g.replay()
+                torch.cuda.synchronize()
+                best = 1e9
+                for _ in range(5):
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
+                    g.replay()
+                    e.record()
+                    torch.cuda.synchronize()
+                    best = min(best, s.elapsed_time(e) * 1e3 / args.reps)
+                results[(li, layout, variant)] = (best, err)
+                print(f"line {li:3d} {layout} variant {variant:3d}: {best:8.2f} us  {100 * alg_bytes / best / 1e3 / 8000:5.2f} % of 8 TB/s  "
+                      f"max|diff vs generic| {err:.2e}", flush=True)
+    print("\nmean over geometries (us):")
+    for layout in layouts:
+        for variant in variants:
+            ts = [v[0] for (li, lo, va), v in results.items() if lo == layout and va == variant]
+            es = [v[1] for (li, lo, va), v in results.items() if lo == layout and va == variant]
+            if ts:
+                print(f"  {layout} variant {variant:3d}: mean {sum(ts) / len(ts):8.2f}  min {min(ts):8.2f}  max {max(ts):8.2f}   worst diff {max(es):.2e}")
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, "w") as f:
+            json.dump({f"{li}/{lo}/{va}": {"us": v[0], "max_diff_vs_generic": v[1]} for (li, lo, va), v in results.items()}, f, indent=1)
 
 
 if __name__ == "__main__":
