@@ -103,9 +103,7 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
     lib = _capi.lib()
     from dvmvs import utils
     from dvmvs.hip import ops as _ops
-    ws_bytes = (lib.dvmvs_cost_volume_workspace_bytes_two_pass(B, n_meas, H, W, D) if _ops.COST_VOLUME_TWO_PASS
-                else lib.dvmvs_cost_volume_workspace_bytes(B, n_meas))
-    workspace = torch.empty((ws_bytes + 3) // 4, device=ref.device)
+    workspace, ws_bytes = _ops.sweep_workspace(ref.device, B, n_meas, H, W, D)
 
     def launch():
         rc = lib.dvmvs_cost_volume_fwd(ref.data_ptr(), img_ptrs, s["pose"].data_ptr(), pose_ptrs, s["half_K"].data_ptr(), out.data_ptr(),

@@ -16,11 +16,8 @@ struct CostVolumeArgs {
   int B, M, C, H, W, D;
   double inv_depth_base, inv_depth_step;
   int image2_nhwc;     // measurement maps are channels-last ([B,H,W,C]); reference map and output stay NCHW
-  unsigned int* spill;   // optional spill list: [0] = item count, [4..] = items (2 words each); nullptr = spill inline
-  const float* setup;  // optional [B][M][12]: Hm (9) + kt (3) written by sweep_setup_kernel; nullptr = derive per workgroup
+  unsigned int* spill;   // optional spill workspace of the two-pass tiled sweep (layout: sweep_tiled.hip); nullptr = gather inline
 };
-
-constexpr int kSetupFloats = 12;
 
 // Per-(batch, measurement) sweep constants, evaluated once per workgroup into LDS.
 //   Hm = K R K^-1 (row-major 3x3), kt = K t   with [R|t] = inverse(pose2) * pose1     (utils.py:51-56)
@@ -52,16 +49,7 @@ __device__ inline float plane_depth(double inv_base, double inv_step, int d) {
 // Fills s_H[M][9], s_kt[M][3] and s_ktd[M][planes][3] (= kt / depth_d for d in [d_begin, d_begin+planes)).
 __device__ inline void sweep_setup(const CostVolumeArgs& a, int b, int d_begin, int planes, int tid, int nthreads,
                                    float* s_H, float* s_kt, float* s_ktd) {
-  if (a.setup != nullptr) {
-    for (int i = tid; i < a.M * kSetupFloats; i += nthreads) {
-      const float v = a.setup[static_cast<size_t>(b) * a.M * kSetupFloats + i];
-      const int m = i / kSetupFloats, k = i - m * kSetupFloats;
-      if (k < 9) s_H[m * 9 + k] = v;
-      else s_kt[m * 3 + (k - 9)] = v;
-    }
-  } else if (tid < a.M) {
-    sweep_matrices(a.pose1 + b * 16, a.pose2[tid] + b * 16, a.K + b * 9, s_H + tid * 9, s_kt + tid * 3);
-  }
+  if (tid < a.M) sweep_matrices(a.pose1 + b * 16, a.pose2[tid] + b * 16, a.K + b * 9, s_H + tid * 9, s_kt + tid * 3);
   __syncthreads();
   for (int i = tid; i < a.M * planes * 3; i += nthreads) {
     const int k = i % 3;
@@ -112,7 +100,6 @@ inline int fill_sweep_args(CostVolumeArgs* a, const float* image1, const float* 
   // utils.py:59-60, python doubles
   a->inv_depth_base = 1.0 / max_depth;
   a->inv_depth_step = D > 1 ? (1.0 / min_depth - 1.0 / max_depth) / (D - 1) : 0.0;
-  a->setup = nullptr;
   a->spill = nullptr;
   a->image2_nhwc = 0;
   return 0;

@@ -234,21 +234,51 @@ __device__ inline float gather_plane(const CostVolumeArgs& a, gcfloat_p meas, gc
   return sum;
 }
 
+// ---- tap accumulation of one plane in one staged channel pass ------------------------------------------------------------
+// 4 taps x QPR 16-byte reads; "dot per tap" over the pass's channels, two channels per v_pk_fma_f32; then the four bilinear
+// weights (register pairs {nw, ne}, {sw, se}, either half broadcast through op_sel).  (Deeper software pipelining across
+// planes was measured: no gain -- the launch is bound by the workgroup's chain of staging round trips, not by LDS latency.)
+template <int QPR, int REC>
+__device__ inline void tap_plane(const char* tile_bytes, int row_bytes, int addr, float2v w_n, float2v w_s, const float2v* rv, float2v* acc) {
+  const char* row0 = tile_bytes + addr;
+  const char* row1 = row0 + row_bytes;
+  float2v t_nw = {0.0f, 0.0f}, t_ne = {0.0f, 0.0f}, t_sw = {0.0f, 0.0f}, t_se = {0.0f, 0.0f};
+#pragma unroll
+  for (int q = 0; q < QPR; ++q) {
+    const float4v nw = *reinterpret_cast<const float4v*>(row0 + q * 16);
+    const float4v ne = *reinterpret_cast<const float4v*>(row0 + REC * 4 + q * 16);
+    const float4v sw = *reinterpret_cast<const float4v*>(row1 + q * 16);
+    const float4v se = *reinterpret_cast<const float4v*>(row1 + REC * 4 + q * 16);
+    t_nw = fma2(rv[q * 2], nw.lo, t_nw); t_nw = fma2(rv[q * 2 + 1], nw.hi, t_nw);
+    t_ne = fma2(rv[q * 2], ne.lo, t_ne); t_ne = fma2(rv[q * 2 + 1], ne.hi, t_ne);
+    t_sw = fma2(rv[q * 2], sw.lo, t_sw); t_sw = fma2(rv[q * 2 + 1], sw.hi, t_sw);
+    t_se = fma2(rv[q * 2], se.lo, t_se); t_se = fma2(rv[q * 2 + 1], se.hi, t_se);
+  }
+  float2v f = *acc;
+  f = fma2(t_nw, __builtin_shufflevector(w_n, w_n, 0, 0), f);
+  f = fma2(t_ne, __builtin_shufflevector(w_n, w_n, 1, 1), f);
+  f = fma2(t_sw, __builtin_shufflevector(w_s, w_s, 0, 0), f);
+  f = fma2(t_se, __builtin_shufflevector(w_s, w_s, 1, 1), f);
+  *acc = f;
+}
+
 // ---- spill groups ------------------------------------------------------------------------------------------------------
-// Workspace words after the set-up block: [0] = number of registered groups, [1..3] unused, then `groups` group ids, then
-// one slot per workgroup of (1 + M * DP) words: item count, items.  An item packs (m, seg_lo, seg_len); a workgroup
-// queues its items in (measurement frame, plane) order.
+// Spill workspace words: [0] = number of registered groups, [1] = finished workgroups of the second pass, [2..3] unused,
+// then `groups` group ids, then one slot per workgroup of (1 + M * DP + 12 M) words: item count, items, and the workgroup's
+// sweep constants Hm (9) + K t (3) per frame, so that the second pass does not repeat the fp64 pose algebra.  An item packs
+// (m, seg_lo, seg_len); a workgroup queues its items in (measurement frame, plane) order.
+// The header must be zero when a call starts; the second pass restores that (its last workgroup to finish clears words 0 and
+// 1), so the caller zero-fills a workspace once, when it allocates it, and never again.
 constexpr int kSpillHeaderWords = 4;
 
-__host__ __device__ inline int spill_slot_words(int M, int DP) { return 1 + M * DP; }
+__host__ __device__ inline int spill_slot_words(int M, int DP) { return 1 + M * DP + 12 * M; }
 __device__ inline unsigned int spill_pack(int m, int seg_lo, int seg_len) {
   return (static_cast<unsigned int>(m) << 16) | (static_cast<unsigned int>(seg_lo) << 8) | static_cast<unsigned int>(seg_len);
 }
 
 // ---- the kernel ----------------------------------------------------------------------------------------------------------
-template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, bool XCD_ = true, int DBG_ = 0>
+template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, bool XCD_ = true>
 struct SweepConfig {
-  static constexpr int DBG = DBG_;   // timing experiments only (wrong results): 1 = no staging loads, 2 = no tap compute, 3 = neither
   static constexpr int TW = TW_, TH = TH_, DP = DP_, CCH = CCH_, CAP = CAP_, MINSEG = MINSEG_;
   static constexpr int WAVES = WAVES_;   // waves per SIMD the register allocation is held to
   static constexpr bool XCD = XCD_;      // XCD-aware workgroup numbering
@@ -306,17 +336,8 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   const int tid = threadIdx.x, lane = tid & 63;
   const int planes = min(DP, a.D - d_block);
 
-  // ---- per-workgroup tables: Hm, kt (from the set-up launch or derived here), K t / depth per plane ----
-  if (a.setup != nullptr) {
-    for (int i = tid; i < a.M * kSetupFloats; i += NT) {
-      const float v = as_global(a.setup)[static_cast<size_t>(b) * a.M * kSetupFloats + i];
-      const int m = i / kSetupFloats, k = i - m * kSetupFloats;
-      if (k < 9) s_H[m * 9 + k] = v;
-      else s_kt[m * 3 + (k - 9)] = v;
-    }
-  } else if (tid < a.M) {
-    sweep_matrices(a.pose1 + b * 16, a.pose2[tid] + b * 16, a.K + b * 9, s_H + tid * 9, s_kt + tid * 3);
-  }
+  // ---- per-workgroup tables: Hm = K R K^-1 and K t per measurement frame (fp64 on the first M lanes), K t / depth per plane ----
+  if (tid < a.M) sweep_matrices(a.pose1 + b * 16, a.pose2[tid] + b * 16, a.K + b * 9, s_H + tid * 9, s_kt + tid * 3);
   __syncthreads();
   for (int i = tid; i < a.M * DP; i += NT) {
     const int m = i / DP, j = i - m * DP;
@@ -332,7 +353,10 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   __syncthreads();
 
   const int HW = a.H * a.W;
-  const int x = tile_x * TW + (TW == 32 ? sweep_lane_pixel(tid & 31) : tid % TW), y = tile_y * TH + tid / TW;
+  // lane -> pixel: each 16-lane ds_read_b128 service group owns 16 consecutive pixels of one tile row (see sweep_lane_pixel)
+  const int lane_pixel = sweep_lane_pixel(tid & 31);
+  const int x = tile_x * TW + (TW == 32 ? lane_pixel : TW == 16 ? (lane_pixel & 15) : tid % TW);
+  const int y = tile_y * TH + (TW == 32 ? tid / 32 : TW == 16 ? (tid >> 5) * 2 + (lane_pixel >> 4) : tid / TW);
   const bool live = x < a.W && y < a.H;
   const float xf = static_cast<float>(x), yf = static_cast<float>(y);
   const int pix = live ? y * a.W + x : 0;
@@ -380,8 +404,8 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
       if (box.state == 1) {
         const int P = box.pitch, RS = box.pitch * box.RH;
         const int row_bytes = P * REC * 4;
-        // ---- this thread's taps: byte address of the north-west record and the four weights, per plane ----
-        // (weights as register pairs {nw, ne}, {sw, se}: v_pk_fma_f32 broadcasts either half through op_sel)
+        // ---- this thread's taps: byte address of the north-west record and the four weights (register pairs {nw, ne},
+        // {sw, se}: v_pk_fma_f32 broadcasts either half through op_sel), per plane of the run ----
         int addr[DP];
         float2v w_n[DP], w_s[DP];
 #pragma unroll
@@ -389,9 +413,9 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
           addr[j] = 0;
           w_n[j] = w_s[j] = float2v{0.0f, 0.0f};
           if (j >= seg_lo && j < seg_hi) {   // workgroup-uniform
-            const float4v k = ktd_m[j];
+            const float4v kd = ktd_m[j];
             float ix, iy;
-            sweep_sample(ray, k.x, k.y, k.z, sc, &ix, &iy);
+            sweep_sample(ray, kd.x, kd.y, kd.z, sc, &ix, &iy);
             const float fx = floorf(ix), fy = floorf(iy);
             const float ex = (fx + 1.0f) - ix, wx = ix - fx;   // ATen's order: (ix_se - ix), (ix - ix_nw)
             const float ey = (fy + 1.0f) - iy, wy = iy - fy;
@@ -400,7 +424,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
                                   (static_cast<unsigned int>(ry) > static_cast<unsigned int>(box.RH - 2));
             rx = min(max(rx, 0), box.RW - 2);
             ry = min(max(ry, 0), box.RH - 2);
-            addr[j] = (ry * P + rx) * (REC * 4);
+            addr[j] = __mul24(__mul24(ry, P) + rx, REC * 4);   // full-rate 24-bit multiplies: ry, P, rx < 2^11
             w_n[j] = float2v{ex * ey, wx * ey};
             w_s[j] = float2v{ex * wy, wx * wy};
           }
@@ -447,7 +471,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
                   const int piece = tid + k * NT;
                   unsigned int vo = goff[k];
                   if (ragged && c0 + (piece % QPR) * 4 >= a.C) vo = kBufferOutOfRange;
-                  v[kk] = (Cfg::DBG & 1) ? float4v{0.0f, 0.0f, 0.0f, 0.0f} : buffer_f32x4(meas_rsrc, vo, static_cast<unsigned int>(c0) * 4u);
+                  v[kk] = buffer_f32x4(meas_rsrc, vo, static_cast<unsigned int>(c0) * 4u);
                 }
 #pragma unroll
                 for (int kk = 0; kk < kBatch; ++kk) {
@@ -465,7 +489,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
                 float4v v[QPR];
 #pragma unroll
                 for (int c = 0; c < CCH; ++c)
-                  v[c / 4][c % 4] = (Cfg::DBG & 1) ? 0.0f : buffer_f32(meas_rsrc, goff[k], static_cast<unsigned int>(min(c0 + c, a.C - 1)) * plane_bytes);
+                  v[c / 4][c % 4] = buffer_f32(meas_rsrc, goff[k], static_cast<unsigned int>(min(c0 + c, a.C - 1)) * plane_bytes);
                 if (r < RS) {
 #pragma unroll
                   for (int q = 0; q < QPR; ++q) *reinterpret_cast<float4v*>(s_tile + r * REC + q * 4) = v[q];
@@ -475,31 +499,9 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
           }
           __syncthreads();
 #pragma unroll
-          for (int j = 0; j < DP; ++j) {
-            if (j >= seg_lo && j < seg_hi && !(Cfg::DBG & 2)) {   // workgroup-uniform
-              const char* row0 = tile_bytes + addr[j];
-              const char* row1 = row0 + row_bytes;
-              float2v t_nw = {0.0f, 0.0f}, t_ne = {0.0f, 0.0f}, t_sw = {0.0f, 0.0f}, t_se = {0.0f, 0.0f};
-#pragma unroll
-              for (int q = 0; q < QPR; ++q) {
-                const float4v nw = *reinterpret_cast<const float4v*>(row0 + q * 16);
-                const float4v ne = *reinterpret_cast<const float4v*>(row0 + REC * 4 + q * 16);
-                const float4v sw = *reinterpret_cast<const float4v*>(row1 + q * 16);
-                const float4v se = *reinterpret_cast<const float4v*>(row1 + REC * 4 + q * 16);
-                // dot per tap, two channels per v_pk_fma_f32 (rv is 0 for channels beyond C)
-                t_nw = fma2(rv[q * 2], nw.lo, t_nw); t_nw = fma2(rv[q * 2 + 1], nw.hi, t_nw);
-                t_ne = fma2(rv[q * 2], ne.lo, t_ne); t_ne = fma2(rv[q * 2 + 1], ne.hi, t_ne);
-                t_sw = fma2(rv[q * 2], sw.lo, t_sw); t_sw = fma2(rv[q * 2 + 1], sw.hi, t_sw);
-                t_se = fma2(rv[q * 2], se.lo, t_se); t_se = fma2(rv[q * 2 + 1], se.hi, t_se);
-              }
-              float2v f = acc2[j];
-              f = fma2(t_nw, __builtin_shufflevector(w_n[j], w_n[j], 0, 0), f);
-              f = fma2(t_ne, __builtin_shufflevector(w_n[j], w_n[j], 1, 1), f);
-              f = fma2(t_sw, __builtin_shufflevector(w_s[j], w_s[j], 0, 0), f);
-              f = fma2(t_se, __builtin_shufflevector(w_s[j], w_s[j], 1, 1), f);
-              acc2[j] = f;
-            }
-          }
+          for (int j = 0; j < DP; ++j)
+            if (j >= seg_lo && j < seg_hi)   // workgroup-uniform
+              tap_plane<QPR, REC>(tile_bytes, row_bytes, addr[j], w_n[j], w_s[j], rv, &acc2[j]);
           __syncthreads();
         }
       } else if (box.state == 0 && !GATHER) {
@@ -551,10 +553,17 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
     for (int j = 0; j < DP; ++j)
       if (j < planes) out[static_cast<size_t>(j) * HW] = ((acc2[j].x + acc2[j].y) / static_cast<float>(a.C)) / static_cast<float>(a.M);
   }
-  if (!GATHER && tid == 0 && n_spilled > 0) {
-    slot[0] = static_cast<unsigned int>(n_spilled);
-    const unsigned int at = atomicAdd(a.spill, 1u);
-    as_global(a.spill)[kSpillHeaderWords + at] = static_cast<unsigned int>(work.group);
+  if (!GATHER && n_spilled > 0) {
+    if (tid < a.M * 12) {
+      const int m = tid / 12, k = tid - m * 12;
+      slot[1 + a.M * DP + tid] = __float_as_uint(k < 9 ? s_H[m * 9 + k] : s_kt[m * 3 + (k - 9)]);
+    }
+    __syncthreads();   // the constants are written before the group becomes visible to the second pass (a later launch anyway)
+    if (tid == 0) {
+      slot[0] = static_cast<unsigned int>(n_spilled);
+      const unsigned int at = atomicAdd(a.spill, 1u);
+      as_global(a.spill)[kSpillHeaderWords + at] = static_cast<unsigned int>(work.group);
+    }
   }
 }
 
@@ -584,12 +593,12 @@ __global__ __launch_bounds__(Cfg::NT) void sweep_spill_kernel(CostVolumeArgs a) 
     const int d = chunk * DP + j;
     const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
     const int x = tile_x * TW + tid % TW, y = tile_y * TH + tid / TW;
-    if (d >= a.D || x >= a.W || y >= a.H) continue;
+    const bool live = d < a.D && x < a.W && y < a.H;
     const float xf = static_cast<float>(x), yf = static_cast<float>(y);
-    const int pix = y * a.W + x;
+    const int pix = live ? y * a.W + x : 0;
     gcfloat_p ref = as_global(a.image1) + static_cast<size_t>(b) * a.C * HW + pix;
-    gfloat_p out = as_global(a.out) + (static_cast<size_t>(b) * a.D + d) * HW + pix;
-    const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d);
+    gfloat_p out = as_global(a.out) + (static_cast<size_t>(b) * a.D + min(d, a.D - 1)) * HW + pix;
+    const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, min(d, a.D - 1));
     const int n_items = static_cast<int>(slot[0]);
     float value = 0.0f;
     bool touched = false;
@@ -597,23 +606,36 @@ __global__ __launch_bounds__(Cfg::NT) void sweep_spill_kernel(CostVolumeArgs a) 
       const unsigned int w = slot[1 + it];
       const int m = static_cast<int>(w >> 16), seg_lo = static_cast<int>((w >> 8) & 0xffu), seg_len = static_cast<int>(w & 0xffu);
       if (j < seg_lo || j >= seg_lo + seg_len) continue;   // workgroup-uniform
-      gcfloat_p setup = as_global(a.setup) + (static_cast<size_t>(b) * a.M + m) * kSetupFloats;   // Hm (9) + kt (3)
+      if (!live) continue;
+      const guint_p setup = slot + 1 + a.M * DP + m * 12;   // Hm (9) + K t (3), as the first pass used them
       float Hm[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Hm[k] = setup[k];
+      for (int k = 0; k < 9; ++k) Hm[k] = __uint_as_float(setup[k]);
       const SweepRay ray = sweep_ray(Hm, xf, yf);
       const float part = gather_plane<NHWC>(a, as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW, ref, HW, ray,
-                                            setup[9] / depth, setup[10] / depth, setup[11] / depth, sc);
+                                            __uint_as_float(setup[9]) / depth, __uint_as_float(setup[10]) / depth,
+                                            __uint_as_float(setup[11]) / depth, sc);
       if (!touched) value = *out;
       touched = true;
       value += (part / static_cast<float>(a.C)) / static_cast<float>(a.M);   // same scaling order as the first pass
     }
     if (touched) *out = value;
   }
+  // leave the header as the next call expects it (nothing to do for an empty list): every workgroup has read word 0 by
+  // the time it takes a ticket, and the last one to finish clears both words
+  __syncthreads();
+  if (tid == 0 && units != 0) {
+    const unsigned int ticket = atomicAdd(a.spill + 1, 1u);
+    if (ticket == gridDim.x - 1) {
+      spill[0] = 0u;
+      spill[1] = 0u;
+    }
+  }
 }
 
 // ---- launch ------------------------------------------------------------------------------------------------------------
 constexpr int kMaxDevices = 64;
+constexpr int kSpillGrid = 256;   // second-pass workgroups (grid-stride over the queued units; an empty pass should cost little)
 
 template <class Kernel>
 int raise_dynamic_lds_limit(Kernel kernel, size_t bytes, bool* configured) {
@@ -650,7 +672,7 @@ int launch_sweep_tiled_layout(const CostVolumeArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(Cfg::NT), Cfg::kLdsBytes, stream, a);
   const int rc2 = launch_status();
   if (rc2 != 0) return rc2;
-  hipLaunchKernelGGL((sweep_spill_kernel<Cfg, NHWC>), dim3(2048), dim3(Cfg::NT), 0, stream, a);
+  hipLaunchKernelGGL((sweep_spill_kernel<Cfg, NHWC>), dim3(kSpillGrid), dim3(Cfg::NT), 0, stream, a);
   return launch_status();
 }
 
@@ -662,44 +684,43 @@ int launch_sweep_tiled(const CostVolumeArgs& a, hipStream_t stream) {
 // the shipped configuration; the spill workspace is sized for it
 using SweepDefault = SweepConfig<32, 8, 8, 8, 1024, 2>;
 
-size_t sweep_spill_words(int B, int M, int H, int W, int D) {
-  using Cfg = SweepDefault;
+template <class Cfg>
+size_t spill_words_for(int B, int M, int H, int W, int D) {
   const size_t tiles = static_cast<size_t>((W + Cfg::TW - 1) / Cfg::TW) * ((H + Cfg::TH - 1) / Cfg::TH);
   const size_t groups = tiles * ((D + Cfg::DP - 1) / Cfg::DP) * B;
   return kSpillHeaderWords + groups + groups * spill_slot_words(M, Cfg::DP);
 }
 
+// sized for the finest tiling among the configurations that may use it (each launch indexes it with its own tiling)
+size_t sweep_spill_words(int B, int M, int H, int W, int D) {
+  const size_t a = spill_words_for<SweepDefault>(B, M, H, W, D), b = spill_words_for<SweepConfig<16, 4, 8, 8, 320, 2>>(B, M, H, W, D);
+  return a > b ? a : b;
+}
+
 int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream) { return launch_sweep_tiled<SweepDefault>(a, stream); }
 
-// tuning configurations for tools/cv_microbench.py (TW, TH, DP, CCH, CAP, MINSEG, WAVES, XCD); the spill workspace layout
-// depends on (TW, TH, DP), so configurations with another tile shape run single-pass (inline gather)
+// tuning configurations for tools/cv_microbench.py (TW, TH, DP, CCH, CAP, MINSEG, WAVES, XCD); the spill workspace is sized
+// for the 32x8 and 16x4 tilings, other tile shapes run single-pass (inline gather)
 int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream) {
   CostVolumeArgs b = a;
   b.spill = nullptr;
   switch (which) {
     case 0: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true>>(a, stream);    // 48 KB: 3 workgroups / CU
-    case 1: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, false>>(a, stream);   // ... plain numbering
-    case 2: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 4, 3, true>>(a, stream);
+    case 1: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, false>>(a, stream);   // ... plain workgroup numbering
+    case 2: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 4, 3, true>>(a, stream);    // runs of >= 4 planes, else spill
     case 3: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 1, 3, true>>(a, stream);
     case 4: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1280, 2, 2, true>>(a, stream);    // 60 KB: 2 / CU
     case 5: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 768, 2, 4, true>>(a, stream);     // 36 KB: 4 / CU, <= 128 VGPRs
     case 6: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 640, 2, 3, true>>(a, stream);     // 30 KB
     case 7: return launch_sweep_tiled<SweepConfig<32, 8, 8, 16, 640, 2, 3, true>>(a, stream);    // 80-byte records, 50 KB
-    case 8: return launch_sweep_tiled<SweepConfig<32, 8, 8, 16, 640, 2, 2, true>>(a, stream);    // ... 2 waves / SIMD of registers
-    case 9: return launch_sweep_tiled<SweepConfig<32, 8, 8, 16, 1024, 2, 2, true>>(a, stream);   // 80 KB: 2 / CU
-    case 10: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true>>(a, stream);
-    case 11: return launch_sweep_tiled<SweepConfig<16, 16, 8, 8, 1024, 2, 3, true>>(b, stream);
-    case 12: return launch_sweep_tiled<SweepConfig<32, 8, 4, 8, 768, 2, 4, true>>(b, stream);    // 4 planes / workgroup
-    case 13: return launch_sweep_tiled<SweepConfig<32, 8, 16, 8, 1536, 2, 2, true>>(b, stream);  // 16 planes, 72 KB
-    case 14: return launch_sweep_tiled<SweepConfig<32, 4, 8, 8, 640, 2, 4, true>>(b, stream);    // 128 threads, 30 KB
-    case 15: return launch_sweep_tiled<SweepConfig<16, 8, 8, 8, 512, 2, 4, true>>(b, stream);    // 128 threads, 24 KB
-    case 16: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 1>>(a, stream);   // timing skeletons
-    case 17: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 2>>(a, stream);
-    case 18: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 3>>(a, stream);
-    case 19: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true, 0>>(a, stream);
-    case 20: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true, 1>>(a, stream);
-    case 21: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true, 2>>(a, stream);
-    case 22: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true, 3>>(a, stream);
+    case 8: return launch_sweep_tiled<SweepConfig<32, 8, 8, 16, 1024, 2, 2, true>>(a, stream);   // 80 KB: 2 / CU
+    case 9: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true>>(a, stream);    // 2 waves / SIMD of registers
+    case 10: return launch_sweep_tiled<SweepConfig<16, 16, 8, 8, 1024, 2, 3, true>>(b, stream);
+    case 11: return launch_sweep_tiled<SweepConfig<32, 8, 4, 8, 768, 2, 4, true>>(b, stream);    // 4 planes / workgroup
+    case 12: return launch_sweep_tiled<SweepConfig<32, 8, 16, 8, 1536, 2, 2, true>>(b, stream);  // 16 planes, 72 KB
+    // one wave per workgroup: no barriers, every wave stages its own 16x4-pixel footprint and free-runs
+    case 13: return launch_sweep_tiled<SweepConfig<16, 4, 8, 8, 320, 2, 3, true>>(a, stream);    // 15 KB: 10 / CU
+    case 14: return launch_sweep_tiled<SweepConfig<16, 4, 8, 8, 384, 2, 2, true>>(a, stream);    // 18 KB: 8 / CU
     default: return DVMVS_EINVAL;
   }
 }

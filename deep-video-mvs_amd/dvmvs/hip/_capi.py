@@ -16,7 +16,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVMVS_HIP_LIB", os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libdvmvs_hip.so")))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_MEASUREMENTS = 8
 MAX_DEPTH_LEVELS = 256
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
@@ -32,8 +32,7 @@ SIGNATURES = {
     "dvmvs_abi_version": (_c_int, []),
     "dvmvs_build_arch": (ctypes.c_char_p, []),
     "dvmvs_error_string": (ctypes.c_char_p, [_c_int]),
-    "dvmvs_cost_volume_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
-    "dvmvs_cost_volume_workspace_bytes_two_pass": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "dvmvs_cost_volume_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "dvmvs_cost_volume_fwd": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fpp, _c_fp, _c_fp,
                                        _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                        _c_dbl, _c_dbl, _c_int, _c_int, _c_int, _c_fp, ctypes.c_size_t, _c_stream]),

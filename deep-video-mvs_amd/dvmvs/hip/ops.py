@@ -21,6 +21,28 @@ __all__ = ["cost_volume", "hidden_warp", "relative_pose", "lstm_gates", "depth_r
 COST_VOLUME_TWO_PASS = os.environ.get("DVMVS_COST_VOLUME_TWO_PASS", "1") == "1"
 
 
+_workspaces = {}
+
+
+def sweep_workspace(device, B, M, H, W, D):
+    """Persistent spill workspace of the two-pass sweep for (device, shape): zero-filled once here and left zeroed by every
+    call (contract in include/dvmvs_hip.h).  Returns (tensor, bytes).
+
+    One buffer per device and shape: calls that use it must be ordered with respect to each other, which is the case for
+    the one-process-per-GPU, one-stream-per-process model of this package (a hipGraph replay runs on the stream that
+    launches it).  Code that issues cost volumes of the same shape on several streams concurrently must pass its own
+    workspaces through the C ABI.  Allocated outside any graph capture when the first (eager / warm-up) call happens."""
+    device = torch.device(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, B, M, H, W, D)
+    entry = _workspaces.get(key)
+    if entry is None:
+        nbytes = _capi.lib().dvmvs_cost_volume_workspace_bytes(B, M, H, W, D)
+        entry = (torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device), nbytes)
+        _workspaces[key] = entry
+    return entry
+
+
 def _no_cpu(op):
     raise RuntimeError(f"dvmvs::{op} only runs as a HIP kernel on an MI355X; move the tensors to the GPU. "
                        f"There is deliberately no CPU fallback (the CPU oracle under oracle/ is for tests).")
@@ -67,15 +89,13 @@ def cost_volume(image1: Tensor, image2s: Sequence[Tensor], pose1: Tensor, pose2s
     K = K.contiguous()
     out = torch.empty((B, n_depth_levels, H, W), dtype=torch.float32, device=image1.device)
     lib = _capi.lib()
-    ws_bytes = (lib.dvmvs_cost_volume_workspace_bytes_two_pass(B, M, H, W, n_depth_levels) if COST_VOLUME_TWO_PASS
-                else lib.dvmvs_cost_volume_workspace_bytes(B, M))
-    workspace = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=image1.device)
+    workspace, ws_bytes = sweep_workspace(image1.device, B, M, H, W, n_depth_levels) if COST_VOLUME_TWO_PASS else (None, 0)
     with torch.cuda.device(image1.device):
         rc = lib.dvmvs_cost_volume_fwd(
             _ptr(image1), _capi.pointer_array([_ptr(t) for t in image2s]), _ptr(pose1),
             _capi.pointer_array([_ptr(t) for t in pose2s]), _ptr(K), _ptr(out),
             B, M, C, H, W, n_depth_levels, float(min_depth), float(max_depth), int(bool(dot_product)), int(variant),
-            _capi.LAYOUT_NHWC if nhwc else _capi.LAYOUT_NCHW, _ptr(workspace), ws_bytes, _stream(image1))
+            _capi.LAYOUT_NHWC if nhwc else _capi.LAYOUT_NCHW, _ptr(workspace) if workspace is not None else None, ws_bytes, _stream(image1))
     _capi.check(rc, "dvmvs_cost_volume_fwd")
     return out
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DVMVS_ABI_VERSION 1
+#define DVMVS_ABI_VERSION 2
 #define DVMVS_MAX_MEASUREMENTS 8      /* measurement frames fused per launch */
 #define DVMVS_MAX_DEPTH_LEVELS 256    /* sweep planes per launch */
 
@@ -54,22 +54,24 @@ const char* dvmvs_error_string(int code);
  *   cost_volume [B,D,H,W]   out; plane 0 = max_depth ... plane D-1 = min_depth, uniform in inverse depth
  *   dot_product 1: sum_c(f1*warp(f2))/C   0: sum_c|f1-warp(f2)|  (utils.py:81-84); result is the mean over M
  *   variant     0 = pick the fastest kernel for the shape; 1 = force the generic reference-order kernel (taps through
- *               the vector L1); 2 = force the LDS-tiled kernel (dot_product only)
+ *               the vector L1); 2 = force the LDS-tiled sweep (dot_product only); 32.. = tuning configurations of the
+ *               sweep for tools/cv_microbench.py, not part of the stable interface
  *   image2_layout DVMVS_LAYOUT_NCHW, or DVMVS_LAYOUT_NHWC when the MEASUREMENT maps are stored channels-last (a keyframe's
  *               features are reused as measurement features by later frames, so a runner converts them once per
- *               keyframe): a bilinear tap is then one 128-byte line for all 32 channels, which is what keeps the kernel
- *               fast on wide-baseline / forward-motion pairs whose sample footprint does not fit in LDS.  Supported by the
- *               LDS-tiled dot-product kernel (C % 4 == 0, H*W >= 4096); image1 and cost_volume are always NCHW.
- *   workspace   optional device scratch of dvmvs_cost_volume_workspace_bytes(B, M) bytes.  When given, the 3x3
- *               homography K R K^-1 and K t of utils.py:51-56 are evaluated once by a one-workgroup set-up launch and
- *               read by the sweep kernel; when NULL every workgroup of the sweep kernel derives them itself (one
- *               launch, slightly longer).  Either way they are computed on the device from the poses (fp64).
+ *               keyframe).  Supported by the LDS-tiled dot-product kernel (C % 4 == 0, H*W >= 4096); image1 and
+ *               cost_volume are always NCHW.
+ *   workspace   optional device scratch of dvmvs_cost_volume_workspace_bytes(B, M, H, W, D) bytes for the two-pass form of
+ *               the LDS-tiled sweep: runs of planes whose sample footprint does not fit in LDS (magnified or behind-camera
+ *               views) are queued there by the sweep launch and finished by a second, finely grained gather launch that
+ *               is spread over the whole chip, in a fixed order (the volume is bit-reproducible run to run).
+ *               CONTRACT: the first 16 bytes must be zero when a call starts.  Every call leaves them zero again, so the
+ *               owner zero-fills the buffer once, when it allocates it; a buffer must not be shared by calls that may
+ *               overlap in time (different streams).  With workspace == NULL (or too small) such runs are gathered inline
+ *               by the sweep kernel itself (one launch, long tail on wide-baseline / forward-motion pairs).
+ *   All pose algebra (inverse(pose2) * pose1, K R K^-1, K t: utils.py:51-56) is evaluated on the device, in fp64, by the
+ *   kernels themselves: no host round trip and no set-up launch.
  */
-size_t dvmvs_cost_volume_workspace_bytes(int B, int M);
-/* Larger workspace that also holds a spill list: given at least this many bytes, the LDS-tiled sweep runs in two passes --
- * tiles whose sample footprint does not fit in LDS are queued by the first launch and processed by a second, finely
- * grained gather launch spread over the whole chip (no long tail on wide-baseline / forward-motion pairs). */
-size_t dvmvs_cost_volume_workspace_bytes_two_pass(int B, int M, int H, int W, int D);
+size_t dvmvs_cost_volume_workspace_bytes(int B, int M, int H, int W, int D);
 int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, const float* pose1,
                           const float* const* pose2s, const float* K, float* cost_volume,
                           int B, int M, int C, int H, int W, int D,

@@ -55,15 +55,17 @@ def test_argument_validation_without_gpu(library):
     assert lib.dvmvs_hidden_warp_fwd(null, null, null, null, null, 1, 512, 8, 10, 1, null) == -1
     arr = library.pointer_array([None])
     assert lib.dvmvs_cost_volume_fwd(null, arr, null, arr, null, null, 1, 1, 32, 128, 160, 64, 0.25, 20.0, 1, 0, 0, null, 0, null) == -1
-    assert lib.dvmvs_cost_volume_workspace_bytes(2, 3) == 2 * 3 * 12 * 4
+    assert lib.dvmvs_cost_volume_workspace_bytes(0, 3, 128, 160, 64) == 0
 
 
 def test_workspace_sizes(library):
     lib = library.lib()
-    assert lib.dvmvs_cost_volume_workspace_bytes(1, 2) == 96
-    # set-up block (96 B) + 4 header words + 2 words for each of 1 * (5 * 16 tiles) * 8 plane chunks * 2 frames * 8 segments
-    assert lib.dvmvs_cost_volume_workspace_bytes_two_pass(1, 2, 128, 160, 64) == 96 + 4 * (4 + 2 * 80 * 8 * 2 * 8)
-    assert lib.dvmvs_cost_volume_workspace_bytes_two_pass(0, 2, 128, 160, 64) == 0
+    # spill workspace of the two-pass sweep: 4 header words + per workgroup one id and one slot of (1 + 8 M + 12 M) words,
+    # sized for the finest tiling that may use it (16x4-pixel tiles x 8-plane chunks)
+    groups = (160 // 16) * (128 // 4) * 8
+    assert lib.dvmvs_cost_volume_workspace_bytes(1, 2, 128, 160, 64) == 4 * (4 + groups + groups * (1 + 2 * 8 + 2 * 12))
+    assert lib.dvmvs_cost_volume_workspace_bytes(0, 2, 128, 160, 64) == 0
+    assert lib.dvmvs_cost_volume_workspace_bytes(2, 3, 33, 47, 10) > 0
 
 
 def test_code_object_is_gfx950(library):

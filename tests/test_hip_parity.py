@@ -206,6 +206,36 @@ def test_cost_volume_channels_last_measurement_maps(ops, dev):
         as_accurate_as_reference(nhwc[:1], exp, exp64, floor=1e-5)
 
 
+def test_cost_volume_two_pass_is_bit_reproducible(ops, dev):
+    """SURVEY section 5 / VERDICT r1: the two-pass sweep queues runs of planes it cannot stage (here: forward motion and a
+    behind-camera pair, three measurement frames so that several frames spill the same pixel and plane) and finishes them in
+    a second launch.  That launch applies a (pixel, plane)'s contributions in frame order from a single writer, so repeated
+    runs must agree BIT FOR BIT, and must agree with the single-pass form (inline gather) to fp32 round-off."""
+    halfK = syn.scaled_K(syn.full_K(), 2.0)
+    f = [syn.smooth_noise((2, 32, 128, 160), seed=170 + i) for i in range(4)]
+    for (r, ms) in ((202, (196, 188, 180)), (141, (135, 130, 120)), (170, (168, 167, 160))):
+        p1 = torch.cat([syn.pose(r), syn.pose(r)]).to(dev)
+        p2s = [torch.cat([syn.pose(m), syn.pose(max(m - 2, 0))]).to(dev) for m in ms]
+        K = torch.cat([halfK, halfK]).to(dev)
+        f1 = f[0].to(dev)
+        for layout in ("nchw", "nhwc"):
+            f2s = [t.to(dev) for t in f[1:]]
+            if layout == "nhwc":
+                f2s = [t.contiguous(memory_format=torch.channels_last) for t in f2s]
+            runs = [ops.cost_volume(f1, f2s, p1, p2s, K, 0.25, 20.0, 64, True, 2).clone() for _ in range(4)]
+            for other in runs[1:]:
+                assert torch.equal(runs[0], other), (r, layout)
+            saved = ops.COST_VOLUME_TWO_PASS
+            ops.COST_VOLUME_TWO_PASS = False
+            try:
+                single = ops.cost_volume(f1, f2s, p1, p2s, K, 0.25, 20.0, 64, True, 2)
+            finally:
+                ops.COST_VOLUME_TWO_PASS = saved
+            assert maxerr(single, runs[0]) < 1e-6, (r, layout)
+            generic = ops.cost_volume(f1, [t.contiguous() for t in f2s], p1, p2s, K, 0.25, 20.0, 64, True, 1)
+            assert maxerr(generic, runs[0]) < 3e-5, (r, layout)   # different (reference-order) arithmetic, same volume
+
+
 def test_cost_volume_limits(ops, dev):
     """Maximum measurement-frame and plane counts the ABI accepts (8 and 256), one step beyond, and degenerate arguments."""
     g = torch.Generator().manual_seed(31)

@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--layouts", default="nchw")
     ap.add_argument("--lines", default="0,40,80,117,170,202,250", help="index lines; -1 = the synthetic sideways trajectory")
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--small-workspace", action="store_true", help="set-up block only: no spill list (single-pass sweep)")
+    ap.add_argument("--small-workspace", action="store_true", help="no spill workspace (single-pass sweep, inline gather)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -55,8 +55,8 @@ def main():
     K = syn.scaled_K(syn.full_K(), 2.0).repeat(B, 1, 1).to(dev)
     allp = torch.from_numpy(syn.sample_poses()).float()
     lines = index_lines(2)
-    ws_bytes = lib.dvmvs_cost_volume_workspace_bytes(B, M) if args.small_workspace else lib.dvmvs_cost_volume_workspace_bytes_two_pass(B, M, H, W, D)
-    ws = torch.empty((ws_bytes + 3) // 4, device=dev)
+    ws_bytes = 0 if args.small_workspace else lib.dvmvs_cost_volume_workspace_bytes(B, M, H, W, D)
+    ws = torch.zeros(max(1, (ws_bytes + 3) // 4), device=dev)   # header zero-filled once (contract in include/dvmvs_hip.h)
     out = torch.empty(B, D, H, W, device=dev)
     ref_out = torch.empty_like(out)
     alg_bytes = (1 + M) * B * C * H * W * 4 + B * D * H * W * 4
@@ -77,7 +77,7 @@ def main():
             img_ptrs = _capi.pointer_array([t.data_ptr() for t in meas])
             rc = lib.dvmvs_cost_volume_fwd(feats[0].data_ptr(), img_ptrs, pose1.data_ptr(), pose_ptrs, K.data_ptr(), dst.data_ptr(),
                                            B, M, C, H, W, D, 0.25, 20.0, 1, variant, 1 if layout == "nhwc" else 0,
-                                           ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
+                                           ws.data_ptr() if ws_bytes else None, ws_bytes, torch.cuda.current_stream().cuda_stream)
             _capi.check(rc, f"variant {variant}")
 
         launch(1, ref_out, "nchw")      # generic kernel on NCHW maps = the cross-check
