@@ -29,6 +29,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (same guide)
+ROOFLINE_GEOMETRIES = 25       # keyframe geometries the sweep kernel is timed on, spread over the WHOLE index file
 
 
 def parse():
@@ -53,6 +55,7 @@ def parse():
     ap.add_argument("--mark-region", action="store_true",
                     help="bracket the timed loop with a cumsum kernel so tools/summarize_trace.py can cut it out of a rocprofv3 trace")
     ap.add_argument("--no-roofline-leg", action="store_true", help="skip the dedicated cost-volume timing (profiling runs)")
+    ap.add_argument("--no-rel-l1", action="store_true", help="skip the golden-frame parity check that fills the rel_l1 field")
     return ap.parse_args()
 
 
@@ -83,13 +86,53 @@ def synthetic_sequence(seq_id, n_images, n_frames, n_meas):
     return images, frames, syn.full_K()
 
 
-def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
-    """Average duration of one fused cost-volume launch over the geometries of the timed region.
+def index_pose_sets(n_meas, count):
+    """(reference pose, [measurement poses]) of ``count`` lines spread evenly over the sample scene's whole nmeas+2 keyframe
+    index (286 lines: easy sideways pairs, rotations, forward motion, wide baselines), independent of --steps."""
+    import synthetic as syn
+    all_poses = torch.from_numpy(syn.sample_poses()).float()
+    names = {n: i for i, n in enumerate(syn.sample_image_names())}
+    lines = [l.split() for l in open(os.path.join(ROOT, "tests", "golden", "indices", "keyframe+hololens-dataset+000+nmeas+2"))]
+    lines = [[names[x] for x in l] for l in lines if len(l) == 3]
+    picks = sorted({(i * (len(lines) - 1)) // max(count - 1, 1) for i in range(count)})
+    sets = []
+    for j in picks:
+        ref, *meas = lines[j]
+        meas = (meas * n_meas)[:n_meas]
+        sets.append((all_poses[ref:ref + 1], [all_poses[i:i + 1] for i in meas]))
+    return picks, sets
 
-    ``pose_sets``: (reference pose, [measurement poses]) of keyframes sampled evenly from the timed loop -- the kernel's
-    duration depends on the epipolar geometry (how large the LDS-staged footprint of a tile is), so one geometry is not
-    representative.  For each, a hipGraph of ``reps`` back-to-back launches (no host gaps) is timed with HIP events on the
-    stream it is replayed on.  Returns (mean seconds per launch, algorithmic bytes per launch, [per-geometry seconds])."""
+
+def golden_rel_l1(modules, device, args):
+    """Depth rel-L1 of the frame engine (the configuration being benchmarked, minus graph replay) against the REFERENCE
+    forward on the three golden frames (tests/golden/fusionnet_e2e.npz: captured by running the reference itself, see
+    tests/golden/make_goldens.py).  mean(|d - d_ref| / d_ref) on the stored 4x-subsampled depth maps."""
+    import synthetic as syn
+    from dvmvs.engine import DepthEngine
+    z = np.load(os.path.join(ROOT, "tests", "golden", "fusionnet_e2e.npz"))
+    engine = DepthEngine(*modules, device=device, fold_bn=not args.no_fold_bn, cache_features=not args.no_feature_cache,
+                         use_graphs=False, channels_last=args.channels_last, lstm_channels_last=not args.no_lstm_channels_last)
+    fullK = syn.full_K().to(device)
+    out = []
+    with torch.no_grad():
+        for n, (r, ms) in enumerate(syn.E2E_FRAMES):
+            depth = engine.step(syn.e2e_image(r).to(device), syn.pose(r).to(device), [syn.e2e_image(i).to(device) for i in ms],
+                                [syn.pose(i).to(device) for i in ms], fullK, frame_id=r, measurement_ids=list(ms))
+            d = depth[0, ::4, ::4].cpu().numpy().astype(np.float64)
+            ref = z[f"f{n}_depth_sub4"].astype(np.float64)
+            out.append({"frame": n, "engine_vs_reference": float(np.mean(np.abs(d - ref) / ref)),
+                        "engine_vs_float64": float(np.mean(np.abs(d - z[f"f{n}_depth64_sub4"]) / z[f"f{n}_depth64_sub4"])),
+                        "reference_vs_float64": float(np.mean(np.abs(ref - z[f"f{n}_depth64_sub4"]) / z[f"f{n}_depth64_sub4"]))})
+    return out
+
+
+def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
+    """Average duration of one fused cost-volume op (the sweep launch + its spill launch) over keyframe geometries.
+
+    ``pose_sets``: (reference pose, [measurement poses]) of index lines -- the duration depends on the epipolar geometry
+    (how large the LDS-staged footprint of a tile is, how many runs of planes spill), so one geometry is not
+    representative.  For each, a hipGraph of ``reps`` back-to-back ops (no host gaps) is timed with HIP events on the
+    stream it is replayed on.  Returns (mean seconds per op, algorithmic bytes per op, [per-geometry seconds])."""
     from dvmvs.hip import _capi
     s = engine._static
     ref = s["ref_half"]
@@ -333,22 +376,30 @@ def main():
 
     result = None
     if rank == 0:
+        picks = []
         if args.no_roofline_leg:
             kernel_s, alg_bytes, per_geometry = float("nan"), (1 + M) * 32 * 128 * 160 * 4 + 64 * 128 * 160 * 4, []
         else:
-            first = M + args.warmup
-            n_geo = min(25, args.steps)
-            sample = [first + (i * max(args.steps - 1, 1)) // max(n_geo - 1, 1) for i in range(n_geo)]
-            pose_sets = [seq[j] for j in sample]
+            picks, pose_sets = index_pose_sets(M, ROOFLINE_GEOMETRIES)
+            pose_sets = [(r.to(device), [p.to(device) for p in ms]) for r, ms in pose_sets]
             kernel_s, alg_bytes, per_geometry = measure_cost_volume_kernel(engine, M, args.kernel_reps, pose_sets)
         achieved = alg_bytes / kernel_s / 1e9
-        traffic = None
-        try:   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, see profiles/)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_cost_volume_pmc.json")))
-            if pmc.get("shape") == [1, M, 32, 128, 160, 64]:
-                traffic = pmc["hbm_bytes_per_launch"]
+        # HBM bytes per op from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: only when the committed measurement was taken on
+        # exactly the kernel sources that are being benchmarked, otherwise null (profiles/README.md says how to re-collect)
+        traffic, traffic_source = None, None
+        try:
+            import hashlib
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_cost_volume_pmc.json")))
+            digest = hashlib.sha256(b"".join(open(os.path.join(ROOT, "deep-video-mvs_amd", "csrc", f), "rb").read()
+                                             for f in ("sweep_tiled.hip", "cost_volume.hip", "plane_sweep.h"))).hexdigest()
+            if pmc.get("shape") == [1, M, 32, 128, 160, 64] and pmc.get("kernel_sources_sha256") == digest:
+                traffic, traffic_source = pmc["hbm_bytes_per_launch"], "profiles/r02_cost_volume_pmc.json"
         except (OSError, ValueError, KeyError):
             pass
+        # useful arithmetic of the op: per (pixel, plane, frame) 4 taps x C channels of FMA + 4 weight FMAs, 2 flop each
+        useful_flop = 128 * 160 * 64 * M * (4 * 32 + 4) * 2
+        valu_tflops = useful_flop / kernel_s / 1e12
+        rel = golden_rel_l1(modules, device, args) if not args.no_rel_l1 else None
         result = {
             "metric": "depth frames/sec/GPU @ 320x256x64 planes (fusionnet); rel-L1 vs ref",
             "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -357,12 +408,25 @@ def main():
             "config": {"workload": "fusionnet inference, one synthetic-image sequence per GPU on the sample scene's keyframe poses, "
                                    f"320x256, 64 planes, M={M} measurement frames, batch 1 (BASELINE.json configs[2]; configs[3] at N>1)",
                        "sequences_per_gpu": 1, "hip_graphs": not args.no_graphs, "bn_folded": not args.no_fold_bn,
-                       "feature_cache": not args.no_feature_cache, "weights": "seeded (tests/synthetic.py) + published FPN checkpoint",
+                       "feature_cache": not args.no_feature_cache, "full_resolution_only": True,
+                       "weights": "seeded (tests/synthetic.py) + published FPN checkpoint",
                        "parallelism": f"sequence-sharded x{world}, no data-path collective"},
-            "roofline": {"kernel": "cost_volume (fused warp + correlation, all planes, all measurement frames)", "bound": "hbm",
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel_us": kernel_s * 1e6, "algorithmic_bytes": alg_bytes,
-                         "kernel_us_per_geometry": [round(t * 1e6, 2) for t in per_geometry]},
+            "roofline": {"kernel": "sweep_tiled_kernel + sweep_spill_kernel (fused warp + correlation, all planes, all measurement frames)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel_us": kernel_s * 1e6, "algorithmic_bytes": alg_bytes,
+                         "geometries": f"{len(per_geometry)} lines spread over the whole nmeas+2 keyframe index of the sample scene",
+                         "index_lines": picks, "kernel_us_per_geometry": [round(t * 1e6, 2) for t in per_geometry]},
+            # HBM is not what binds this op (13 MB of algorithmic traffic against 0.69 GFLOP of tap arithmetic and 1.3 GB of LDS
+            # reads): the same duration against the fp32 vector peak, counting only the useful tap FMAs
+            "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": valu_tflops / FP32_VALU_PEAK_TFLOPS, "useful_flop": useful_flop},
+            "rel_l1": None if rel is None else {
+                "what": "depth rel-L1 mean(|d - d_ref| / d_ref) of this engine configuration vs the REFERENCE forward on the 3 golden frames "
+                        "(tests/golden/fusionnet_e2e.npz); target 1e-4; the kernels alone (CPU convolutions held fixed) are pinned by "
+                        "tests/test_hybrid_parity.py",
+                "engine_vs_reference": [r["engine_vs_reference"] for r in rel],
+                "engine_vs_float64": [r["engine_vs_float64"] for r in rel],
+                "reference_vs_float64": [r["reference_vs_float64"] for r in rel]},
         }
         if world == 1 and not args.no_cpu_baseline:
             cpu_mods = build_modules()

@@ -15,10 +15,10 @@
 //   * the box is found by every wave on its own (8 lanes evaluate the corners, three xor-shuffles reduce, readfirstlane
 //     makes it scalar): no LDS round trip and no barrier per segment attempt, and the segment length adapts per tile
 //     (DP planes, halved down to MINSEG while the box does not fit in CAP records);
-//   * per sample the set-up is one v_rcp_f32 (+ one Newton step) instead of two IEEE divisions, the
-//     normalise/un-normalise pair of grid_sample folded into one multiply, clamping instead of per-tap bounds tests
-//     (the apron supplies the zeros), and the tap accumulation is "dot per tap" (4 FMAs per channel, 4 more per sample)
-//     instead of "interpolate, then multiply" (5 per channel);
+//   * per sample the position keeps the reference's fp32 rounding exactly (see SweepScale) but without the range-scaling
+//     half of IEEE division, clamping replaces per-tap bounds tests (the apron supplies the zeros), and the tap
+//     accumulation is "dot per tap" in packed FMAs (2 v_pk_fma_f32 per channel quad and tap, 4 more per sample) instead of
+//     "interpolate, then multiply" (5 scalar FMAs per channel);
 //   * workgroups are numbered so that the 8 plane chunks of a tile AND neighbouring tiles land on the same XCD
 //     (blockIdx % 8 selects the XCD): a measurement footprint is then fetched into one L2 instead of up to eight;
 //   * segments that cannot be staged even at MINSEG planes (magnified / behind-camera footprints) are queued per
@@ -61,32 +61,67 @@ __device__ inline SweepRay sweep_ray(const float* Hm, float xf, float yf) {
   return r;
 }
 
+// Sample positions are computed with the REFERENCE's fp32 arithmetic, rounding for rounding: u = X / (Z + 1e-8),
+// g = (u - W/2) / (W/2) (utils.py:70-73), pixel = ((g + 1) / 2) * (W - 1) (ATen's align_corners un-normalisation).  The
+// position is where fp32 round-off enters the volume (1e-5 px times the feature gradient), and the network downstream
+// amplifies it: with "mathematically equal, differently rounded" positions the hybrid pipeline of
+// tests/test_hybrid_parity.py sits 9e-5 (depth rel-L1) from the oracle, with identical positions ~1e-6.  Divisions are
+// IEEE-exact for finite normal operands without v_div_scale / v_div_fixup: a refined reciprocal, then two residual
+// corrections (the sequence the compiler emits for '/', minus its range scaling -- sample coordinates never need it).
 struct SweepScale {
-  float cW, cH;   // (W-1)/W, (H-1)/H: ((u - W/2)/(W/2) + 1)/2 * (W-1) == u * (W-1)/W
+  float wn, hn;       // W / 2, H / 2
+  float r_wn, r_hn;   // their refined reciprocals
+  float Wm1, Hm1;     // W - 1, H - 1
   float Wf, Hf;
 };
+
+#pragma clang fp contract(off)
+__device__ inline float refined_rcp(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+
+__device__ inline float exact_div(float n, float d, float rcp_d) {   // n / d, correctly rounded (finite, normal range)
+  float q = n * rcp_d;
+  q = fmaf(fmaf(-d, q, n), rcp_d, q);
+  return fmaf(fmaf(-d, q, n), rcp_d, q);
+}
 
 __device__ inline SweepScale sweep_scale(int W, int H) {
   SweepScale s;
   s.Wf = static_cast<float>(W);
   s.Hf = static_cast<float>(H);
-  s.cW = static_cast<float>(W - 1) / s.Wf;
-  s.cH = static_cast<float>(H - 1) / s.Hf;
+  s.wn = s.Wf * 0.5f;
+  s.hn = s.Hf * 0.5f;
+  s.r_wn = refined_rcp(s.wn);
+  s.r_hn = refined_rcp(s.hn);
+  s.Wm1 = static_cast<float>(W - 1);
+  s.Hm1 = static_cast<float>(H - 1);
   return s;
 }
+
+// un-clamped sample position (NaN / Inf when Z + 1e-8 == 0, as in the reference)
+__device__ inline void sweep_position_exact(const SweepRay& r, float kx, float ky, float kz, const SweepScale& s, float* ix, float* iy,
+                                            float* denom_out = nullptr) {
+  const float X = r.X0 + kx, Y = r.Y0 + ky, Z = r.Z0 + kz;
+  const float denom = Z + 1e-8f;
+  const float rcp = refined_rcp(denom);
+  if (denom_out) *denom_out = denom;
+  const float u = exact_div(X, denom, rcp), v = exact_div(Y, denom, rcp);
+  const float gx = exact_div(u - s.wn, s.wn, s.r_wn), gy = exact_div(v - s.hn, s.hn, s.r_hn);
+  *ix = ((gx + 1.0f) * 0.5f) * s.Wm1;
+  *iy = ((gy + 1.0f) * 0.5f) * s.Hm1;
+}
+#pragma clang fp contract(fast)
 
 // Sample position in measurement-image pixels, clamped to [-1, W] x [-1, H]: everything at or beyond those bounds has
 // all four taps outside the image (zeros padding), and v_max/v_min return the non-NaN operand, so NaN (Z + 1e-8 == 0)
 // lands on -1 as well, where both taps are zero -- ATen's "non-finite coordinates fail the bounds test".
-__device__ inline void sweep_sample(const SweepRay& r, float kx, float ky, float kz, const SweepScale& s, float* ix, float* iy,
-                                    float* denom_out = nullptr) {
-  const float X = r.X0 + kx, Y = r.Y0 + ky, Z = r.Z0 + kz;
-  const float denom = Z + 1e-8f;
-  float rcp = __builtin_amdgcn_rcpf(denom);
-  rcp = fmaf(fmaf(-denom, rcp, 1.0f), rcp, rcp);   // one Newton step: <= 1 ulp, NaN/Inf propagate
-  if (denom_out) *denom_out = denom;
-  *ix = fminf(fmaxf((X * rcp) * s.cW, -1.0f), s.Wf);
-  *iy = fminf(fmaxf((Y * rcp) * s.cH, -1.0f), s.Hf);
+__device__ inline void sweep_sample(const SweepRay& r, float kx, float ky, float kz, const SweepScale& s, float* ix, float* iy) {
+  float px, py;
+  sweep_position_exact(r, kx, ky, kz, s, &px, &py);
+  *ix = fminf(fmaxf(px, -1.0f), s.Wf);
+  *iy = fminf(fmaxf(py, -1.0f), s.Hf);
 }
 
 // ---- wave-uniform sample box -------------------------------------------------------------------------------------------
@@ -134,9 +169,8 @@ __device__ inline SampleBox wave_sample_box(const CostVolumeArgs& a, const float
   const float4v k = ktd_m[(lane & 4) ? j_hi : j_lo];
   const SweepRay ray = sweep_ray(Hm, static_cast<float>(cx), static_cast<float>(cy));
   // un-clamped position (the box test has to see how far outside the image the corner is)
-  const float denom = (ray.Z0 + k.z) + 1e-8f;
-  const float ux = ((ray.X0 + k.x) / denom) * sc.cW;
-  const float uy = ((ray.Y0 + k.y) / denom) * sc.cH;
+  float ux, uy, denom;
+  sweep_position_exact(ray, k.x, k.y, k.z, sc, &ux, &uy, &denom);
   // direction of a one-pixel step along the tile's top edge (lanes 0 and 1 hold its two ends on plane j_lo)
   const float edge = static_cast<float>(max(1, min(tile_x * TW + TW - 1, a.W - 1) - tile_x * TW));
   const float step_x = (__shfl(ux, 1) - __shfl(ux, 0)) / edge, step_y = (__shfl(uy, 1) - __shfl(uy, 0)) / edge;

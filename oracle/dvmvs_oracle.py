@@ -96,15 +96,44 @@ def plane_depths(min_depth: float, max_depth: float, n_depth_levels: int) -> Lis
 # ----------------------------------------------------------------------------------------------------------------------
 # a2 / a3: plane-sweep cost volume
 # ----------------------------------------------------------------------------------------------------------------------
+# Diagnostic switch (tests/test_hybrid_parity.py): None = the reference's arithmetic, i.e. the small pose / intrinsics
+# algebra (inverse(pose2) @ pose1, K R K^-1, K t, inverse(prev_pose) @ pose) in the tensors' own dtype, float32 in practice.
+# Set to torch.float64 (``with exact_pose_algebra():``) those few matrices are evaluated in float64 and rounded once -- what
+# the HIP kernels do on the device.  In float32 the inverse of a camera-to-world pose with translations of several metres
+# carries ~5e-7 m of cancellation error in the relative translation, which the sweep turns into up to ~3e-4 px at the
+# 0.25 m plane: by far the largest difference between "the reference" and "the exact result", and the only one the
+# kernels do not reproduce.  The switch lets a test separate that term from everything else.
+POSE_ALGEBRA_DTYPE = None
+
+
+class exact_pose_algebra:
+    def __enter__(self):
+        global POSE_ALGEBRA_DTYPE
+        self.saved, POSE_ALGEBRA_DTYPE = POSE_ALGEBRA_DTYPE, torch.float64
+
+    def __exit__(self, *exc):
+        global POSE_ALGEBRA_DTYPE
+        POSE_ALGEBRA_DTYPE = self.saved
+
+
+def relative_pose(a: Tensor, c: Tensor) -> Tensor:
+    """inverse(a) @ c  (utils.py:51, :121; convlstm.py:30), in POSE_ALGEBRA_DTYPE when that is set."""
+    if POSE_ALGEBRA_DTYPE is None:
+        return torch.linalg.inv(a) @ c
+    return (torch.linalg.inv(a.to(POSE_ALGEBRA_DTYPE)) @ c.to(POSE_ALGEBRA_DTYPE)).to(c.dtype)
+
+
 def plane_sweep_setup(pose1: Tensor, pose2: Tensor, K: Tensor) -> Tuple[Tensor, Tensor]:
     """Per-batch homography part ``K R K^-1`` [B,3,3] and translation part ``K t`` [B,3,1].
 
     /root/reference/dvmvs/utils.py:51-56: extrinsic2 = inv(pose2) @ pose1.
     """
-    E = torch.linalg.inv(pose2) @ pose1
+    dt = POSE_ALGEBRA_DTYPE or pose1.dtype
+    E = torch.linalg.inv(pose2.to(dt)) @ pose1.to(dt)
     R = E[:, 0:3, 0:3]
     t = E[:, 0:3, 3:4]
-    return K @ R @ torch.linalg.inv(K), K @ t
+    Kd = K.to(dt)
+    return (Kd @ R @ torch.linalg.inv(Kd)).to(pose1.dtype), (Kd @ t).to(pose1.dtype)
 
 
 def cost_volume(image1: Tensor, image2: Tensor, pose1: Tensor, pose2: Tensor, K: Tensor,
@@ -237,7 +266,7 @@ def reproject_depth(reference_pose: Tensor, measurement_pose: Tensor, previous_d
     """
     B = reference_pose.shape[0]
     hw, hh = int(original_width / 2), int(original_height / 2)
-    trans = torch.linalg.inv(reference_pose) @ measurement_pose
+    trans = relative_pose(reference_pose, measurement_pose)
     pts = rigid_transform(trans, depth_to_points(previous_depth, full_K)).reshape(B, -1, 3)
     z = torch.relu(pts[..., 2])
     proj = torch.round(project(pts, half_K))
@@ -321,7 +350,7 @@ def convlstm_cell(conv_weight: Tensor, x: Tensor, h_cur: Tensor, c_cur: Tensor, 
                   current_pose: Tensor, estimated_current_depth: Tensor, camera_matrix: Tensor) -> Tuple[Tensor, Tensor]:
     """Whole cell forward (/root/reference/dvmvs/convlstm.py:26-59): warp+mask, 3x3 conv (no bias), gates."""
     if previous_pose is not None:
-        T = torch.linalg.inv(previous_pose) @ current_pose
+        T = relative_pose(previous_pose, current_pose)
         h_cur = warp_hidden_state(h_cur, estimated_current_depth, T, camera_matrix, zero_invalid=True)
     pad = (conv_weight.shape[2] // 2, conv_weight.shape[3] // 2)
     cc = torch.nn.functional.conv2d(torch.cat([x, h_cur], dim=1), conv_weight, bias=None, padding=pad)

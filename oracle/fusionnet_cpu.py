@@ -12,16 +12,39 @@ import torch
 import dvmvs_oracle as orc
 
 
+class OracleHotPath:
+    """The four hot-path operations of a frame as the CPU oracle evaluates them.  ``CpuDepthPipeline`` takes any object with
+    these methods: the hybrid parity test (tests/test_hybrid_parity.py) passes one whose methods run the HIP kernels through
+    the C ABI instead, so that the dense convolutions of both pipelines are the SAME CPU code and every difference in the
+    depth comes from the hot path alone."""
+
+    def __init__(self, planewise=False):
+        self.planewise = planewise
+
+    def cost_volume_fusion(self, ref_half, meas_halves, pose, meas_poses, half_K, lo, hi, D):
+        return orc.cost_volume_fusion(ref_half, meas_halves, pose, meas_poses, half_K, lo, hi, D, True, planewise=self.planewise)
+
+    def depth_estimate(self, pose, previous_pose, previous_depth, full_K, half_K, width, height):
+        return orc.nearest_downsample(orc.reproject_depth(pose, previous_pose, previous_depth, full_K, half_K, width, height), 16)
+
+    def warp_hidden(self, h, depth_estimate, previous_pose, pose, lstm_K):
+        return orc.warp_hidden_state(h, depth_estimate, orc.relative_pose(previous_pose, pose), lstm_K, zero_invalid=True)
+
+    def lstm_gates(self, combined_conv, c):
+        return orc.lstm_gates(combined_conv, c)
+
+
 class CpuDepthPipeline:
     def __init__(self, feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder,
-                 min_depth=0.25, max_depth=20.0, n_depth_levels=64, planewise_cost_volume=False):
+                 min_depth=0.25, max_depth=20.0, n_depth_levels=64, planewise_cost_volume=False, hot_path=None):
         self.fe, self.fs, self.enc, self.lstm, self.dec = (feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion,
                                                            cost_volume_decoder)
         for m in (self.fe, self.fs, self.enc, self.lstm, self.dec):
             if m is not None:
                 m.eval()
         self.depth_range = (min_depth, max_depth, n_depth_levels)
-        self.planewise = planewise_cost_volume   # bench.py: the per-plane grid_sample formulation is the fast one on CPUs
+        # bench.py: the per-plane grid_sample formulation of the cost volume is the fast one on CPUs
+        self.hot = hot_path if hot_path is not None else OracleHotPath(planewise=planewise_cost_volume)
         self.stage_seconds = {}
         self.reset()
 
@@ -45,20 +68,26 @@ class CpuDepthPipeline:
 
         meas_half = self._timed("features", lambda: [self.fs(*self.fe(img))[0] for img in measurement_images])
         ref_feats = self._timed("features", lambda: self.fs(*self.fe(reference_image)))
-        cv = self._timed("cost_volume", lambda: orc.cost_volume_fusion(ref_feats[0], meas_half, reference_pose, measurement_poses,
-                                                                        half_K, lo, hi, D, True, planewise=self.planewise))
+        cv = self._timed("cost_volume", lambda: self.hot.cost_volume_fusion(ref_feats[0], meas_half, reference_pose, measurement_poses,
+                                                                             half_K, lo, hi, D))
         skip0, skip1, skip2, skip3, bottom = self._timed("encoder", lambda: self.enc(*ref_feats, cv))
         de = None
         if self.lstm is not None:
             if self.previous_depth is not None:
-                de = self._timed("reprojection", lambda: orc.nearest_downsample(
-                    orc.reproject_depth(reference_pose, self.previous_pose, self.previous_depth, full_K, half_K, W, H), 16))
+                de = self._timed("reprojection", lambda: self.hot.depth_estimate(reference_pose, self.previous_pose, self.previous_depth,
+                                                                                 full_K, half_K, W, H))
             else:
                 de = torch.zeros(1, 1, H // 32, W // 32)
             h, c = self.lstm_state if self.lstm_state is not None else (torch.zeros_like(bottom), torch.zeros_like(bottom))
             weight = self.lstm.lstm_cell.conv.weight
-            self.lstm_state = self._timed("lstm", lambda: orc.convlstm_cell(weight, bottom, h, c, self.previous_pose, reference_pose,
-                                                                           de, lstm_K))
+
+            def cell():   # /root/reference/dvmvs/convlstm.py:26-59: warp + mask, 3x3 convolution without bias, gates
+                hw = h if self.previous_pose is None else self.hot.warp_hidden(h, de, self.previous_pose, reference_pose, lstm_K)
+                cc = torch.nn.functional.conv2d(torch.cat([bottom, hw], dim=1), weight, bias=None,
+                                                padding=(weight.shape[2] // 2, weight.shape[3] // 2))
+                return self.hot.lstm_gates(cc, c)
+
+            self.lstm_state = self._timed("lstm", cell)
             bottom_out = self.lstm_state[0]
         else:
             bottom_out = bottom
