@@ -308,11 +308,15 @@ extern "C" int dvmvs_cost_volume_bwd(const float* grad_cost, const float* image1
     constexpr int TW = 32, TH = 8, DP = 8, CCH = 16, CAP = 768;
     constexpr size_t kLds = sizeof(float) * CAP * (CCH + 1);   // 51 KB
     auto kernel = cost_volume_bwd_meas_tiled_kernel<TW, TH, DP, CCH, CAP>;
-    static bool configured = false;
-    if (!configured) {
+    // the dynamic-LDS limit is a per-device function attribute; setting it is idempotent, racing threads write the same value
+    static bool configured[64] = {};
+    int device = 0;
+    DVMVS_RETURN_IF_HIP(hipGetDevice(&device));
+    const bool tracked = device >= 0 && device < 64;
+    if (!tracked || !configured[device]) {
       DVMVS_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               static_cast<int>(kLds)));
-      configured = true;
+      if (tracked) configured[device] = true;
     }
     dim3 block(TW * TH), grid(((W + TW - 1) / TW) * ((H + TH - 1) / TH), (D + DP - 1) / DP, B);
     hipLaunchKernelGGL(kernel, grid, block, kLds, s, a);

@@ -77,6 +77,57 @@ def fusionnet_subsequence_loss(model, images, depths, poses, K, warp_grid=None):
     return loss, full_predictions
 
 
+class TrainingHyperparameters:
+    """fusionnet/run-training.py:21-27."""
+    Config.train_subsequence_length = Config.train_subsequence_length or 8
+    batch_size = 4
+    learning_rate = 1e-4
+    momentum = 0.9
+    beta = 0.999
+    weight_decay = 0
+    loss_type = "L1-inv"   # "L1", "L1-inv", "L1-rel" or "Huber"
+    finetune_epochs = 1
+    use_checkpoint = False
+
+
+def forward_pass(images, depths, poses, K, model, is_training):
+    """The fusionnet training scripts' ``forward_pass`` (run-training.py:184-284) with its exact return contract:
+    (l1_meter, huber_meter, l1_inv_meter, l1_rel_meter, optimizer_loss, [quarter, half, full] predictions of the last frame,
+    their names).  Tensors are moved to the current HIP device; the cost volume, hidden-state warp and gates run as HIP
+    kernels with their backward kernels, the convolutions through MIOpen."""
+    from dvmvs.losses import LossMeter, update_losses
+    fe, fs, enc, lstm, dec = model
+    device = next(fe.parameters()).device
+    images = [t.to(device) for t in images]
+    depths = [t.to(device) for t in depths]
+    poses = [t.to(device) for t in poses]
+    K = K.to(device)
+    B, _, H, W = images[0].shape
+    half_K = K.clone()
+    half_K[:, 0:2, :] = half_K[:, 0:2, :] * 0.5
+    lstm_K = K.clone()
+    lstm_K[:, 0:2, :] = lstm_K[:, 0:2, :] / 32.0
+    warp_grid = get_warp_grid_for_cost_volume_calculation(W // 2, H // 2, device)
+    feats = [fs(*fe(img)) for img in images]
+    meters = [LossMeter() for _ in range(4)]
+    l1_meter, huber_meter, l1_inv_meter, l1_rel_meter = meters
+    optimizer_loss, predictions, state = 0, None, None
+    for i in range(1, len(images)):
+        ref, meas = feats[i], feats[i - 1]
+        cost_volume = calculate_cost_volume_by_warping(ref[0], meas[0], poses[i], poses[i - 1], half_K, warp_grid, Config.train_min_depth,
+                                                       Config.train_max_depth, Config.train_n_depth_levels, device, True)
+        skip0, skip1, skip2, skip3, bottom = enc(ref[0], ref[1], ref[2], ref[3], cost_volume)
+        depth_estimation = F.interpolate(depths[i].view(B, 1, H, W), scale_factor=1.0 / 32.0, mode="nearest")
+        state = lstm(bottom, state, poses[i - 1], poses[i], depth_estimation, lstm_K)
+        full, half, quarter, one_eight, one_sixteen = dec(images[i], skip0, skip1, skip2, skip3, state[0])
+        optimizer_loss = optimizer_loss + update_losses(predictions=[one_sixteen, one_eight, quarter, half, full], weights=[1, 1, 1, 1, 1],
+                                                        groundtruth=depths[i], is_training=is_training, l1_meter=l1_meter,
+                                                        huber_meter=huber_meter, l1_inv_meter=l1_inv_meter, l1_rel_meter=l1_rel_meter,
+                                                        loss_type=TrainingHyperparameters.loss_type)
+        predictions = [quarter, half, full]
+    return l1_meter, huber_meter, l1_inv_meter, l1_rel_meter, optimizer_loss, predictions, ["prediction_quarter", "prediction_half", "prediction_full"]
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # bucketed gradient all-reduce
 # ----------------------------------------------------------------------------------------------------------------------

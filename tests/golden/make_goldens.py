@@ -348,10 +348,34 @@ def error_metric_goldens(ref):
          nothing_valid=np.array(ref.errors.compute_errors(np.zeros((4, 4)), np.ones((4, 4)))))
 
 
+def loss_goldens(ref):
+    """dvmvs/losses.py:26-82 on deterministic maps: the four sums + valid count of calculate_loss at three resolutions, and
+    update_losses (optimizer loss + meter state) for every loss type in training mode and once in evaluation mode."""
+    gt, preds = syn.loss_inputs()
+    out = {}
+    for j, p in enumerate(preds):
+        l1, huber, l1_inv, l1_rel, count = ref.losses.calculate_loss(groundtruth=gt, prediction=p)
+        out[f"calc{j}"] = np.array([l1.item(), huber.item(), l1_inv.item(), l1_rel.item(), float(count)], dtype=np.float64)
+    weights = [0.5, 1.0, 2.0]
+    for loss_type in ("L1", "L1-inv", "L1-rel", "Huber"):
+        meters = [ref.losses.LossMeter() for _ in range(4)]
+        total = ref.losses.update_losses(preds, weights, gt, True, meters[0], meters[1], meters[2], meters[3], loss_type)
+        total = total + ref.losses.update_losses(preds[::-1], weights, gt, True, meters[0], meters[1], meters[2], meters[3], loss_type)
+        out[f"train_{loss_type}"] = np.array([float(total)] + [v for m in meters for v in (m.sum, m.count, m.avg, m.item_average)], dtype=np.float64)
+        out[f"repr_{loss_type}"] = np.array([repr(m) for m in meters])
+    meters = [ref.losses.LossMeter() for _ in range(4)]
+    total = ref.losses.update_losses(preds, weights, gt, False, meters[0], meters[1], meters[2], meters[3], "L1")
+    out["eval"] = np.array([float(total)] + [v for m in meters for v in (m.sum, m.count, m.avg, m.item_average)], dtype=np.float64)
+    save("losses", **out)
+
+
 def main():
     ref = import_reference()
     if "--only-errors" in sys.argv:      # adds one fixture without rewriting the others
         error_metric_goldens(ref)
+        return
+    if "--only-losses" in sys.argv:
+        loss_goldens(ref)
         return
     cost_volume_goldens(ref)
     de16 = reprojection_goldens(ref)
@@ -359,6 +383,7 @@ def main():
     end_to_end_goldens(ref)
     keyframe_goldens(ref)
     error_metric_goldens(ref)
+    loss_goldens(ref)
     REPORT["_meta"] = {"torch": torch.__version__, "reference": "ardaduz/deep-video-mvs @ /root/reference", "device": "cpu",
                        "note": "differences are |oracle - reference| on identical inputs, float32"}
     with open(os.path.join(HERE, "PINNING_REPORT.json"), "w") as f:

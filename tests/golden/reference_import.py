@@ -102,6 +102,7 @@ def import_reference():
     ns.pairnet_model = importlib.import_module("dvmvs.pairnet.model")
     ns.keyframe_buffer = importlib.import_module("dvmvs.keyframe_buffer")
     ns.errors = importlib.import_module("dvmvs.errors")
+    ns.losses = importlib.import_module("dvmvs.losses")
     ns.oracle = oracle
     assert ns.utils.__file__.startswith(REFERENCE_ROOT)
     return ns

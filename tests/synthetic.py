@@ -237,3 +237,24 @@ def error_metric_inputs():
     pred = gt * (1.0 + 0.1 * np.sin(np.arange(320) / 17.0))[None, :] + 0.05
     pred[:20, :30] = 1.0
     return gt, pred
+
+
+def loss_inputs():
+    """Deterministic (ground truth [B,H,W], [predictions at 1/4, 1/2, full resolution]) for the training-loss golden:
+    invalid (zero) ground-truth pixels, errors on both sides of the smooth-L1 knee."""
+    B, H, W = 2, 32, 40
+    y = torch.arange(H, dtype=torch.float64).view(1, H, 1)
+    x = torch.arange(W, dtype=torch.float64).view(1, 1, W)
+    b = torch.arange(B, dtype=torch.float64).view(B, 1, 1)
+    gt = 1.5 + 0.8 * torch.sin(x / 7.0 + b) + 0.5 * torch.cos(y / 5.0)
+    gt[:, :6, :9] = 0.0
+    gt[1, 20:24, 30:] = 0.0
+    gt = gt.float()
+    preds = []
+    for s in (4, 2, 1):
+        h, w = H // s, W // s
+        yy = torch.arange(h, dtype=torch.float64).view(1, h, 1) * s
+        xx = torch.arange(w, dtype=torch.float64).view(1, 1, w) * s
+        p = 1.5 + 0.8 * torch.sin(xx / 7.0 + b + 0.05 * s) + 0.5 * torch.cos(yy / 5.0) + 0.3 * torch.sin(xx * yy / 90.0) * s
+        preds.append(p.clamp(min=0.3).float())
+    return gt, preds

@@ -124,24 +124,110 @@ def test_gpu_training_step_matches_cpu_oracle_autograd(hip_device):
     loss_gpu.backward()
     reducer.finish()
     assert abs(loss_gpu.item() - loss_cpu.item()) <= 2e-3 * abs(loss_cpu.item())
-    checked = 0
-    for mc, mg in zip(cpu_model, gpu_model):
-        for (name, pc), (_, pg) in zip(mc.named_parameters(), mg.named_parameters()):
+    # The same loss and gradients in float64 on the CPU: the arbiter.  |.| in the loss and ~50 ReLU layers make the gradient
+    # piecewise constant in the activations, so ANY float32 evaluation (oneDNN's or MIOpen's) flips a few gates relative to
+    # float64 and isolated entries move by a few per cent.  The criterion is therefore the one used for the forward kernels:
+    # the GPU's float32 gradient may be at most twice as far from the float64 gradient as the CPU's float32 gradient is
+    # (floor 1e-2 relative L2), and must point the same way (cosine >= 0.9995).
+    model64 = [m.double() for m in syn.build_e2e_modules(ctors)]
+    loss64 = cpu_subsequence_loss(model64, [t.double() for t in images], [t.double() for t in depths], [t.double() for t in poses],
+                                  K.double(), Config.train_min_depth, Config.train_max_depth, Config.train_n_depth_levels)
+    loss64.backward()
+    assert abs(loss_gpu.item() - loss64.item()) <= 2.0 * abs(loss_cpu.item() - loss64.item()) + 1e-4 * abs(loss64.item())
+    checked, worst = 0, (0.0, "")
+    for mc, mg, m64 in zip(cpu_model, gpu_model, model64):
+        for (name, pc), (_, pg), (_, p64) in zip(mc.named_parameters(), mg.named_parameters(), m64.named_parameters()):
             if pc.grad is None:
                 continue
-            scale = pc.grad.abs().max().item()
-            if scale < 1e-8:
+            if pc.grad.abs().max().item() < 1e-8:
                 continue
-            # |.| in the loss and ~50 ReLU layers make the gradient piecewise constant in the activations: fp32 differences
-            # between MIOpen and oneDNN flip a few gates (isolated entries move by a few %), so the comparison is direction (cosine) + relative L2 error
+            ref = p64.grad.flatten()
             a, b = pg.grad.cpu().double().flatten(), pc.grad.double().flatten()
-            cosine = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
-            rel_l2 = float((a - b).norm() / (b.norm() + 1e-30))
-            assert cosine >= 0.999 and rel_l2 <= 5e-2, (type(mc).__name__, name, cosine, rel_l2, scale)
+            cosine = float(torch.dot(a, ref) / (a.norm() * ref.norm() + 1e-30))
+            gpu_l2 = float((a - ref).norm() / (ref.norm() + 1e-30))
+            cpu_l2 = float((b - ref).norm() / (ref.norm() + 1e-30))
+            assert cosine >= 0.9995 and gpu_l2 <= max(1e-2, 2.0 * cpu_l2), (type(mc).__name__, name, cosine, gpu_l2, cpu_l2)
+            worst = max(worst, (gpu_l2, f"{type(mc).__name__}.{name} (cpu fp32: {cpu_l2:.2e})"))
             checked += 1
+    print(f"training-step gradients: {checked} parameters, worst GPU-vs-float64 relative L2 {worst[0]:.2e} at {worst[1]}")
     assert checked > 100
     # and one optimiser step runs end to end
     opt = torch.optim.Adam(params, lr=1e-4)
     before = params[-1].detach().clone()
     out = train_step(gpu_model, opt, reducer, [t.to(dev) for t in images], [t.to(dev) for t in depths], [t.to(dev) for t in poses], K.to(dev))
     assert torch.isfinite(out) and not torch.equal(before, params[-1].detach())
+
+
+@pytest.mark.gpu
+def test_training_step_at_the_config5_size(hip_device):
+    """BASELINE.json configs[4] at its stated size: sub-sequences of 8 frames, 4 per GPU, 256x256, 64 planes, batch-norm in
+    training mode (fusionnet/run-training.py:184-284).  Too large for a CPU oracle run, so size-independent properties:
+    finite loss, gradient reaching all five modules, the forward pass reproducible to 1e-6 and the backward pass (atomic
+    scatters of the measurement-feature and hidden-state gradients, MIOpen's weight-gradient kernels) to 2e-2, the reference-signature forward_pass agreeing
+    with the bare loss, one Adam step changing the weights -- and the LDS-privatised measurement-gradient scatter of the cost
+    volume checked against autograd through the CPU oracle at this feature size (4096+ pixels select it)."""
+    import dvmvs_oracle as orc
+    from dvmvs.config import Config
+    from dvmvs.fusionnet.model import CostVolumeDecoder, CostVolumeEncoder, FeatureExtractor, FeatureShrinker, LSTMFusion
+    from dvmvs.hip import ops
+    from dvmvs.training import BucketedGradientReducer, forward_pass, fusionnet_subsequence_loss, train_step
+    from dvmvs.train import switch_mode
+    dev = hip_device
+    ctors = (FeatureExtractor, FeatureShrinker, CostVolumeEncoder, LSTMFusion, CostVolumeDecoder)
+    model = [m.to(dev) for m in syn.build_e2e_modules(ctors)]
+    switch_mode(model, "train")
+    B, T, H, W = 4, 8, Config.train_image_height, Config.train_image_width
+    g = torch.Generator().manual_seed(77)
+    images = [syn.smooth_noise((B, 3, H, W), seed=5000 + i).to(dev) for i in range(T)]
+    depths = [(torch.rand(B, H, W, generator=g) * 4.5 + 0.5).to(dev) for _ in range(T)]
+    depths[3][:, :16, :16] = 0.0
+    all_poses = torch.from_numpy(syn.sample_poses()).float()
+    poses = [torch.stack([all_poses[(40 * b + 3 * i) % len(all_poses)] for b in range(B)]).to(dev) for i in range(T)]
+    K = torch.cat([syn.full_K(width=W, height=H)] * B).to(dev)
+    params = [p for m in model for p in m.parameters()]
+    reducer = BucketedGradientReducer(params)
+
+    def run():
+        reducer.zero_grad()
+        loss, predictions = fusionnet_subsequence_loss(model, images, depths, poses, K)
+        loss.backward()
+        reducer.finish()
+        return loss.detach(), [f.clone() for f in reducer.flat], predictions
+
+    loss1, grads1, predictions = run()
+    assert torch.isfinite(loss1) and len(predictions) == T - 1 and tuple(predictions[0].shape) == (B, H, W)
+    for module in model:
+        norms = [p.grad.norm().item() for p in module.parameters() if p.requires_grad]
+        assert all(np.isfinite(norms)) and sum(n > 0 for n in norms) >= 0.9 * len(norms), type(module).__name__
+    loss2, grads2, _ = run()
+    assert abs(loss2.item() - loss1.item()) <= 1e-6 * abs(loss1.item())
+    for a, b in zip(grads1, grads2):
+        # run-to-run noise of floating-point atomics (scatter kernels here, weight-gradient kernels in MIOpen), amplified on
+        # the way down to the first layers: measured 2e-4 (last buckets) to 3.4e-3 (feature extractor)
+        assert float((a - b).norm() / (a.norm() + 1e-30)) <= 2e-2
+    # the script-level forward pass (meters + loss, reference signature) computes the same loss
+    meters_and_loss = forward_pass(images=images, depths=depths, poses=poses, K=K, model=model, is_training=True)
+    assert abs(meters_and_loss[4].item() - loss1.item()) <= 1e-5 * abs(loss1.item())
+    assert meters_and_loss[2].count > 0 and len(meters_and_loss[5]) == 3
+    opt = torch.optim.Adam(params, lr=1e-4)
+    before = params[-1].detach().clone()
+    out = train_step(model, opt, reducer, images, depths, poses, K)
+    assert torch.isfinite(out) and not torch.equal(before, params[-1].detach())
+
+    # measurement-feature gradient of the cost volume at the training feature size (128 x 128): HIP (LDS-privatised scatter)
+    # against autograd through the CPU oracle
+    f1 = syn.smooth_noise((2, 32, 128, 128), seed=811).requires_grad_(True)
+    f2 = syn.smooth_noise((2, 32, 128, 128), seed=812).requires_grad_(True)
+    p1 = torch.cat([syn.pose(20), syn.pose(203)])
+    p2 = torch.cat([syn.pose(19), syn.pose(202)])
+    halfK = syn.scaled_K(torch.cat([syn.full_K(width=256, height=256)] * 2), 2.0)
+    w = syn.smooth_noise((2, 64, 128, 128), seed=813)
+    with orc.exact_pose_algebra():   # float64 pose algebra like the kernels (see tests/test_hybrid_parity.py)
+        (orc.cost_volume(f1, f2, p1, p2, halfK, 0.25, 20.0, 64, True) * w).sum().backward()
+    g1, g2 = f1.detach().to(dev).requires_grad_(True), f2.detach().to(dev).requires_grad_(True)
+    (ops.cost_volume(g1, [g2], p1.to(dev), [p2.to(dev)], halfK.to(dev), 0.25, 20.0, 64, True, 0) * w.to(dev)).sum().backward()
+    for got, exp in ((g1.grad, f1.grad), (g2.grad, f2.grad)):
+        err = (got.cpu() - exp).abs()
+        print(f"cost-volume gradient at 128x128: max |err| {err.max().item():.2e} (max |g| {exp.abs().max().item():.2e}), mean {err.mean().item():.2e}")
+        assert err.max().item() <= 5e-5 * max(1.0, exp.abs().max().item())       # measured 4e-6 of max |g|
+        assert err.mean().item() <= 5e-6 * max(1.0, exp.abs().mean().item())
