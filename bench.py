@@ -56,6 +56,10 @@ def parse():
                     help="bracket the timed loop with a cumsum kernel so tools/summarize_trace.py can cut it out of a rocprofv3 trace")
     ap.add_argument("--no-roofline-leg", action="store_true", help="skip the dedicated cost-volume timing (profiling runs)")
     ap.add_argument("--no-rel-l1", action="store_true", help="skip the golden-frame parity check that fills the rel_l1 field")
+    ap.add_argument("--sequences-per-gpu", type=int, default=8,
+                    help="secondary measurement: S independent sequences in lockstep on one engine (batch S); 0 = skip. "
+                         "The headline value is always one sequence per GPU (BASELINE.json configs[2]).")
+    ap.add_argument("--batched-steps", type=int, default=40)
     return ap.parse_args()
 
 
@@ -124,6 +128,49 @@ def golden_rel_l1(modules, device, args):
                         "engine_vs_float64": float(np.mean(np.abs(d - z[f"f{n}_depth64_sub4"]) / z[f"f{n}_depth64_sub4"])),
                         "reference_vs_float64": float(np.mean(np.abs(ref - z[f"f{n}_depth64_sub4"]) / z[f"f{n}_depth64_sub4"]))})
     return out
+
+
+def batched_throughput(modules, device, args, S, M):
+    """Secondary figure: S independent sequences per GPU advancing in lockstep on ONE engine (batch S through every
+    convolution and one cost-volume launch for all of them).  Returns (frames/s over all S sequences, ms per lockstep step,
+    mean seconds of the batch-S cost-volume op, its algorithmic bytes)."""
+    from dvmvs.engine import DepthEngine
+    engine = DepthEngine(*modules, device=device, fold_bn=not args.no_fold_bn, cache_features=not args.no_feature_cache,
+                         use_graphs=not args.no_graphs, channels_last=args.channels_last,
+                         lstm_channels_last=not args.no_lstm_channels_last, sequences=S)
+    n_images, warmup, steps = 16, 6, args.batched_steps
+    per_seq = [synthetic_sequence(sid, n_images, warmup + steps + M + 1, M) for sid in range(S)]
+    images = [torch.cat([per_seq[sid][0][i] for sid in range(S)]).to(device) for i in range(n_images)]
+    seq = [(torch.cat([per_seq[sid][1][j][0] for sid in range(S)]).to(device),
+            [torch.cat([per_seq[sid][1][j][1][m] for sid in range(S)]).to(device) for m in range(M)]) for j in range(len(per_seq[0][1]))]
+    full_K = per_seq[0][2].repeat(S, 1, 1).to(device)
+    cache = not args.no_feature_cache
+
+    def run_frame(k):
+        ids = [k - 1 - i for i in range(M)]
+        return engine.step(images[k % n_images], seq[k][0], None if cache else [images[i % n_images] for i in ids], seq[k][1], full_K,
+                           frame_id=k if cache else None, measurement_ids=ids if cache else None)
+
+    with torch.no_grad():
+        if cache:
+            for k in range(M):
+                engine._half_features(k, images[k % n_images])
+        k = M
+        for _ in range(warmup):
+            run_frame(k)
+            k += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run_frame(k)
+            k += 1
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    assert np.isfinite(float(engine._static["depth"].mean()))
+    _, pose_sets = index_pose_sets(M, 9)
+    pose_sets = [(r.repeat(S, 1, 1).to(device), [p.repeat(S, 1, 1).to(device) for p in ms]) for r, ms in pose_sets]
+    kernel_s, alg_bytes, _ = measure_cost_volume_kernel(engine, M, max(2, args.kernel_reps // 2), pose_sets)
+    return S * steps / elapsed, 1e3 * elapsed / steps, kernel_s, alg_bytes
 
 
 def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
@@ -428,6 +475,19 @@ def main():
                 "engine_vs_float64": [r["engine_vs_float64"] for r in rel],
                 "reference_vs_float64": [r["reference_vs_float64"] for r in rel]},
         }
+        if world == 1 and args.sequences_per_gpu > 1:
+            try:
+                S = args.sequences_per_gpu
+                fps_b, ms_b, kernel_b, bytes_b = batched_throughput(modules, device, args, S, M)
+                result["value_batched"] = fps_b
+                result["batched"] = {"sequences_per_gpu": S, "frames_per_s": fps_b, "ms_per_lockstep_step": ms_b, "steps": args.batched_steps,
+                                     "note": "secondary: S independent sequences in lockstep on one engine (batch S); not the headline"}
+                result["roofline"]["frac_batched"] = bytes_b / kernel_b / 1e9 / HBM_PEAK_GBPS
+                result["roofline"]["kernel_us_batched"] = kernel_b * 1e6
+                result["roofline_valu"]["frac_batched"] = (S * useful_flop / kernel_b / 1e12) / FP32_VALU_PEAK_TFLOPS
+            except Exception as e:   # the secondary figure must never cost the headline line
+                result["value_batched"] = None
+                result["batched"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             cpu_mods = build_modules()
             result["cpu_baseline"] = cpu_baseline(args, cpu_mods, M)

@@ -138,14 +138,19 @@ def fuse_epilogues(module):
 # frame engine
 # ----------------------------------------------------------------------------------------------------------------------
 class DepthEngine:
-    """Sequential keyframe processor for ONE video sequence (batch 1), pairnet (``lstm_fusion=None``) or fusionnet.
+    """Sequential keyframe processor for one video sequence (batch 1: the reference's case) or ``sequences`` = S independent
+    sequences advancing in lockstep (batch S: one cost-volume launch, one convolution per layer for all of them), pairnet
+    (``lstm_fusion=None``) or fusionnet.
 
-    ``step`` mirrors one iteration of the reference loop; ``reset`` is the "TRACKING LOST" rule.
+    ``step`` mirrors one iteration of the reference loop; ``reset`` is the "TRACKING LOST" rule (per sequence when S > 1).
+    With S > 1 every frame takes the "has a previous frame" path: a sequence without one has zero state, zero previous
+    depth and therefore an all-zero depth estimate, for which warp + mask return exactly the zeros the reference's
+    first-frame path starts from (convlstm.py:29-41), so the per-sequence results do not depend on what the others do.
     """
 
     def __init__(self, feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder,
                  device="cuda", min_depth=0.25, max_depth=20.0, n_depth_levels=64, fold_bn=True, cache_features=True,
-                 use_graphs=True, cache_size=None, channels_last=False, fuse=True, lstm_channels_last=True):
+                 use_graphs=True, cache_size=None, channels_last=False, fuse=True, lstm_channels_last=True, sequences=1):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DepthEngine runs on an MI355X; there is no CPU execution path in this package")
@@ -169,6 +174,9 @@ class DepthEngine:
         self.cache_size = cache_size or (Config.test_keyframe_buffer_size + 2)
         self.use_graphs = use_graphs
         self.height, self.width = Config.test_image_height, Config.test_image_width
+        self.sequences = int(sequences)
+        if self.sequences < 1:
+            raise ValueError("sequences must be >= 1")
         self._feature_cache = OrderedDict()
         self._graphs = {}
         self._static = None
@@ -180,15 +188,26 @@ class DepthEngine:
     def is_fusionnet(self):
         return self.lstm is not None
 
-    def reset(self):
-        """Forget the recurrent state and the previous depth/pose (reference: "TRACKING LOST", run-testing.py:97-101)."""
-        self.has_previous = False
-        if self._static is not None:
+    def reset(self, sequence=None):
+        """Forget the recurrent state and the previous depth/pose (reference: "TRACKING LOST", run-testing.py:97-101), of all
+        sequences or of one (S > 1)."""
+        if sequence is None or self.sequences == 1:
+            self.has_previous = False
+            if self._static is not None:
+                for k in ("h", "c", "prev_depth"):
+                    self._static[k].zero_()
+        elif self._static is not None:
             for k in ("h", "c", "prev_depth"):
-                self._static[k].zero_()
+                self._static[k][sequence].zero_()
 
     def clear_feature_cache(self):
         self._feature_cache.clear()
+
+    def new_sequence(self):
+        """Start of another video sequence on the same engine: forget the recurrent state AND the cached keyframe features
+        (the cache is keyed by the caller's frame ids, which restart with every sequence)."""
+        self.reset()
+        self.clear_feature_cache()
 
     # ---- pieces -----------------------------------------------------------------------------------------------------
     def _features(self, image):
@@ -211,16 +230,16 @@ class DepthEngine:
                 self._feature_cache.popitem(last=False)
 
     def _allocate_static(self, n_meas):
-        d, H, W = self.device, self.height, self.width
+        d, H, W, S = self.device, self.height, self.width, self.sequences
         z = lambda *s: torch.zeros(*s, device=d, dtype=torch.float32)
         if self._static is None:
-            self._static = dict(image=z(1, 3, H, W), pose=z(1, 4, 4), full_K=z(1, 3, 3), half_K=z(1, 3, 3), lstm_K=z(1, 3, 3),
-                                prev_pose=z(1, 4, 4), prev_depth=z(1, 1, H, W), h=z(1, 512, H // 32, W // 32),
-                                c=z(1, 512, H // 32, W // 32), meas_feat=[], meas_pose=[],
-                                ref_half=z(1, 32, H // 2, W // 2), depth=z(1, H, W))
+            self._static = dict(image=z(S, 3, H, W), pose=z(S, 4, 4), full_K=z(S, 3, 3), half_K=z(S, 3, 3), lstm_K=z(S, 3, 3),
+                                prev_pose=torch.eye(4, device=d).repeat(S, 1, 1), prev_depth=z(S, 1, H, W), h=z(S, 512, H // 32, W // 32),
+                                c=z(S, 512, H // 32, W // 32), meas_feat=[], meas_pose=[],
+                                ref_half=z(S, 32, H // 2, W // 2), depth=z(S, H, W))
         while len(self._static["meas_feat"]) < n_meas:
-            self._static["meas_feat"].append(z(1, 32, H // 2, W // 2))
-            self._static["meas_pose"].append(z(1, 4, 4))
+            self._static["meas_feat"].append(z(S, 32, H // 2, W // 2))
+            self._static["meas_pose"].append(z(S, 4, 4))
 
     def _frame_body(self, n_meas, has_previous):
         """The per-frame computation on the static buffers (this is what gets captured into a hipGraph)."""
@@ -237,7 +256,7 @@ class DepthEngine:
                                                                   s["half_K"], 16)
                 state = self.lstm(bottom, (s["h"], s["c"]), s["prev_pose"], s["pose"], depth_estimation, s["lstm_K"])
             else:
-                depth_estimation = torch.zeros(1, 1, self.height // 32, self.width // 32, device=self.device)
+                depth_estimation = torch.zeros(self.sequences, 1, self.height // 32, self.width // 32, device=self.device)
                 state = self.lstm(bottom, None, None, s["pose"], depth_estimation, s["lstm_K"])
             s["h"].copy_(state[0])
             s["c"].copy_(state[1])
@@ -245,17 +264,19 @@ class DepthEngine:
         prediction = self.dec(s["image"], skip0, skip1, skip2, skip3, bottom, full_resolution_only=True)[0]
         s["depth"].copy_(prediction)
         if self.is_fusionnet:
-            s["prev_depth"].copy_(prediction.view(1, 1, self.height, self.width))
+            s["prev_depth"].copy_(prediction.view(self.sequences, 1, self.height, self.width))
             s["prev_pose"].copy_(s["pose"])
 
     # ---- public -----------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, reference_image, reference_pose, measurement_images, measurement_poses, full_K, frame_id=None,
              measurement_ids=None):
-        """One keyframe.  Images [1,3,H,W] normalised, poses [1,4,4] cam-to-world, ``full_K`` [1,3,3]; all on the GPU.
+        """One keyframe (of each of the S sequences).  Images [S,3,H,W] normalised, poses [S,4,4] cam-to-world, ``full_K``
+        [S,3,3]; all on the GPU.  With S > 1 the sequences advance in lockstep: ``frame_id`` / ``measurement_ids`` name the
+        step for all of them and a cached feature entry holds all S maps.
 
         ``measurement_images[i]`` may be ``None`` when ``measurement_ids[i]`` is in the feature cache.
-        Returns the full-resolution depth [1,H,W] (a static buffer that the next call overwrites: clone to keep).
+        Returns the full-resolution depth [S,H,W] (a static buffer that the next call overwrites: clone to keep).
         """
         n_meas = len(measurement_poses)
         if n_meas < 1:
@@ -263,14 +284,26 @@ class DepthEngine:
         measurement_ids = measurement_ids or [None] * n_meas
         self._allocate_static(n_meas)
         s = self._static
-        if tuple(reference_image.shape) != (1, 3, self.height, self.width):
-            raise ValueError(f"image must be [1,3,{self.height},{self.width}], got {tuple(reference_image.shape)}")
+        if tuple(reference_image.shape) != (self.sequences, 3, self.height, self.width):
+            raise ValueError(f"image must be [{self.sequences},3,{self.height},{self.width}], got {tuple(reference_image.shape)}")
+        # resolve every measurement frame BEFORE anything is inserted into the cache: an insertion may evict the least
+        # recently used entry, which could be a frame this very call still needs
+        fresh = []
         for i in range(n_meas):
             img = measurement_images[i] if measurement_images is not None else None
-            if img is None and not (self.cache_features and measurement_ids[i] in self._feature_cache):
-                raise ValueError(f"measurement frame {measurement_ids[i]} is not cached and no image was given")
-            s["meas_feat"][i].copy_(self._half_features(measurement_ids[i], img))
+            mid = measurement_ids[i]
+            if self.cache_features and mid is not None and mid in self._feature_cache:
+                self._feature_cache.move_to_end(mid)
+                half = self._feature_cache[mid]
+            elif img is None:
+                raise ValueError(f"measurement frame {mid} is not cached and no image was given")
+            else:
+                half = self._features(img)[0].contiguous()
+                fresh.append((mid, half))
+            s["meas_feat"][i].copy_(half)
             s["meas_pose"][i].copy_(measurement_poses[i])
+        for mid, half in fresh:
+            self._remember(mid, half)
         s["image"].copy_(reference_image)
         s["pose"].copy_(reference_pose)
         s["full_K"].copy_(full_K)
@@ -279,7 +312,8 @@ class DepthEngine:
         s["lstm_K"].copy_(full_K)
         s["lstm_K"][:, 0:2, :] /= 32.0
 
-        key = (n_meas, self.has_previous and self.is_fusionnet)
+        # S > 1: always the previous-state path (see the class docstring); S == 1: the reference's two frame kinds
+        key = (n_meas, (self.has_previous or self.sequences > 1) and self.is_fusionnet)
         if not self.use_graphs:
             self._frame_body(*key)
         elif key not in self._warm:

@@ -71,17 +71,19 @@ def _run_frame(engine, scene, timer, device, reference_index, measurement_indice
     return prediction, reference_depth
 
 
-def predict_offline(engine: DepthEngine, scene_folder, keyframe_index_file, evaluate=True, max_frames=None):
-    """Runs the lines of a keyframe index file ("ref meas1 meas2 ..." or "TRACKING LOST") through ``engine``."""
+def predict_offline(engine: DepthEngine, scene_folder, keyframe_index_file, evaluate=True, max_frames=None, frame_log=None):
+    """Runs the lines of a keyframe index file ("ref meas1 meas2 ..." or "TRACKING LOST") through ``engine``.
+    ``frame_log`` (a list) receives the line each prediction belongs to: "ref meas1 ..." file names, or "TRACKING LOST"."""
     scene = Scene(scene_folder)
     device = engine.device
     position = {name: i for i, name in enumerate(scene.image_names)}
     timer = InferenceTimer()
     predictions, reference_depths = [], []
-    engine.reset()
-    engine.clear_feature_cache()
+    engine.new_sequence()
     lines = [l.strip() for l in open(keyframe_index_file) if l.strip()]
     for line in lines[:max_frames]:
+        if frame_log is not None:
+            frame_log.append(line)
         if line == "TRACKING LOST":
             engine.reset()
             continue
@@ -92,8 +94,10 @@ def predict_offline(engine: DepthEngine, scene_folder, keyframe_index_file, eval
     return predictions, (reference_depths if evaluate and scene.depth_names else None), timer
 
 
-def predict_online(engine: DepthEngine, scene_folder, evaluate=False, max_frames=None):
-    """Feeds every frame of the scene to a KeyframeBuffer and predicts depth for the frames it accepts as keyframes."""
+def predict_online(engine: DepthEngine, scene_folder, evaluate=False, max_frames=None, frame_log=None):
+    """Feeds every frame of the scene to a KeyframeBuffer and predicts depth for the frames it accepts as keyframes.
+    ``frame_log`` (a list) receives, in index-file syntax, what the buffer decided: one "ref meas1 ..." line per prediction and
+    "TRACKING LOST" where it cleared itself -- the lines simulate_keyframe_index would write for the same poses."""
     scene = Scene(scene_folder)
     device = engine.device
     buffer = KeyframeBuffer(buffer_size=Config.test_keyframe_buffer_size, keyframe_pose_distance=Config.test_keyframe_pose_distance,
@@ -101,17 +105,46 @@ def predict_online(engine: DepthEngine, scene_folder, evaluate=False, max_frames
                             store_return_indices=True)
     timer = InferenceTimer()
     predictions, reference_depths = [], []
-    engine.reset()
-    engine.clear_feature_cache()
+    engine.new_sequence()
     n = len(scene.poses) if max_frames is None else min(max_frames, len(scene.poses))
     for i in range(n):
         response = buffer.try_new_keyframe(scene.poses[i], None, index=i)
         if response == 3:
             engine.reset()
+            if frame_log is not None:
+                frame_log.append("TRACKING LOST")
         if response != 1:
             continue
         measurement_indices = [frame[2] for frame in buffer.get_best_measurement_frames(Config.test_n_measurement_frames)]
+        if frame_log is not None:
+            frame_log.append(" ".join(scene.image_names[j] for j in [i] + measurement_indices))
         prediction, reference_depth = _run_frame(engine, scene, timer, device, i, measurement_indices, evaluate)
         predictions.append(prediction)
         reference_depths.append(reference_depth)
     return predictions, (reference_depths if evaluate and scene.depth_names else None), timer
+
+
+def predict_sharded(make_engine, scene_folders, keyframe_index_files, evaluate=True, max_frames=None, rank=None, world=None):
+    """BASELINE.json configs[3]: independent scenes sharded over the ranks of one node (scene ``s`` belongs to rank
+    ``s % world``, dvmvs.sharding), each run through ``predict_offline`` on this rank's engine; no data-path collective.
+    ``make_engine()`` builds the rank's DepthEngine lazily (a rank that owns no scene builds none).  Returns
+    ({scene number: (predictions, reference depths or None, InferenceTimer)}, (frames, seconds, frames/s) of the whole job)."""
+    import time
+
+    from dvmvs.sharding import reduce_throughput, run_sharded
+    if len(scene_folders) != len(keyframe_index_files):
+        raise ValueError("one keyframe index file per scene folder")
+    state = {"engine": None}
+
+    def run_scene(s):
+        if state["engine"] is None:
+            state["engine"] = make_engine()
+        return predict_offline(state["engine"], scene_folders[s], keyframe_index_files[s], evaluate=evaluate, max_frames=max_frames)
+
+    t0 = time.perf_counter()
+    results = run_sharded(len(scene_folders), run_scene, rank=rank, world=world)
+    seconds = time.perf_counter() - t0
+    frames = sum(len(r[0]) for r in results.values())
+    device = state["engine"].device if state["engine"] is not None and torch.distributed.is_initialized() and \
+        torch.distributed.get_backend() == "nccl" else "cpu"
+    return results, reduce_throughput(frames, seconds, device=device)

@@ -47,3 +47,65 @@ def test_ownership_is_a_partition():
             assert seen == list(range(n))
             sizes = [len(sharding.sequences_for_rank(n, r, world)) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
+
+
+class _StubEngine:
+    """Stands in for DepthEngine on the CPU: the sharded scene runner only needs the frame contract."""
+    cache_features = False
+
+    def __init__(self, rank):
+        self.device, self.rank, self._feature_cache, self.sequences, self.resets = torch.device("cpu"), rank, {}, 0, 0
+
+    def new_sequence(self):
+        self.sequences += 1
+
+    def reset(self):
+        self.resets += 1
+
+    def step(self, image, pose, measurement_images, measurement_poses, full_K, frame_id=None, measurement_ids=None):
+        assert tuple(image.shape) == (1, 3, 256, 320) and len(measurement_images) == len(measurement_poses) == 2
+        return torch.full((1, 256, 320), 1.0 + self.rank + 0.01 * frame_id)
+
+
+def _scene_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    sys.path.insert(0, os.path.join(root, "deep-video-mvs_amd"))
+    from dvmvs import runner
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scenes = [os.path.join(out_dir, f"scene{i}") for i in range(3)]
+    indices = [os.path.join(out_dir, f"index{i}") for i in range(3)]
+    built = []
+
+    def make_engine():
+        built.append(_StubEngine(rank))
+        return built[-1]
+
+    results, (frames, seconds, fps) = runner.predict_sharded(make_engine, scenes, indices, evaluate=False)
+    summary = {s: [float(p.mean()) for p in r[0]] for s, r in results.items()}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (summary, len(built), built[0].sequences if built else 0, built[0].resets if built else 0))
+    if rank == 0:
+        torch.save({"gathered": gathered, "frames": frames, "fps": fps}, os.path.join(out_dir, "scenes.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_scene_runner(tmp_path):
+    """BASELINE.json configs[3] on the CPU: three scene folders over two gloo ranks through runner.predict_sharded (real scene
+    folders, keyframe index files with a TRACKING LOST line, real pre-processing; a stub engine in place of the GPU one)."""
+    from test_runner import _write_scene
+    for i in range(3):
+        _write_scene(os.path.join(str(tmp_path), f"scene{i}"), 8)
+        with open(os.path.join(str(tmp_path), f"index{i}"), "w") as f:
+            f.write("00003.png 00002.png 00001.png\nTRACKING LOST\n00005.png 00003.png 00002.png\n" + ("00007.png 00005.png 00003.png\n" if i == 1 else ""))
+    world = 2
+    mp.spawn(_scene_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "scenes.pt"), weights_only=False)
+    (s0, built0, seq0, resets0), (s1, built1, seq1, resets1) = res["gathered"]
+    assert sorted(s0) == [0, 2] and sorted(s1) == [1]                       # scene s runs on rank s % 2, exactly once
+    assert built0 == 1 and built1 == 1 and seq0 == 2 and seq1 == 1         # one engine per rank, one new_sequence() per scene
+    assert resets0 == 2 and resets1 == 1                                  # the TRACKING LOST lines
+    assert [round(v, 2) for v in s0[0]] == [1.03, 1.05] and [round(v, 2) for v in s1[1]] == [2.03, 2.05, 2.07]
+    assert res["frames"] == 7.0 and res["fps"] > 0
