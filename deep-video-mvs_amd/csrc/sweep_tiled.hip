@@ -273,7 +273,7 @@ __device__ inline float gather_plane(const CostVolumeArgs& a, gcfloat_p meas, gc
 // weights (register pairs {nw, ne}, {sw, se}, either half broadcast through op_sel).  (Deeper software pipelining across
 // planes was measured: no gain -- the launch is bound by the workgroup's chain of staging round trips, not by LDS latency.)
 template <int QPR, int REC>
-__device__ inline void tap_plane(const char* tile_bytes, int row_bytes, int addr, float2v w_n, float2v w_s, const float2v* rv, float2v* acc) {
+__device__ inline void tap_plane(const char* tile_bytes, int row_bytes, int addr, float2v frac, const float2v* rv, float2v* acc) {
   const char* row0 = tile_bytes + addr;
   const char* row1 = row0 + row_bytes;
   float2v t_nw = {0.0f, 0.0f}, t_ne = {0.0f, 0.0f}, t_sw = {0.0f, 0.0f}, t_se = {0.0f, 0.0f};
@@ -288,6 +288,12 @@ __device__ inline void tap_plane(const char* tile_bytes, int row_bytes, int addr
     t_sw = fma2(rv[q * 2], sw.lo, t_sw); t_sw = fma2(rv[q * 2 + 1], sw.hi, t_sw);
     t_se = fma2(rv[q * 2], se.lo, t_se); t_se = fma2(rv[q * 2 + 1], se.hi, t_se);
   }
+  // ATen's weights (ix_se - ix)(iy_se - iy) ... from the stored fractions: (fx + 1) - ix == 1 - (ix - fx) bit for bit wherever
+  // the tap it multiplies is inside the image (ix - fx is exact for ix >= 0, and then so is its complement)
+  asm volatile("" : "+v"(frac));   // opaque: keeps the four products out of registers between passes (they are loop-invariant
+                                    // and would be hoisted right back into the 16 VGPRs this formulation saves)
+  const float2v xw = {1.0f - frac.x, frac.x};                 // {west, east}
+  const float2v w_n = xw * (1.0f - frac.y), w_s = xw * frac.y;   // {nw, ne}, {sw, se}
   float2v f = *acc;
   f = fma2(t_nw, __builtin_shufflevector(w_n, w_n, 0, 0), f);
   f = fma2(t_ne, __builtin_shufflevector(w_n, w_n, 1, 1), f);
@@ -311,8 +317,9 @@ __device__ inline unsigned int spill_pack(int m, int seg_lo, int seg_len) {
 }
 
 // ---- the kernel ----------------------------------------------------------------------------------------------------------
-template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, bool XCD_ = true>
+template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, bool XCD_ = true, bool PREFETCH_ = false>
 struct SweepConfig {
+  static constexpr bool PREFETCH = PREFETCH_;   // next pass's loads in flight during this pass's taps (measured: slower, see the kernel)
   static constexpr int TW = TW_, TH = TH_, DP = DP_, CCH = CCH_, CAP = CAP_, MINSEG = MINSEG_;
   static constexpr int WAVES = WAVES_;   // waves per SIMD the register allocation is held to
   static constexpr bool XCD = XCD_;      // XCD-aware workgroup numbering
@@ -438,29 +445,27 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
       if (box.state == 1) {
         const int P = box.pitch, RS = box.pitch * box.RH;
         const int row_bytes = P * REC * 4;
-        // ---- this thread's taps: byte address of the north-west record and the four weights (register pairs {nw, ne},
-        // {sw, se}: v_pk_fma_f32 broadcasts either half through op_sel), per plane of the run ----
+        // ---- this thread's taps: byte address of the north-west record and the fractional position (ix - floor, iy - floor),
+        // per plane of the run; the four bilinear weights are re-formed from the fractions in every channel pass (16 registers
+        // instead of 32: what keeps this kernel at 3 waves per SIMD without scratch traffic) ----
         int addr[DP];
-        float2v w_n[DP], w_s[DP];
+        float2v frac[DP];
 #pragma unroll
         for (int j = 0; j < DP; ++j) {
           addr[j] = 0;
-          w_n[j] = w_s[j] = float2v{0.0f, 0.0f};
+          frac[j] = float2v{0.0f, 0.0f};
           if (j >= seg_lo && j < seg_hi) {   // workgroup-uniform
             const float4v kd = ktd_m[j];
             float ix, iy;
             sweep_sample(ray, kd.x, kd.y, kd.z, sc, &ix, &iy);
             const float fx = floorf(ix), fy = floorf(iy);
-            const float ex = (fx + 1.0f) - ix, wx = ix - fx;   // ATen's order: (ix_se - ix), (ix - ix_nw)
-            const float ey = (fy + 1.0f) - iy, wy = iy - fy;
             int rx = static_cast<int>(fx) - box.x_lo, ry = static_cast<int>(fy) - box.y_lo;
             if (live) violated |= (static_cast<unsigned int>(rx) > static_cast<unsigned int>(box.RW - 2)) |
                                   (static_cast<unsigned int>(ry) > static_cast<unsigned int>(box.RH - 2));
             rx = min(max(rx, 0), box.RW - 2);
             ry = min(max(ry, 0), box.RH - 2);
             addr[j] = __mul24(__mul24(ry, P) + rx, REC * 4);   // full-rate 24-bit multiplies: ry, P, rx < 2^11
-            w_n[j] = float2v{ex * ey, wx * ey};
-            w_s[j] = float2v{ex * wy, wx * wy};
+            frac[j] = float2v{ix - fx, iy - fy};
           }
         }
         // ---- staging plan: byte offset into the measurement map of each of this thread's LDS pieces ----
@@ -483,59 +488,89 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
         }
         const __amdgpu_buffer_rsrc_t meas_rsrc = map_resource(meas, map_bytes);
 
-        for (int c0 = 0; c0 < a.C; c0 += CCH) {
-          // reference features of this pass first: their latency overlaps the copy.  Channels beyond C (last pass of a
-          // ragged channel count) re-read channel C-1 on both sides and are cancelled by rv = 0.
-          float2v rv[CCH / 2];
+        // ---- channel passes.  All workgroups of a frame are resident at once, so the launch lasts about as long as one
+        // workgroup's dependency chain, and the global-load round trip of every pass sits on it (load -> wait -> ds_write ->
+        // barrier -> taps -> barrier).  PREFETCH (a tuning option, off) requests the first kPre pieces of the NEXT pass and its
+        // reference features before the taps of the current pass and holds them in registers until the buffer is free.
+        // Measured on MI355X: 39.6 us against 36.0 us without (sideways pair), 57 against 52 (index line 117): the 16-24
+        // extra live registers push the kernel past 168 VGPRs (scratch traffic), which costs more than the overlap gains.
+        constexpr int kPre = Cfg::PREFETCH ? (NHWC ? (kPieces < 4 ? kPieces : 4) : (kPieces < 2 ? kPieces : 2)) : 0;
+        constexpr int kPreRegs = NHWC ? 1 : QPR;   // float4 per piece
+        float4v pre[kPre > 0 ? kPre * kPreRegs : 1];
+        float2v rv_next[CCH / 2];
+        auto load_ref = [&](int c0, float2v* rv) {
+          // channels beyond C (last pass of a ragged channel count) re-read channel C-1 on both sides and are cancelled by rv = 0
 #pragma unroll
           for (int c = 0; c < CCH; ++c) {
             const float v = buffer_f32(ref_rsrc, ref_voffset, static_cast<unsigned int>(min(c0 + c, a.C - 1)) * plane_bytes);
             rv[c / 2][c % 2] = (c0 + c < a.C) ? v : 0.0f;
           }
+        };
+        auto load_piece = [&](int k, int c0, float4v* v) {   // piece k of pass c0 into kPreRegs float4
           if (NHWC) {
-            const bool ragged = c0 + CCH > a.C;   // workgroup-uniform
-            constexpr int kBatch = 4;             // 16-byte loads in flight per thread before their ds_write_b128s
-#pragma unroll
-            for (int k0 = 0; k0 < kPieces; k0 += kBatch) {
-              if (k0 * NT < n_pieces) {   // workgroup-uniform
-                float4v v[kBatch];
-#pragma unroll
-                for (int kk = 0; kk < kBatch; ++kk) {
-                  const int k = k0 + kk < kPieces ? k0 + kk : kPieces - 1;
-                  const int piece = tid + k * NT;
-                  unsigned int vo = goff[k];
-                  if (ragged && c0 + (piece % QPR) * 4 >= a.C) vo = kBufferOutOfRange;
-                  v[kk] = buffer_f32x4(meas_rsrc, vo, static_cast<unsigned int>(c0) * 4u);
-                }
-#pragma unroll
-                for (int kk = 0; kk < kBatch; ++kk) {
-                  const int piece = tid + (k0 + kk) * NT;
-                  if (k0 + kk < kPieces && piece < n_pieces)
-                    *reinterpret_cast<float4v*>(s_tile + (piece / QPR) * REC + (piece % QPR) * 4) = v[kk];
-                }
-              }
-            }
+            const int piece = tid + k * NT;
+            unsigned int vo = goff[k];
+            if (c0 + CCH > a.C && c0 + (piece % QPR) * 4 >= a.C) vo = kBufferOutOfRange;
+            v[0] = buffer_f32x4(meas_rsrc, vo, static_cast<unsigned int>(c0) * 4u);
           } else {
 #pragma unroll
-            for (int k = 0; k < kPieces; ++k) {
-              if (k * NT < n_pieces) {   // workgroup-uniform
-                const int r = tid + k * NT;
-                float4v v[QPR];
+            for (int c = 0; c < CCH; ++c)
+              v[c / 4][c % 4] = buffer_f32(meas_rsrc, goff[k], static_cast<unsigned int>(min(c0 + c, a.C - 1)) * plane_bytes);
+          }
+        };
+        auto store_piece = [&](int k, const float4v* v) {
+          const int piece = tid + k * NT;
+          if (piece < n_pieces) {
+            if (NHWC) {
+              *reinterpret_cast<float4v*>(s_tile + (piece / QPR) * REC + (piece % QPR) * 4) = v[0];
+            } else {
 #pragma unroll
-                for (int c = 0; c < CCH; ++c)
-                  v[c / 4][c % 4] = buffer_f32(meas_rsrc, goff[k], static_cast<unsigned int>(min(c0 + c, a.C - 1)) * plane_bytes);
-                if (r < RS) {
-#pragma unroll
-                  for (int q = 0; q < QPR; ++q) *reinterpret_cast<float4v*>(s_tile + r * REC + q * 4) = v[q];
-                }
-              }
+              for (int q = 0; q < QPR; ++q) *reinterpret_cast<float4v*>(s_tile + piece * REC + q * 4) = v[q];
             }
           }
+        };
+        if (kPre > 0) {
+          load_ref(0, rv_next);
+#pragma unroll
+          for (int k = 0; k < kPre; ++k)
+            if (k * NT < n_pieces) load_piece(k, 0, pre + k * kPreRegs);   // workgroup-uniform
+        }
+        for (int c0 = 0; c0 < a.C; c0 += CCH) {
+          float2v rv[CCH / 2];
+          if (kPre > 0) {
+#pragma unroll
+            for (int c = 0; c < CCH / 2; ++c) rv[c] = rv_next[c];
+          } else {
+            load_ref(c0, rv);   // first, so that its latency overlaps the copy
+          }
+          // pieces that were not prefetched: load now, a few in flight at a time
+          constexpr int kBatch = NHWC ? 4 : 1;
+#pragma unroll
+          for (int k0 = kPre; k0 < kPieces; k0 += kBatch) {
+            if (k0 * NT < n_pieces) {   // workgroup-uniform
+              float4v v[kBatch * kPreRegs];
+#pragma unroll
+              for (int kk = 0; kk < kBatch; ++kk)
+                load_piece(k0 + kk < kPieces ? k0 + kk : kPieces - 1, c0, v + kk * kPreRegs);
+#pragma unroll
+              for (int kk = 0; kk < kBatch; ++kk)
+                if (k0 + kk < kPieces) store_piece(k0 + kk, v + kk * kPreRegs);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < kPre; ++k)
+            if (k * NT < n_pieces) store_piece(k, pre + k * kPreRegs);
           __syncthreads();
+          if (kPre > 0 && c0 + CCH < a.C) {   // the next pass's requests go out before the taps of this one
+            load_ref(c0 + CCH, rv_next);
+#pragma unroll
+            for (int k = 0; k < kPre; ++k)
+              if (k * NT < n_pieces) load_piece(k, c0 + CCH, pre + k * kPreRegs);
+          }
 #pragma unroll
           for (int j = 0; j < DP; ++j)
             if (j >= seg_lo && j < seg_hi)   // workgroup-uniform
-              tap_plane<QPR, REC>(tile_bytes, row_bytes, addr[j], w_n[j], w_s[j], rv, &acc2[j]);
+              tap_plane<QPR, REC>(tile_bytes, row_bytes, addr[j], frac[j], rv, &acc2[j]);
           __syncthreads();
         }
       } else if (box.state == 0 && !GATHER) {
@@ -740,7 +775,7 @@ int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream) 
   b.spill = nullptr;
   switch (which) {
     case 0: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true>>(a, stream);    // 48 KB: 3 workgroups / CU
-    case 1: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, false>>(a, stream);   // ... plain workgroup numbering
+    case 1: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, true>>(a, stream);    // ... with register prefetch
     case 2: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 4, 3, true>>(a, stream);    // runs of >= 4 planes, else spill
     case 3: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 1, 3, true>>(a, stream);
     case 4: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1280, 2, 2, true>>(a, stream);    // 60 KB: 2 / CU
