@@ -148,7 +148,8 @@ def test_runners_match_the_cpu_pipeline_and_the_keyframe_simulation(hip_device, 
     online, _, _ = predict_online(engine, folder, evaluate=False, frame_log=online_log)
     expected = simulate_keyframe_index(scene.poses, scene.image_names, Config.test_n_measurement_frames)
     assert online_log == expected and len(online) == sum(l != "TRACKING LOST" for l in expected)
-    # the first online keyframes are the first offline lines: same inputs, same engine -> the same depth, up to the engine's
-    # execution mode (a frame kind runs eagerly the first time and as a replayed hipGraph afterwards; the modes agree to 1e-4)
-    for a, b in zip(online[:2], preds[:2]):
-        assert float(np.mean(np.abs(a - b) / b)) <= 1e-4
+    # the first online keyframe is the first offline line: same inputs, same engine -> the same depth, up to the engine's
+    # execution mode (a frame kind runs eagerly the first time and as a replayed hipGraph afterwards, and MIOpen may pick
+    # another algorithm: the modes agree to 1e-4).  Later frames additionally depend on the discrete depth-estimate decision
+    # discussed above, so only the first one is compared.
+    assert float(np.mean(np.abs(online[0] - preds[0]) / preds[0])) <= 1e-4
