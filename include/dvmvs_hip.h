@@ -172,6 +172,21 @@ int dvmvs_upsample2x_fwd(const float* in, float* out, int B, int C, int H, int W
 int dvmvs_depthwise_conv_fwd(const float* in, const float* weight, const float* bias, float* out, int B, int C, int H, int W,
                              int kernel_size, int stride, int activation, dvmvs_stream_t stream);
 
+/*
+ * TSDF fusion of one RGB-D frame into a voxel volume, in place.  Replaces the `integrate` CUDA kernel the reference's
+ * reconstruction script compiles with pycuda (/root/reference/sample-data/run-tsdf-reconstruction.py:79-152) and the
+ * per-"gpu loop" launches around it (:240-268): one launch covers the whole volume.
+ *   tsdf_vol, weight_vol, color_vol [dim_x,dim_y,dim_z]   (z fastest; colour folded as b * 65536 + g * 256 + r)
+ *   origin_*, voxel_size    world position of voxel (0,0,0) and the voxel edge, metres
+ *   cam_intr [3,3], cam_pose [4,4] camera-to-world        (device pointers)
+ *   color_im, depth_im [im_h,im_w]   folded colour and depth in metres (0 = invalid)
+ *   trunc_margin            truncation distance (the reference uses 5 voxels);  obs_weight  weight of this observation
+ */
+int dvmvs_tsdf_integrate(float* tsdf_vol, float* weight_vol, float* color_vol, int dim_x, int dim_y, int dim_z,
+                         float origin_x, float origin_y, float origin_z, float voxel_size, const float* cam_intr,
+                         const float* cam_pose, const float* color_im, const float* depth_im, int im_h, int im_w,
+                         float trunc_margin, float obs_weight, dvmvs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

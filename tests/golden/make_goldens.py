@@ -369,7 +369,42 @@ def loss_goldens(ref):
     save("losses", **out)
 
 
+def tsdf_goldens():
+    """The reference's TSDFVolume CPU fall-back (sample-data/run-tsdf-reconstruction.py:222-302) on two deterministic frames:
+    the script is loaded where it lies with stand-ins for its absent imports (numba.njit -> identity, prange -> range,
+    skimage / cv2 / path / pycuda missing -> CPU mode)."""
+    import importlib.util
+    import types
+    numba = types.ModuleType("numba")
+    numba.njit = lambda *a, **k: (a[0] if a and callable(a[0]) else (lambda f: f))
+    numba.prange = range
+    sys.modules["numba"] = numba
+    sk = types.ModuleType("skimage")
+    sk.measure = types.ModuleType("skimage.measure")
+    sys.modules.update({"skimage": sk, "skimage.measure": sk.measure})
+    for name in ("gc",):
+        __import__(name)
+    spec = importlib.util.spec_from_file_location("ref_tsdf", "/root/reference/sample-data/run-tsdf-reconstruction.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.FUSION_GPU_MODE == 0
+    frames, bounds, voxel = syn.tsdf_inputs()
+    vol = mod.TSDFVolume(bounds.copy(), voxel, use_gpu=False)
+    out = {}
+    for n, (color, depth, K, pose) in enumerate(frames):
+        vol.integrate(color, depth, K, pose, obs_weight=1.0 + n)
+        tsdf, col = vol.get_volume()
+        out[f"tsdf{n}"], out[f"color{n}"], out[f"weight{n}"] = tsdf.copy(), col.copy(), vol._weight_vol_cpu.copy()
+    out["vol_dim"], out["vol_origin"] = vol._vol_dim, vol._vol_origin
+    out["frustum"] = mod.TSDFFusion.get_view_frustum(frames[0][1], frames[0][2], frames[0][3])
+    save("tsdf", **out)
+
+
 def main():
+    if "--only-tsdf" in sys.argv:
+        import_reference()     # installs the cv2 / path stand-ins the script's own imports need
+        tsdf_goldens()
+        return
     ref = import_reference()
     if "--only-errors" in sys.argv:      # adds one fixture without rewriting the others
         error_metric_goldens(ref)
@@ -384,6 +419,7 @@ def main():
     keyframe_goldens(ref)
     error_metric_goldens(ref)
     loss_goldens(ref)
+    tsdf_goldens()
     REPORT["_meta"] = {"torch": torch.__version__, "reference": "ardaduz/deep-video-mvs @ /root/reference", "device": "cpu",
                        "note": "differences are |oracle - reference| on identical inputs, float32"}
     with open(os.path.join(HERE, "PINNING_REPORT.json"), "w") as f:

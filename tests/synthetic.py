@@ -258,3 +258,20 @@ def loss_inputs():
         p = 1.5 + 0.8 * torch.sin(xx / 7.0 + b + 0.05 * s) + 0.5 * torch.cos(yy / 5.0) + 0.3 * torch.sin(xx * yy / 90.0) * s
         preds.append(p.clamp(min=0.3).float())
     return gt, preds
+
+
+def tsdf_inputs():
+    """Deterministic two-frame RGB-D input for the TSDF goldens: a tilted wall at 0.9-1.3 m with an invalid (zero depth)
+    corner, 64 x 48 images, poses = two keyframes of the sample scene moved to the origin, volume 20 x 16 x 24 voxels of 4 cm."""
+    H, W = 48, 64
+    K = np.array([[61.3, 0.0, 31.37], [0.0, 59.1, 23.61], [0.0, 0.0, 1.0]])   # (irrational-ish: no systematic projection ties)
+    y, x = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    frames = []
+    base = np.linalg.inv(sample_poses()[9])
+    for n, idx in enumerate((9, 12)):
+        depth = (0.9 + 0.006 * x + 0.003 * y + 0.05 * n).astype(np.float32)
+        depth[:6, :8] = 0.0
+        color = np.stack([(40 + 3 * x + n * 17) % 256, (200 - 2 * y + n * 5) % 256, (x + 2 * y + 90) % 256], axis=-1).astype(np.uint8)
+        frames.append((color, depth, K.copy(), (base @ sample_poses()[idx])))
+    bounds = np.array([[-0.42, 0.38], [-0.34, 0.30], [0.62, 1.58]])
+    return frames, bounds, 0.04
