@@ -400,7 +400,37 @@ def tsdf_goldens():
     save("tsdf", **out)
 
 
+def crawler_goldens(ref):
+    """The reference's training-sample crawler (dataset_loader.py:112-219) on the sample scene's 373 poses and on a synthetic
+    trajectory: which frame indices form each sample, for sub-sequence lengths 2 (pairs), 3 and 8."""
+    import json
+    import pathlib
+    import types
+    import tempfile
+    dl = ref.dataset_loader
+    dl.Path = pathlib.Path           # the 'path' package is absent; pathlib joins the same way
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        scenes = {"sample": syn.sample_poses(), "synthetic": syn.synthetic_trajectory(240, seed=77)}
+        for scene, poses in scenes.items():
+            os.makedirs(os.path.join(tmp, scene))
+            np.savetxt(os.path.join(tmp, scene, "poses.txt"), np.reshape(poses, (-1, 16)))
+            progress = types.SimpleNamespace(value=0)
+            out[f"{scene}_pairs"] = [s["indices"] for s in dl.crawl_subprocess_short(scene, tmp, 1, progress)]
+            for length in (3, 8):
+                out[f"{scene}_len{length}"] = [s["indices"] for s in dl.crawl_subprocess_long(scene, tmp, 1, progress, length)]
+            measures = [dl.is_valid_pair(poses[0], poses[j], 0.125, 0.325, return_measure=True) for j in (1, 5, 20)]
+            out[f"{scene}_is_valid_pair"] = [[bool(v), float(m)] for v, m in measures]
+    for k, v in out.items():
+        print(k, len(v))
+    with open(os.path.join(HERE, "crawler.json"), "w") as f:
+        json.dump(out, f)
+
+
 def main():
+    if "--only-crawler" in sys.argv:
+        crawler_goldens(import_reference())
+        return
     if "--only-tsdf" in sys.argv:
         import_reference()     # installs the cv2 / path stand-ins the script's own imports need
         tsdf_goldens()
@@ -420,6 +450,7 @@ def main():
     error_metric_goldens(ref)
     loss_goldens(ref)
     tsdf_goldens()
+    crawler_goldens(ref)
     REPORT["_meta"] = {"torch": torch.__version__, "reference": "ardaduz/deep-video-mvs @ /root/reference", "device": "cpu",
                        "note": "differences are |oracle - reference| on identical inputs, float32"}
     with open(os.path.join(HERE, "PINNING_REPORT.json"), "w") as f:

@@ -103,6 +103,7 @@ def import_reference():
     ns.keyframe_buffer = importlib.import_module("dvmvs.keyframe_buffer")
     ns.errors = importlib.import_module("dvmvs.errors")
     ns.losses = importlib.import_module("dvmvs.losses")
+    ns.dataset_loader = importlib.import_module("dvmvs.dataset_loader")
     ns.oracle = oracle
     assert ns.utils.__file__.startswith(REFERENCE_ROOT)
     return ns
