@@ -100,17 +100,28 @@ __device__ inline SweepScale sweep_scale(int W, int H) {
   return s;
 }
 
-// un-clamped sample position (NaN / Inf when Z + 1e-8 == 0, as in the reference)
+// un-clamped sample position (NaN / Inf when Z + 1e-8 == 0, as in the reference).  x and y go through the same operations, so
+// they ride in the two halves of packed instructions (v_pk_add / v_pk_mul / v_pk_fma_f32: one issue slot for both): 20 VALU
+// instructions per sample instead of 35, with the scalar version's rounding.
 __device__ inline void sweep_position_exact(const SweepRay& r, float kx, float ky, float kz, const SweepScale& s, float* ix, float* iy,
                                             float* denom_out = nullptr) {
-  const float X = r.X0 + kx, Y = r.Y0 + ky, Z = r.Z0 + kz;
+  const float Z = r.Z0 + kz;
   const float denom = Z + 1e-8f;
   const float rcp = refined_rcp(denom);
   if (denom_out) *denom_out = denom;
-  const float u = exact_div(X, denom, rcp), v = exact_div(Y, denom, rcp);
-  const float gx = exact_div(u - s.wn, s.wn, s.r_wn), gy = exact_div(v - s.hn, s.hn, s.r_hn);
-  *ix = ((gx + 1.0f) * 0.5f) * s.Wm1;
-  *iy = ((gy + 1.0f) * 0.5f) * s.Hm1;
+  const float2v n = float2v{r.X0, r.Y0} + float2v{kx, ky};          // X, Y
+  const float2v d = {denom, denom}, rd = {rcp, rcp};
+  float2v q = n * rd;                                                // exact_div(X, denom), exact_div(Y, denom)
+  q = fma2(fma2(-d, q, n), rd, q);
+  q = fma2(fma2(-d, q, n), rd, q);
+  const float2v half = {s.wn, s.hn}, rhalf = {s.r_wn, s.r_hn};
+  const float2v t = q - half;
+  float2v g = t * rhalf;                                             // exact_div(u - W/2, W/2), exact_div(v - H/2, H/2)
+  g = fma2(fma2(-half, g, t), rhalf, g);
+  g = fma2(fma2(-half, g, t), rhalf, g);
+  const float2v pos = ((g + 1.0f) * 0.5f) * float2v{s.Wm1, s.Hm1};
+  *ix = pos.x;
+  *iy = pos.y;
 }
 #pragma clang fp contract(fast)
 
@@ -158,15 +169,24 @@ __device__ inline int sweep_pitch_residue(float ax, float ay) {
   return ((ax < 0.0f) != (ay < 0.0f)) ? 15 : 1;
 }
 
-// Every lane evaluates corner (lane & 7) -- bit 0: right edge, bit 1: bottom edge, bit 2: last plane of the run -- so that
-// three xor-shuffles leave the extrema in all lanes; readfirstlane then moves them to SGPRs.  All waves of a workgroup
-// execute this on identical inputs and therefore agree.
-template <int TW, int TH, int CAP>
+// Every lane evaluates corner (lane & 7) -- bit 0: right edge, bit 1: bottom edge, bit 2: last plane of the run -- of
+// candidate run length number (lane >> 3): len0, then halved (rounding up, not below MINSEG) once per candidate.  Three
+// xor-shuffles leave each candidate's extrema in its eight lanes, every lane derives its candidate's box, and the longest
+// run that can be staged (or is entirely outside the image) is picked with one ballot and read into SGPRs -- one evaluation
+// where a retry loop took up to three (1.3 us each in the s_memtime timeline of wide-baseline workgroups).  All waves of a
+// workgroup execute this on identical inputs and therefore agree.  *len_out = planes in the chosen run.
+template <int TW, int TH, int CAP, int MINSEG>
 __device__ inline SampleBox wave_sample_box(const CostVolumeArgs& a, const float* Hm, const float4v* ktd_m, int tile_x, int tile_y,
-                                            int j_lo, int j_hi, const SweepScale& sc, int lane) {
+                                            int j_lo, int len0, const SweepScale& sc, int lane, int* len_out) {
+  int len = len0;
+  const int candidate = lane >> 3;
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+    if (i < candidate) len = max((len + 1) >> 1, MINSEG);
+  len = min(len, len0);   // (len0 itself may be below MINSEG at the end of a chunk)
   const int cx = (lane & 1) ? min(tile_x * TW + TW - 1, a.W - 1) : tile_x * TW;
   const int cy = (lane & 2) ? min(tile_y * TH + TH - 1, a.H - 1) : tile_y * TH;
-  const float4v k = ktd_m[(lane & 4) ? j_hi : j_lo];
+  const float4v k = ktd_m[(lane & 4) ? j_lo + len - 1 : j_lo];
   const SweepRay ray = sweep_ray(Hm, static_cast<float>(cx), static_cast<float>(cy));
   // un-clamped position (the box test has to see how far outside the image the corner is)
   float ux, uy, denom;
@@ -184,39 +204,39 @@ __device__ inline SampleBox wave_sample_box(const CostVolumeArgs& a, const float
   }
   // NaN-safe: v_min/v_max drop NaNs, so test the corner values themselves as well
   const bool corner_ok = (ux > -1e6f) && (ux < 1e6f) && (uy > -1e6f) && (uy < 1e6f) && (denom > 1e-6f);
-  const bool finite = __all(corner_ok);
+  const bool finite = ((__ballot(corner_ok) >> (lane & 56)) & 0xffull) == 0xffull;   // all eight corners of this candidate
+  const float Wf = sc.Wf, Hf = sc.Hf;
+  // 0.05 px of slack for round-off between the corner samples and interior pixels
+  const bool outside = (hi_x + 0.05f <= -1.0f) || (lo_x - 0.05f >= Wf) || (hi_y + 0.05f <= -1.0f) || (lo_y - 0.05f >= Hf);
+  const int x_lo = max(-1, static_cast<int>(floorf(fmaxf(lo_x - 0.05f, -1.0f))));
+  const int y_lo = max(-1, static_cast<int>(floorf(fmaxf(lo_y - 0.05f, -1.0f))));
+  const int x_hi = min(a.W, static_cast<int>(floorf(fminf(hi_x + 0.05f, Wf)))) + 1;
+  const int y_hi = min(a.H, static_cast<int>(floorf(fminf(hi_y + 0.05f, Hf)))) + 1;
+  const int RW = x_hi - x_lo + 1, RH = y_hi - y_lo + 1;
+  const int residue = __builtin_amdgcn_readfirstlane(sweep_pitch_residue(step_x, step_y));
+  const int pitch = RW + ((residue - RW) & 15);
+  const int state = !finite ? 0 : outside ? 2 : (pitch * RH <= CAP) ? 1 : 0;
+  // the first candidate that needs no further halving: stageable, outside, or already at the minimum run length
+  const unsigned long long settled = __ballot(state != 0 || len <= MINSEG);
+  const int pick = __builtin_amdgcn_readfirstlane(static_cast<int>(__builtin_ctzll(settled | (1ull << 63))));
   SampleBox box;
-  box.x_lo = box.y_lo = box.RW = box.RH = box.pitch = 0;
-  box.state = 0;
-  if (finite) {
-    const float Wf = sc.Wf, Hf = sc.Hf;
-    // 0.05 px of slack for round-off between the corner samples and interior pixels
-    const bool outside = (hi_x + 0.05f <= -1.0f) || (lo_x - 0.05f >= Wf) || (hi_y + 0.05f <= -1.0f) || (lo_y - 0.05f >= Hf);
-    if (outside) {
-      box.state = 2;
-    } else {
-      const int x_lo = max(-1, static_cast<int>(floorf(fmaxf(lo_x - 0.05f, -1.0f))));
-      const int y_lo = max(-1, static_cast<int>(floorf(fmaxf(lo_y - 0.05f, -1.0f))));
-      const int x_hi = min(a.W, static_cast<int>(floorf(fminf(hi_x + 0.05f, Wf)))) + 1;
-      const int y_hi = min(a.H, static_cast<int>(floorf(fminf(hi_y + 0.05f, Hf)))) + 1;
-      box.x_lo = __builtin_amdgcn_readfirstlane(x_lo);
-      box.y_lo = __builtin_amdgcn_readfirstlane(y_lo);
-      box.RW = __builtin_amdgcn_readfirstlane(x_hi - x_lo + 1);
-      box.RH = __builtin_amdgcn_readfirstlane(y_hi - y_lo + 1);
-      const int residue = __builtin_amdgcn_readfirstlane(sweep_pitch_residue(step_x, step_y));
-      box.pitch = box.RW + ((residue - box.RW) & 15);
-      box.state = (box.pitch * box.RH <= CAP) ? 1 : 0;
-    }
-  }
-  box.state = __builtin_amdgcn_readfirstlane(box.state);
+  box.state = __builtin_amdgcn_readlane(state, pick);
+  const bool staged = box.state == 1;
+  box.x_lo = staged ? __builtin_amdgcn_readlane(x_lo, pick) : 0;
+  box.y_lo = staged ? __builtin_amdgcn_readlane(y_lo, pick) : 0;
+  box.RW = staged ? __builtin_amdgcn_readlane(RW, pick) : 0;
+  box.RH = staged ? __builtin_amdgcn_readlane(RH, pick) : 0;
+  box.pitch = staged ? __builtin_amdgcn_readlane(pitch, pick) : 0;
+  *len_out = __builtin_amdgcn_readlane(len, pick);
   return box;
 }
 
 // ---- gather path (no staging): taps straight from global memory ----------------------------------------------------------
 // One plane of one measurement frame for this thread's pixel: sum_c ref[c] * warped[c].  Used for runs of planes whose
 // footprint cannot be staged: by sweep_spill_kernel (second pass) and, when the caller gave no spill workspace, inline.
-// Eight channels x four taps = 32 independent loads are in flight before the first use.
-template <bool NHWC>
+// KCH channels x four taps independent loads are in flight before the first use (KCH = 32, all 128 loads of a plane, was
+// measured in the second pass: no faster than 8).
+template <bool NHWC, int KCH = 8>
 __device__ inline float gather_plane(const CostVolumeArgs& a, gcfloat_p meas, gcfloat_p ref, int HW, const SweepRay& ray,
                                      float kx, float ky, float kz, const SweepScale& sc) {
   float ix, iy;
@@ -232,7 +252,7 @@ __device__ inline float gather_plane(const CostVolumeArgs& a, gcfloat_p meas, gc
   // under strong magnification most pixels sample outside the image: a wave whose 64 pixels are all dead for this plane
   // skips its channel loop (wave-uniform branch)
   if (!__any((wgt[0] + wgt[1] + wgt[2] + wgt[3]) != 0.0f)) return 0.0f;
-  constexpr int kChan = 8;
+  constexpr int kChan = KCH;
   for (int c0 = 0; c0 < a.C; c0 += kChan) {
     float r[kChan], v[kChan][4];
     if (NHWC) {
@@ -272,6 +292,14 @@ __device__ inline float gather_plane(const CostVolumeArgs& a, gcfloat_p meas, gc
 // 4 taps x QPR 16-byte reads; "dot per tap" over the pass's channels, two channels per v_pk_fma_f32; then the four bilinear
 // weights (register pairs {nw, ne}, {sw, se}, either half broadcast through op_sel).  (Deeper software pipelining across
 // planes was measured: no gain -- the launch is bound by the workgroup's chain of staging round trips, not by LDS latency.)
+// ATen's bilinear weights (ix_se - ix)(iy_se - iy), ... from the fractional position: (fx + 1) - ix == 1 - (ix - fx) bit for bit
+// wherever the tap it multiplies is inside the image (ix - fx is exact for ix >= 0, and then so is its complement).
+__device__ inline void tap_weights(float frac_x, float frac_y, float2v* w_n, float2v* w_s) {
+  const float2v xw = {1.0f - frac_x, frac_x};   // {west, east}
+  *w_n = xw * (1.0f - frac_y);                  // {nw, ne}
+  *w_s = xw * frac_y;                           // {sw, se}
+}
+
 template <int QPR, int REC>
 __device__ inline void tap_plane(const char* tile_bytes, int row_bytes, int addr, float2v frac, const float2v* rv, float2v* acc) {
   const char* row0 = tile_bytes + addr;
@@ -288,14 +316,12 @@ __device__ inline void tap_plane(const char* tile_bytes, int row_bytes, int addr
     t_sw = fma2(rv[q * 2], sw.lo, t_sw); t_sw = fma2(rv[q * 2 + 1], sw.hi, t_sw);
     t_se = fma2(rv[q * 2], se.lo, t_se); t_se = fma2(rv[q * 2 + 1], se.hi, t_se);
   }
-  // ATen's weights (ix_se - ix)(iy_se - iy) ... from the stored fractions: (fx + 1) - ix == 1 - (ix - fx) bit for bit wherever
-  // the tap it multiplies is inside the image (ix - fx is exact for ix >= 0, and then so is its complement)
   asm volatile("" : "+v"(frac));   // opaque: keeps the four products out of registers between passes (they are loop-invariant
                                     // and would be hoisted right back into the 16 VGPRs this formulation saves)
-  const float2v xw = {1.0f - frac.x, frac.x};                 // {west, east}
-  const float2v w_n = xw * (1.0f - frac.y), w_s = xw * frac.y;   // {nw, ne}, {sw, se}
+  float2v w_n, w_s;
+  tap_weights(frac.x, frac.y, &w_n, &w_s);
   float2v f = *acc;
-  f = fma2(t_nw, __builtin_shufflevector(w_n, w_n, 0, 0), f);
+  f = fma2(t_nw, __builtin_shufflevector(w_n, w_n, 0, 0), f);   // either half broadcast through op_sel
   f = fma2(t_ne, __builtin_shufflevector(w_n, w_n, 1, 1), f);
   f = fma2(t_sw, __builtin_shufflevector(w_s, w_s, 0, 0), f);
   f = fma2(t_se, __builtin_shufflevector(w_s, w_s, 1, 1), f);
@@ -316,9 +342,20 @@ __device__ inline unsigned int spill_pack(int m, int seg_lo, int seg_len) {
   return (static_cast<unsigned int>(m) << 16) | (static_cast<unsigned int>(seg_lo) << 8) | static_cast<unsigned int>(seg_len);
 }
 
+// ---- optional timeline instrumentation (tools/sweep_trace.py; built only by `make trace`) -------------------------------------
+#ifdef DVMVS_SWEEP_TRACE
+constexpr int kTraceWords = 16, kTraceGroups = 8192;
+__device__ unsigned long long g_sweep_trace[kTraceGroups * kTraceWords];
+#define SWEEP_TRACE(...) __VA_ARGS__
+#else
+#define SWEEP_TRACE(...)
+#endif
+
 // ---- the kernel ----------------------------------------------------------------------------------------------------------
-template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, bool XCD_ = true, bool PREFETCH_ = false>
+template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, bool XCD_ = true, bool PREFETCH_ = false, int BATCH_ = 0, int STAGGER_ = 0>
 struct SweepConfig {
+  static constexpr int STAGGER = STAGGER_;   // start offset between the workgroups that share a CU, in units of 64 shader clocks
+  static constexpr int BATCH = BATCH_;   // staging pieces whose loads are in flight together (0: 1 for NCHW, 4 for NHWC)
   static constexpr bool PREFETCH = PREFETCH_;   // next pass's loads in flight during this pass's taps (measured: slower, see the kernel)
   static constexpr int TW = TW_, TH = TH_, DP = DP_, CCH = CCH_, CAP = CAP_, MINSEG = MINSEG_;
   static constexpr int WAVES = WAVES_;   // waves per SIMD the register allocation is held to
@@ -376,7 +413,18 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   const int d_block = work.chunk * DP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int planes = min(DP, a.D - d_block);
+  SWEEP_TRACE(unsigned long long tr_box = 0, tr_stage = 0, tr_taps = 0, tr_passes = 0, tr_records = 0, tr_box_a = 0, tr_box_b = 0, tr_loop_end = 0, tr_sync = 0;)
+  SWEEP_TRACE(const unsigned long long tr_start = __builtin_amdgcn_s_memtime(); const unsigned long long tr_real0 = __builtin_amdgcn_s_memrealtime();)
 
+  if (Cfg::STAGGER > 0) {
+    // Tuning option, off.  Workgroups that share a CU run their phases in lockstep (all on the VALU for positions, then all on
+    // the LDS for taps), so each pipe idles while the other is the bottleneck.  The dispatcher deals an XCD's workgroups round
+    // the XCD's 32 CUs: number k lands with k + 32 and k + 64 (confirmed with HW_ID in tools/sweep_trace.py).  Starting them one
+    // offset apart was measured: the launch gets longer by about the offset (37.3 -> 38.8 / 39.6 / 41.5 us for 2 / 4 / 6 us), the
+    // taps of a workgroup that has the LDS to itself are bound by its own LDS latency chain instead (1.6 us per pass either way).
+    const int rank = ((blockIdx.x >> 3) / 32) % 3;
+    for (int i = 0; i < rank * Cfg::STAGGER; i += 32) __builtin_amdgcn_s_sleep(32);
+  }
   // ---- per-workgroup tables: Hm = K R K^-1 and K t per measurement frame (fp64 on the first M lanes), K t / depth per plane ----
   if (tid < a.M) sweep_matrices(a.pose1 + b * 16, a.pose2[tid] + b * 16, a.K + b * 9, s_H + tid * 9, s_kt + tid * 3);
   __syncthreads();
@@ -393,6 +441,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   }
   __syncthreads();
 
+  SWEEP_TRACE(const unsigned long long tr_setup = __builtin_amdgcn_s_memtime();)
   const int HW = a.H * a.W;
   // lane -> pixel: each 16-lane ds_read_b128 service group owns 16 consecutive pixels of one tile row (see sweep_lane_pixel)
   const int lane_pixel = sweep_lane_pixel(tid & 31);
@@ -429,18 +478,31 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
     const float4v* ktd_m = s_ktd + m * DP;
     gcfloat_p meas = as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW;
     const SweepRay ray = sweep_ray(Hm, xf, yf);
+    // This thread's sample positions on the chunk's planes do not depend on the box: with NCHW maps they are computed once per
+    // frame and kept (16 registers) for workgroups that need several runs; the channels-last instantiation has no registers to
+    // spare and recomputes them per run.  Either way all DP planes are evaluated without branches, so that the DP chains of
+    // dependent operations (three exact divisions each) sit in one basic block.
+    constexpr bool kKeepPositions = !NHWC;
+    float2v pos[DP];
+    auto sample_positions = [&]() {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const float4v kd = ktd_m[j];   // zeros beyond the last plane of a ragged chunk
+        float ix, iy;
+        sweep_sample(ray, kd.x, kd.y, kd.z, sc, &ix, &iy);
+        pos[j] = float2v{ix, iy};
+      }
+    };
+    if (kKeepPositions) sample_positions();
     int seg_hint = DP;   // planes per segment that fitted last time: parallax per plane is uniform along the sweep
     int seg_lo = 0;
     while (seg_lo < planes) {
       int seg_len = min(planes - seg_lo, seg_hint);
-      SampleBox box;
-      for (;;) {
-        box = wave_sample_box<TW, TH, CAP>(a, Hm, ktd_m, tile_x, tile_y, seg_lo, seg_lo + seg_len - 1, sc, lane);
-        if (box.state != 0 || seg_len <= Cfg::MINSEG) break;
-        seg_len = max((seg_len + 1) / 2, Cfg::MINSEG);
-      }
+      SWEEP_TRACE(const unsigned long long tr_b0 = __builtin_amdgcn_s_memtime();)
+      const SampleBox box = wave_sample_box<TW, TH, CAP, Cfg::MINSEG>(a, Hm, ktd_m, tile_x, tile_y, seg_lo, seg_len, sc, lane, &seg_len);
       seg_hint = max(seg_len, Cfg::MINSEG);
       const int seg_hi = seg_lo + seg_len;
+      SWEEP_TRACE(const unsigned long long tr_b1 = __builtin_amdgcn_s_memtime(); tr_box_a += tr_b1 - tr_b0;)
 
       if (box.state == 1) {
         const int P = box.pitch, RS = box.pitch * box.RH;
@@ -450,28 +512,25 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
         // instead of 32: what keeps this kernel at 3 waves per SIMD without scratch traffic) ----
         int addr[DP];
         float2v frac[DP];
+        if (!kKeepPositions) sample_positions();
 #pragma unroll
-        for (int j = 0; j < DP; ++j) {
-          addr[j] = 0;
-          frac[j] = float2v{0.0f, 0.0f};
-          if (j >= seg_lo && j < seg_hi) {   // workgroup-uniform
-            const float4v kd = ktd_m[j];
-            float ix, iy;
-            sweep_sample(ray, kd.x, kd.y, kd.z, sc, &ix, &iy);
-            const float fx = floorf(ix), fy = floorf(iy);
-            int rx = static_cast<int>(fx) - box.x_lo, ry = static_cast<int>(fy) - box.y_lo;
-            if (live) violated |= (static_cast<unsigned int>(rx) > static_cast<unsigned int>(box.RW - 2)) |
-                                  (static_cast<unsigned int>(ry) > static_cast<unsigned int>(box.RH - 2));
-            rx = min(max(rx, 0), box.RW - 2);
-            ry = min(max(ry, 0), box.RH - 2);
-            addr[j] = __mul24(__mul24(ry, P) + rx, REC * 4);   // full-rate 24-bit multiplies: ry, P, rx < 2^11
-            frac[j] = float2v{ix - fx, iy - fy};
-          }
+        for (int j = 0; j < DP; ++j) {   // all planes (those outside the run get addresses that are never used)
+          const bool in_run = j >= seg_lo && j < seg_hi;   // workgroup-uniform
+          const float ix = pos[j].x, iy = pos[j].y;
+          const float fx = floorf(ix), fy = floorf(iy);
+          int rx = static_cast<int>(fx) - box.x_lo, ry = static_cast<int>(fy) - box.y_lo;
+          if (live && in_run) violated |= (static_cast<unsigned int>(rx) > static_cast<unsigned int>(box.RW - 2)) |
+                                          (static_cast<unsigned int>(ry) > static_cast<unsigned int>(box.RH - 2));
+          rx = min(max(rx, 0), box.RW - 2);
+          ry = min(max(ry, 0), box.RH - 2);
+          addr[j] = __mul24(__mul24(ry, P) + rx, REC * 4);   // full-rate 24-bit multiplies: ry, P, rx < 2^11
+          frac[j] = float2v{ix - fx, iy - fy};
         }
         // ---- staging plan: byte offset into the measurement map of each of this thread's LDS pieces ----
         // NHWC: a piece is one 16-byte channel quad of one box position; NCHW: a piece is one box position (CCH dword loads).
         // Positions outside the image (zero apron), pad columns and pieces past the box get kBufferOutOfRange: the load
         // then returns zeros by itself.
+        SWEEP_TRACE(asm volatile("" :: "v"(addr[0]), "v"(addr[DP - 1]), "v"(frac[DP - 1])); tr_box_b += __builtin_amdgcn_s_memtime() - tr_b1;)
         constexpr int kPieces = NHWC ? (CAP * QPR + NT - 1) / NT : (CAP + NT - 1) / NT;
         const unsigned int magic = 0xffffffffu / static_cast<unsigned int>(P) + 1u;   // r / P == mulhi(r, magic) for r < 2^16
         const int n_pieces = NHWC ? RS * QPR : RS;
@@ -487,6 +546,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
           goff[k] = in ? static_cast<unsigned int>(NHWC ? (gy * a.W + gx) * a.C + (piece % QPR) * 4 : gy * a.W + gx) * 4u : kBufferOutOfRange;
         }
         const __amdgpu_buffer_rsrc_t meas_rsrc = map_resource(meas, map_bytes);
+        SWEEP_TRACE(tr_box += __builtin_amdgcn_s_memtime() - tr_b0; tr_records += static_cast<unsigned long long>(RS);)
 
         // ---- channel passes.  All workgroups of a frame are resident at once, so the launch lasts about as long as one
         // workgroup's dependency chain, and the global-load round trip of every pass sits on it (load -> wait -> ds_write ->
@@ -536,6 +596,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
             if (k * NT < n_pieces) load_piece(k, 0, pre + k * kPreRegs);   // workgroup-uniform
         }
         for (int c0 = 0; c0 < a.C; c0 += CCH) {
+          SWEEP_TRACE(const unsigned long long tr_s0 = __builtin_amdgcn_s_memtime();)
           float2v rv[CCH / 2];
           if (kPre > 0) {
 #pragma unroll
@@ -544,7 +605,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
             load_ref(c0, rv);   // first, so that its latency overlaps the copy
           }
           // pieces that were not prefetched: load now, a few in flight at a time
-          constexpr int kBatch = NHWC ? 4 : 1;
+          constexpr int kBatch = Cfg::BATCH > 0 ? Cfg::BATCH : (NHWC ? 4 : 1);
 #pragma unroll
           for (int k0 = kPre; k0 < kPieces; k0 += kBatch) {
             if (k0 * NT < n_pieces) {   // workgroup-uniform
@@ -561,6 +622,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
           for (int k = 0; k < kPre; ++k)
             if (k * NT < n_pieces) store_piece(k, pre + k * kPreRegs);
           __syncthreads();
+          SWEEP_TRACE(const unsigned long long tr_s1 = __builtin_amdgcn_s_memtime(); tr_stage += tr_s1 - tr_s0;)
           if (kPre > 0 && c0 + CCH < a.C) {   // the next pass's requests go out before the taps of this one
             load_ref(c0 + CCH, rv_next);
 #pragma unroll
@@ -572,6 +634,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
             if (j >= seg_lo && j < seg_hi)   // workgroup-uniform
               tap_plane<QPR, REC>(tile_bytes, row_bytes, addr[j], frac[j], rv, &acc2[j]);
           __syncthreads();
+          SWEEP_TRACE(tr_taps += __builtin_amdgcn_s_memtime() - tr_s1; ++tr_passes;)
         }
       } else if (box.state == 0 && !GATHER) {
         // cannot be staged: queue the run for the second pass (this workgroup contributes nothing for it)
@@ -594,7 +657,10 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   // A tap outside its staged box can only come from round-off beyond the 0.05 px slack of the corner test.  It has never
   // been observed, but the result must not depend on it: the whole workgroup is redone through the gather path (second
   // pass, or inline when there is none).
-  if (__syncthreads_or(violated)) {
+  SWEEP_TRACE(tr_loop_end = __builtin_amdgcn_s_memtime();)
+  const int any_violated = __syncthreads_or(violated);
+  SWEEP_TRACE(tr_sync = __builtin_amdgcn_s_memtime();)
+  if (any_violated) {
 #pragma unroll
     for (int j = 0; j < DP; ++j) acc2[j] = float2v{0.0f, 0.0f};
     n_spilled = 0;
@@ -618,10 +684,30 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
 
   if (live) {
     gfloat_p out = as_global(a.out) + (static_cast<size_t>(b) * a.D + d_block) * HW + pix;
+    const float Cf = static_cast<float>(a.C), Mf = static_cast<float>(a.M);
+    if (((a.C & (a.C - 1)) | (a.M & (a.M - 1))) == 0) {
+      // both counts are powers of two (the usual 32 channels, 1 or 2 frames): x * 2^-k is x / 2^k, correctly rounded either
+      // way, without the 2 x 10 instructions of an IEEE division per output
+      const float rC = 1.0f / Cf, rM = 1.0f / Mf;
 #pragma unroll
-    for (int j = 0; j < DP; ++j)
-      if (j < planes) out[static_cast<size_t>(j) * HW] = ((acc2[j].x + acc2[j].y) / static_cast<float>(a.C)) / static_cast<float>(a.M);
+      for (int j = 0; j < DP; ++j)
+        if (j < planes) out[static_cast<size_t>(j) * HW] = ((acc2[j].x + acc2[j].y) * rC) * rM;
+    } else {
+#pragma unroll
+      for (int j = 0; j < DP; ++j)
+        if (j < planes) out[static_cast<size_t>(j) * HW] = ((acc2[j].x + acc2[j].y) / Cf) / Mf;
+    }
   }
+#ifdef DVMVS_SWEEP_TRACE
+  if (tid == 0 && work.group < kTraceGroups) {
+    unsigned long long* t = g_sweep_trace + static_cast<size_t>(work.group) * kTraceWords;
+    t[0] = tr_start; t[1] = tr_setup; t[2] = __builtin_amdgcn_s_memtime(); t[3] = tr_box; t[4] = tr_stage; t[5] = tr_taps;
+    t[6] = tr_passes; t[7] = tr_records; t[8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    t[9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                       // XCC_ID
+    t[10] = tr_real0; t[11] = __builtin_amdgcn_s_memrealtime(); t[12] = static_cast<unsigned long long>(n_spilled) | (static_cast<unsigned long long>(blockIdx.x) << 32);
+    t[13] = tr_box_a; t[14] = tr_box_b; t[15] = ((tr_loop_end - tr_start) << 32) | (tr_sync - tr_loop_end);
+  }
+#endif
   if (!GATHER && n_spilled > 0) {
     if (tid < a.M * 12) {
       const int m = tid / 12, k = tid - m * 12;
@@ -788,6 +874,8 @@ int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream) 
     case 11: return launch_sweep_tiled<SweepConfig<32, 8, 4, 8, 768, 2, 4, true>>(b, stream);    // 4 planes / workgroup
     case 12: return launch_sweep_tiled<SweepConfig<32, 8, 16, 8, 1536, 2, 2, true>>(b, stream);  // 16 planes, 72 KB
     // one wave per workgroup: no barriers, every wave stages its own 16x4-pixel footprint and free-runs
+    case 15: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, false, 2>>(a, stream);   // 2 staging pieces in flight (NCHW): no gain
+    case 16: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, false, 0, 64>>(a, stream);   // staggered starts (~2 us apart): slower
     case 13: return launch_sweep_tiled<SweepConfig<16, 4, 8, 8, 320, 2, 3, true>>(a, stream);    // 15 KB: 10 / CU
     case 14: return launch_sweep_tiled<SweepConfig<16, 4, 8, 8, 384, 2, 2, true>>(a, stream);    // 18 KB: 8 / CU
     default: return DVMVS_EINVAL;
@@ -795,3 +883,10 @@ int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream) 
 }
 
 }  // namespace dvmvs
+
+#ifdef DVMVS_SWEEP_TRACE
+extern "C" int dvmvs_debug_sweep_trace(unsigned long long* host, int groups) {
+  if (groups > dvmvs::kTraceGroups) groups = dvmvs::kTraceGroups;
+  return static_cast<int>(hipMemcpyFromSymbol(host, HIP_SYMBOL(dvmvs::g_sweep_trace), sizeof(unsigned long long) * dvmvs::kTraceWords * groups));
+}
+#endif

@@ -13,13 +13,15 @@ groups=(
  "FETCH_SIZE"
  "WRITE_SIZE"
 )
+# PMC_ONLY="3 4" restricts the run to those counter groups (indices into the list above), e.g. the two HBM-traffic passes
 i=0
 for g in "${groups[@]}"; do
-  (cd /tmp && rocprofv3 --pmc $g --kernel-include-regex "sweep_|cost_volume_tiled|cost_volume_spill" -d "$root/$out/pass$i" --output-format csv -- \
+  if [ -n "$PMC_ONLY" ] && ! [[ " $PMC_ONLY " == *" $i "* ]]; then i=$((i+1)); continue; fi
+  (cd /tmp && timeout 120 rocprofv3 --pmc $g --kernel-include-regex "sweep_|cost_volume_tiled|cost_volume_spill" -d "$root/$out/pass$i" --output-format csv -- \
      python "$root/tools/cv_microbench.py" "$@" > "$root/$out/pass$i.log" 2>&1)
   i=$((i+1))
 done
-(cd /tmp && rocprofv3 --kernel-trace --stats -d "$root/$out/trace" --output-format csv -- \
+(cd /tmp && timeout 120 rocprofv3 --kernel-trace --stats -d "$root/$out/trace" --output-format csv -- \
    python "$root/tools/cv_microbench.py" "$@" > "$root/$out/trace.log" 2>&1)
 cp "$out"/trace/*/*kernel_stats.csv "$out/kernel_stats.csv" 2>/dev/null
 python tools/pmc_summary.py "$out" > "$out/summary.txt" 2>&1

@@ -8,7 +8,7 @@ out="${1:-gpurun_out/prof_r02}"
 mkdir -p "$out"
 export TMPDIR=/tmp
 root="$(pwd)"
-(cd /tmp && rocprofv3 --kernel-trace --stats -d "$root/$out/bench_trace" --output-format csv -- \
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$root/$out/bench_trace" --output-format csv -- \
    python "$root/bench.py" --steps 200 --warmup 30 --mark-region --no-cpu-baseline --no-rel-l1 --sequences-per-gpu 0 \
    > "$root/$out/bench_under_rocprof.json" 2> "$root/$out/bench_under_rocprof.err")
 trace=$(ls "$out"/bench_trace/*/*kernel_trace.csv 2>/dev/null | head -1)
@@ -16,7 +16,9 @@ stats=$(ls "$out"/bench_trace/*/*kernel_stats.csv 2>/dev/null | head -1)
 [ -n "$trace" ] && python tools/summarize_trace.py "$trace" "$out/bench_timed_region.csv" 200 > "$out/bench_timed_region.txt" 2>&1
 [ -n "$stats" ] && cp "$stats" "$out/bench_kernel_stats_whole_run.csv"
 rm -rf "$out/bench_trace"
+# all counter groups on the easy line; the HBM-traffic passes (FETCH_SIZE, WRITE_SIZE) and the kernel trace on all three
 for line in 153 118 165; do
-  tools/pmc_sweep.sh "$out/pmc_line$line" --lines=$line --variants 2 --reps 2
+  if [ "$line" = 153 ]; then only=""; else only="3 4"; fi
+  PMC_ONLY="$only" tools/pmc_sweep.sh "$out/pmc_line$line" --lines=$line --variants 2 --reps 2
   rm -rf "$out/pmc_line$line"/pass*/ "$out/pmc_line$line"/trace
 done
