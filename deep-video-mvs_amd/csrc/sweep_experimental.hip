@@ -10,6 +10,10 @@
 
 namespace dvmvs {
 
+// timeline of the experiment (wall clock, 100 MHz): per workgroup and per published half
+__device__ unsigned long long g_adaptive_wg[8192 * 8];
+__device__ unsigned long long g_adaptive_half[8192 * 4];
+
 constexpr int kStealHeaderWords = 16;   // [0] published halves, [1] claim cursor, [2] error flag; then the list, then one flag per group
 
 template <class Cfg>
@@ -39,6 +43,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
   int task_group = work.group, p_lo = 0, p_hi = DP;
   bool own_upper_pending = false;   // this workgroup published the upper half of its unit and has not yet tried to claim it back
   int cur_b = -1;
+  const unsigned long long tx_start = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tx_first = 0, tx_publish = 0;
+  int tx_tasks = 0, tx_first_runs = 0, tx_published = 0;
   bool light = false;   // this workgroup's own unit was light: it may claim published halves
   for (;;) {
   const int b = task_group / per_b;
@@ -129,6 +136,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
         p_hi = DP / 2;
         seg_len = min(seg_len, p_hi);
         own_upper_pending = true;
+        tx_published = 1;
+        tx_publish = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
           const unsigned int at = atomicAdd(steal, 1u);
           atomicExch(steal_list + at, static_cast<unsigned int>(task_group) + 1u);
@@ -315,11 +324,17 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
     }
   }
   // ---- next task ----
+  ++tx_tasks;
+  if (tx_tasks == 1) { tx_first = __builtin_amdgcn_s_memrealtime(); tx_first_runs = staged_runs; }
+  if (tid == 0 && p_lo != 0 && task_group < 8192) g_adaptive_half[task_group * 4 + 2] = __builtin_amdgcn_s_memrealtime();
   __syncthreads();   // every thread is done with s_ktd and the tile before they are rebuilt
   if (task_group == work.group && p_lo == 0) light = staged_runs < a.M;   // judged on the workgroup's own unit, kept afterwards
   if (tid == 0) {
     int next = -1;
-    if (own_upper_pending && atomicExch(steal_flag + work.group, 1u) == 0u) next = work.group;   // nobody took it: do it here
+    if (own_upper_pending && atomicExch(steal_flag + work.group, 1u) == 0u) {   // nobody took it: do it here
+      next = work.group;
+      if (next < 8192) { g_adaptive_half[next * 4 + 0] = __builtin_amdgcn_s_memrealtime(); g_adaptive_half[next * 4 + 1] = 1; }
+    }
     if (next < 0 && light && !(claim_once && s_next[1])) {
       int stolen = 0;
       // claim upper halves other workgroups published, in publication order.  Only workgroups whose own task was light look
@@ -336,6 +351,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
         if (atomicExch(steal_flag + (entry - 1u), 1u) == 0u) {
           next = static_cast<int>(entry - 1u);
           stolen = 1;
+          if (next < 8192) { g_adaptive_half[next * 4 + 0] = __builtin_amdgcn_s_memrealtime(); g_adaptive_half[next * 4 + 1] = 2; }
           break;
         }
       }
@@ -346,7 +362,14 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
   own_upper_pending = false;
   __syncthreads();
   const int next = s_next[0];
-  if (next < 0) break;
+  if (next < 0) {
+    if (tid == 0 && work.group < 8192) {
+      unsigned long long* t = g_adaptive_wg + static_cast<size_t>(work.group) * 8;
+      t[0] = tx_start; t[1] = tx_first; t[2] = __builtin_amdgcn_s_memrealtime(); t[3] = static_cast<unsigned long long>(tx_tasks);
+      t[4] = static_cast<unsigned long long>(tx_first_runs); t[5] = tx_publish; t[6] = static_cast<unsigned long long>(tx_published) | (light ? 2ull : 0ull);
+    }
+    break;
+  }
   task_group = next;
   p_lo = DP / 2;
   p_hi = DP;
@@ -357,6 +380,11 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
 // bit 0: leave out the second pass; bit 1: launch the shipped first-pass kernel instead of the adaptive one (so that the two
 // first passes can be timed alone, side by side); bit 2: a workgroup claims at most one published half
 extern "C" int dvmvs_debug_mode = 0;
+extern "C" int dvmvs_debug_adaptive_trace(unsigned long long* wg, unsigned long long* half, int groups) {
+  if (groups > 8192) groups = 8192;
+  if (hipMemcpyFromSymbol(wg, HIP_SYMBOL(dvmvs::g_adaptive_wg), sizeof(unsigned long long) * 8 * groups) != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(half, HIP_SYMBOL(dvmvs::g_adaptive_half), sizeof(unsigned long long) * 4 * groups) == hipSuccess ? 0 : -1;
+}
 namespace dvmvs {
 
 template <class Cfg>

@@ -8,9 +8,9 @@ clears its two scratch buffers inside the timed region, timed separately as "cle
 the difference to the generic kernel, how many half units were published, and the first passes alone (dvmvs_debug_mode).
 
 Round-2 result (MI355X): bit-identical volumes on all 7 lines; no overhead when nothing is published (36.4 vs 37.2 us); on the
-worst line 177 halves are published and claimed, but the first pass does not get shorter (63.9 vs 64.7 us incl. 4 us of
-clears): the criterion (first fit of the first frame) does not catch the workgroups that end last.  Next: the timeline
-instrumentation of tools/sweep_trace.py on this kernel.
+worst line 177 halves are published and 171 claimed, but the first pass does not get shorter (63.9 vs 64.7 us incl. 4 us of
+clears).  --timeline shows why: a claimed half takes 36 us on a chip that is still full, so the claimers end last instead of
+the owners; lines 118 and 201 publish (almost) nothing because their heavy frame is the second one.  DESIGN.md section 7.
 """
 import argparse
 import ctypes
@@ -48,9 +48,42 @@ def timed(fn, reps=20):
     return best
 
 
+def timeline(lib, groups, li, head):
+    import numpy as np
+    wg = np.zeros((groups, 8), dtype=np.uint64)
+    half = np.zeros((groups, 4), dtype=np.uint64)
+    lib.dvmvs_debug_adaptive_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    assert lib.dvmvs_debug_adaptive_trace(wg.ctypes.data, half.ctypes.data, groups) == 0
+    wg, half = wg.astype(np.float64), half.astype(np.float64)
+    t0 = wg[:, 0].min()
+    start, first, end = (wg[:, 0] - t0) / 100.0, (wg[:, 1] - t0) / 100.0, (wg[:, 2] - t0) / 100.0
+    tasks, runs = wg[:, 3], wg[:, 4]
+    published, light = (wg[:, 6].astype(np.int64) & 1) == 1, (wg[:, 6].astype(np.int64) & 2) == 2
+    pub_t = np.where(published, (wg[:, 5] - t0) / 100.0, np.nan)
+    half[half[:, 0] < t0, 1] = 0   # records of earlier launches
+    claimed = half[:, 1] > 0
+    claim_t, done_t = (half[:, 0] - t0) / 100.0, (half[:, 2] - t0) / 100.0
+    print(f"line {li}: first pass spans {end.max():.1f} us; published {head[0]} halves (at {np.nanmedian(pub_t) if published.any() else float('nan'):.1f} us median); "
+          f"claimed by owner {int((half[:, 1] == 1).sum())}, by another workgroup {int((half[:, 1] == 2).sum())}")
+    if claimed.any():
+        for who, name in ((1, "owner"), (2, "other")):
+            sel = half[:, 1] == who
+            if sel.any():
+                print(f"   halves done by {name}: claimed at {np.median(claim_t[sel]):.1f} us median ({claim_t[sel].min():.1f}..{claim_t[sel].max():.1f}), "
+                      f"done at {np.median(done_t[sel]):.1f} median, {done_t[sel].max():.1f} max; duration {np.median((done_t - claim_t)[sel]):.1f} us median")
+    order = np.argsort(-end)[:32]
+    print(f"   last 32 workgroups to end: end {end[order].mean():.1f} us, own unit done at {first[order].mean():.1f}, tasks {tasks[order].mean():.2f}, "
+          f"staged runs of the own unit {runs[order].mean():.1f}, published {published[order].mean():.2f}, light {light[order].mean():.2f}")
+    for name, sel in (("publishers", published), ("light workgroups", light), ("the rest", ~published & ~light)):
+        if sel.any():
+            print(f"   {name:17s} n={int(sel.sum()):4d}: own unit done at {first[sel].mean():5.1f} us (max {first[sel].max():5.1f}), end {end[sel].mean():5.1f} (max {end[sel].max():5.1f}), "
+                  f"tasks {tasks[sel].mean():.2f}, staged runs {runs[sel].mean():.1f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lines", default="-1,0,35,118,153,177,201")
+    ap.add_argument("--timeline", action="store_true", help="print who ends last (one launch per line, no timing)")
     args = ap.parse_args()
     lib = ctypes.CDLL(os.path.join(ROOT, "deep-video-mvs_amd", "lib", "libdvmvs_hip_trace.so"))
     for name, (restype, argtypes) in _capi.SIGNATURES.items():
@@ -103,6 +136,12 @@ def main():
         adaptive()
         torch.cuda.synchronize()
         head = steal[:3].tolist()
+        if args.timeline:
+            for _ in range(4):   # warm caches: the records read back are those of the last launch
+                adaptive()
+            torch.cuda.synchronize()
+            timeline(lib, groups, li, steal[:3].tolist())
+            continue
         same = bool(torch.equal(out_p, out_a))
         diff_generic, diff_shipped = (out_a - out_g).abs().max().item(), (out_a - out_p).abs().max().item()
         mode = ctypes.c_int.in_dll(lib, "dvmvs_debug_mode")
@@ -116,7 +155,8 @@ def main():
         print(f"line {li:3d}: shipped {r[1]:7.2f} us | adaptive {r[2]:7.2f} us (of which clears {r[3]:5.2f}) | bit-identical {r[4]} "
               f"max|adaptive - shipped| {r[6]:.1e}  max|adaptive - generic| {r[5]:.1e} | halves published {r[7][0]}, claim cursor {r[7][1]}, error {r[7][2]}", flush=True)
         print("          incl. clears: " + ", ".join(f"{k} {v:.2f}" for k, v in extra.items()), flush=True)
-    print("mean: shipped %.2f us, adaptive %.2f us (%.2f without the clears)" % (
+    if rows:
+      print("mean: shipped %.2f us, adaptive %.2f us (%.2f without the clears)" % (
         sum(r[1] for r in rows) / len(rows), sum(r[2] for r in rows) / len(rows), sum(r[2] - r[3] for r in rows) / len(rows)))
 
 
