@@ -139,6 +139,23 @@ def test_dataset_training_augmentations(dataset_root):
             assert torch.isfinite(image).all()
 
 
+def test_dataset_batches_like_the_training_scripts_expect(dataset_root):
+    """run-training.py:135-141 wraps the dataset in a DataLoader; forward_pass (:184) takes lists of batched tensors."""
+    from dvmvs.config import Config
+    old = Config.train_image_width, Config.train_image_height, Config.train_data_pipeline_workers
+    Config.train_image_width, Config.train_image_height, Config.train_data_pipeline_workers = 64, 48, 1
+    try:
+        from dvmvs.dataset_loader import MVSDataset
+        ds = MVSDataset(root=dataset_root, seed=3, split="VALIDATION", subsequence_length=3, scale_rgb=255.0,
+                        mean_rgb=[0.485, 0.456, 0.406], std_rgb=[0.229, 0.224, 0.225])
+        loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=0, drop_last=True)
+        images, depths, poses, K = next(iter(loader))
+    finally:
+        Config.train_image_width, Config.train_image_height, Config.train_data_pipeline_workers = old
+    assert len(images) == len(depths) == len(poses) == 3
+    assert images[0].shape == (2, 3, 48, 64) and depths[0].shape == (2, 48, 64) and poses[0].shape == (2, 4, 4) and K.shape == (2, 3, 3)
+
+
 def test_colour_jitter_operators():
     from dvmvs.dataset_loader import adjust_brightness, adjust_contrast, adjust_gamma
     x = torch.tensor([0.0, 0.25, 0.5, 1.0])
