@@ -8,9 +8,8 @@ the published checkpoints load unchanged.  All convolutions are plain ``torch.nn
 """
 from collections import OrderedDict
 
-import torch
-from torch import nn
 import torch.nn.functional as F
+from torch import nn
 
 # torchvision's MnasNet uses a TF-style BN momentum of 0.9997 (i.e. 1 - 0.9997 in torch convention)
 MNASNET_BN_MOMENTUM = 1.0 - 0.9997
