@@ -6,6 +6,8 @@
 // unit (all measurement frames of them, so every output keeps exactly one writer and its summation order).  Workgroups that
 // are done claim published halves; an owner claims its own half back when nobody did.  Nobody waits for anybody.
 // The kernel body below is sweep_tiled_kernel<Cfg, NCHW, two-pass> with a task loop around it; what differs is marked.
+#include <type_traits>
+
 #include "sweep_tiled.hip"
 
 namespace dvmvs {
@@ -14,9 +16,21 @@ namespace dvmvs {
 __device__ unsigned long long g_adaptive_wg[8192 * 8];
 __device__ unsigned long long g_adaptive_half[8192 * 4];
 
+// The timeline costs registers the kernel does not have (80 B of scratch per lane, +12 us per launch): it is compiled in only
+// with -DDVMVS_ADAPTIVE_TIMELINE, for tools/sweep_adaptive_bench.py --timeline; timings are taken without it.
+#ifdef DVMVS_ADAPTIVE_TIMELINE
+#define ADAPTIVE_TL(...) __VA_ARGS__
+#else
+#define ADAPTIVE_TL(...)
+#endif
+
 constexpr int kStealHeaderWords = 16;   // [0] published halves, [1] claim cursor, [2] error flag; then the list, then one flag per group
 
-template <class Cfg>
+// ADAPTIVE: publish / claim half units.  PREPOS: the next frame's positions are computed inside the tap blocks of the current
+// frame's first pass -- measured: that form needs 232 B of scratch per lane and runs 51 us where the plain kernel runs 34-38
+// (any scratch at all costs this kernel >= 10 us); it needs ~30 registers freed elsewhere first.  <false, false> is the shipped
+// first pass without its trace instrumentation.
+template <class Cfg, bool ADAPTIVE, bool PREPOS>
 __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(CostVolumeArgs a, unsigned int* steal_raw, int claim_once) {
   constexpr bool NHWC = false, GATHER = false;
   constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP, CCH = Cfg::CCH, CAP = Cfg::CAP, NT = Cfg::NT, REC = Cfg::REC;
@@ -43,9 +57,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
   int task_group = work.group, p_lo = 0, p_hi = DP;
   bool own_upper_pending = false;   // this workgroup published the upper half of its unit and has not yet tried to claim it back
   int cur_b = -1;
-  const unsigned long long tx_start = __builtin_amdgcn_s_memrealtime();
-  unsigned long long tx_first = 0, tx_publish = 0;
-  int tx_tasks = 0, tx_first_runs = 0, tx_published = 0;
+  ADAPTIVE_TL(const unsigned long long tx_start = __builtin_amdgcn_s_memrealtime(); unsigned long long tx_first = 0, tx_publish = 0;)
+  ADAPTIVE_TL(int tx_tasks = 0, tx_first_runs = 0, tx_published = 0;)
   bool light = false;   // this workgroup's own unit was light: it may claim published halves
   for (;;) {
   const int b = task_group / per_b;
@@ -105,16 +118,26 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
 #pragma unroll
   for (int j = 0; j < DP; ++j) acc2[j] = float2v{0.0f, 0.0f};
 
+  // (differs) positions of the NEXT frame, computed inside the tap blocks of the current frame's first pass, where the wave
+  // otherwise sits out LDS round trips; pre_mask: planes for which pos_pre holds the coming frame's position
+  float2v pos_pre[DP];
+  unsigned int pre_mask = 0;
   for (int m = 0; m < a.M; ++m) {
     const float* Hm = s_H + m * 9;
     const float4v* ktd_m = s_ktd + m * DP;
+    const bool has_next = m + 1 < a.M;
+    const SweepRay ray_n = sweep_ray(s_H + (has_next ? m + 1 : m) * 9, xf, yf);
+    const float4v* ktd_n = s_ktd + (has_next ? m + 1 : m) * DP;
+    const unsigned int pre_mask_cur = pre_mask;   // what pos_pre holds for THIS frame
+    pre_mask = 0;
+    bool frame_first_staged = true;
     gcfloat_p meas = as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW;
     const SweepRay ray = sweep_ray(Hm, xf, yf);
     // This thread's sample positions on the chunk's planes do not depend on the box: with NCHW maps they are computed once per
     // frame and kept (16 registers) for workgroups that need several runs; the channels-last instantiation has no registers to
     // spare and recomputes them per run.  Either way all DP planes are evaluated without branches, so that the DP chains of
     // dependent operations (three exact divisions each) sit in one basic block.
-    constexpr bool kKeepPositions = false;   // (differs: the task loop's state takes the 16 registers)
+    constexpr bool kKeepPositions = !ADAPTIVE && !PREPOS;   // (the task loop's state / pos_pre take the 16 registers)
     float2v pos[DP];
     auto sample_positions = [&]() {
 #pragma unroll
@@ -131,13 +154,12 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
     while (seg_lo < p_hi) {
       int seg_len = min(p_hi - seg_lo, seg_hint);
       const SampleBox box = wave_sample_box<TW, TH, CAP, Cfg::MINSEG>(a, Hm, ktd_m, tile_x, tile_y, seg_lo, seg_len, sc, lane, &seg_len);
-      if (m == 0 && seg_lo == 0 && p_lo == 0 && p_hi == DP && seg_len < DP && task_group == work.group && !own_upper_pending) {
+      if (ADAPTIVE && m == 0 && seg_lo == 0 && p_lo == 0 && p_hi == DP && seg_len < DP && task_group == work.group && !own_upper_pending) {
         // the first fit of the own unit says "several runs": keep planes [0, DP/2) and publish [DP/2, DP) (all frames of them)
         p_hi = DP / 2;
         seg_len = min(seg_len, p_hi);
         own_upper_pending = true;
-        tx_published = 1;
-        tx_publish = __builtin_amdgcn_s_memrealtime();
+        ADAPTIVE_TL(tx_published = 1; tx_publish = __builtin_amdgcn_s_memrealtime();)
         if (tid == 0) {
           const unsigned int at = atomicAdd(steal, 1u);
           atomicExch(steal_list + at, static_cast<unsigned int>(task_group) + 1u);
@@ -155,11 +177,27 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
         // instead of 32: what keeps this kernel at 3 waves per SIMD without scratch traffic) ----
         int addr[DP];
         float2v frac[DP];
-        if (!kKeepPositions) sample_positions();
+        const unsigned int run_mask = ((1u << seg_len) - 1u) << seg_lo;
+        const bool use_pre = PREPOS && frame_first_staged && (pre_mask_cur & run_mask) == run_mask;
+        const bool fill_next = PREPOS && frame_first_staged && has_next;
+        frame_first_staged = false;
+        if (PREPOS) {
+          if (!use_pre) {   // one array: filled here or during the previous frame's first pass, consumed below, refilled in pass 0
+#pragma unroll
+            for (int j = 0; j < DP; ++j) {
+              const float4v kd = ktd_m[j];
+              float ix, iy;
+              sweep_sample(ray, kd.x, kd.y, kd.z, sc, &ix, &iy);
+              pos_pre[j] = float2v{ix, iy};
+            }
+          }
+        } else if (!kKeepPositions) {
+          sample_positions();
+        }
 #pragma unroll
         for (int j = 0; j < DP; ++j) {   // all planes (those outside the run get addresses that are never used)
           const bool in_run = j >= seg_lo && j < seg_hi;   // workgroup-uniform
-          const float ix = pos[j].x, iy = pos[j].y;
+          const float ix = PREPOS ? pos_pre[j].x : pos[j].x, iy = PREPOS ? pos_pre[j].y : pos[j].y;
           const float fx = floorf(ix), fy = floorf(iy);
           int rx = static_cast<int>(fx) - box.x_lo, ry = static_cast<int>(fy) - box.y_lo;
           if (live && in_run) violated |= (static_cast<unsigned int>(rx) > static_cast<unsigned int>(box.RW - 2)) |
@@ -237,6 +275,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
             if (k * NT < n_pieces) load_piece(k, 0, pre + k * kPreRegs);   // workgroup-uniform
         }
         for (int c0 = 0; c0 < a.C; c0 += CCH) {
+          const bool fill = fill_next && c0 == 0;   // workgroup-uniform
           float2v rv[CCH / 2];
           if (kPre > 0) {
 #pragma unroll
@@ -270,10 +309,19 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
           }
 #pragma unroll
           for (int j = 0; j < DP; ++j)
-            if (j >= seg_lo && j < seg_hi)   // workgroup-uniform
+            if (j >= seg_lo && j < seg_hi) {   // workgroup-uniform
               tap_plane<QPR, REC>(tile_bytes, row_bytes, addr[j], frac[j], rv, &acc2[j]);
+              if (fill) {   // VALU work moved into the LDS-bound half of the pass
+                const float4v kd = ktd_n[j];
+                float nx, ny, kz = kd.z;
+                asm volatile("" : "+v"(kz));   // opaque: the computation is loop-invariant and would be hoisted out of the pass loop
+                sweep_sample(ray_n, kd.x, kd.y, kz, sc, &nx, &ny);
+                pos_pre[j] = float2v{nx, ny};
+              }
+            }
           __syncthreads();
         }
+        if (fill_next) pre_mask |= run_mask;
       } else if (box.state == 0 && !GATHER) {
         // cannot be staged: queue the run for the second pass.  The two halves of a unit may both append to the unit's slot
         // (their planes are disjoint, so the per-plane order of the items stays the frame order); the first item registers
@@ -323,17 +371,17 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
         if (j >= p_lo && j < p_hi) out[static_cast<size_t>(j) * HW] = ((acc2[j].x + acc2[j].y) / Cf) / Mf;
     }
   }
+  if (!ADAPTIVE) break;
   // ---- next task ----
-  ++tx_tasks;
-  if (tx_tasks == 1) { tx_first = __builtin_amdgcn_s_memrealtime(); tx_first_runs = staged_runs; }
-  if (tid == 0 && p_lo != 0 && task_group < 8192) g_adaptive_half[task_group * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+  ADAPTIVE_TL(++tx_tasks; if (tx_tasks == 1) { tx_first = __builtin_amdgcn_s_memrealtime(); tx_first_runs = staged_runs; })
+  ADAPTIVE_TL(if (tid == 0 && p_lo != 0 && task_group < 8192) g_adaptive_half[task_group * 4 + 2] = __builtin_amdgcn_s_memrealtime();)
   __syncthreads();   // every thread is done with s_ktd and the tile before they are rebuilt
   if (task_group == work.group && p_lo == 0) light = staged_runs < a.M;   // judged on the workgroup's own unit, kept afterwards
   if (tid == 0) {
     int next = -1;
     if (own_upper_pending && atomicExch(steal_flag + work.group, 1u) == 0u) {   // nobody took it: do it here
       next = work.group;
-      if (next < 8192) { g_adaptive_half[next * 4 + 0] = __builtin_amdgcn_s_memrealtime(); g_adaptive_half[next * 4 + 1] = 1; }
+      ADAPTIVE_TL(if (next < 8192) { g_adaptive_half[next * 4 + 0] = __builtin_amdgcn_s_memrealtime(); g_adaptive_half[next * 4 + 1] = 1; })
     }
     if (next < 0 && light && !(claim_once && s_next[1])) {
       int stolen = 0;
@@ -351,7 +399,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
         if (atomicExch(steal_flag + (entry - 1u), 1u) == 0u) {
           next = static_cast<int>(entry - 1u);
           stolen = 1;
-          if (next < 8192) { g_adaptive_half[next * 4 + 0] = __builtin_amdgcn_s_memrealtime(); g_adaptive_half[next * 4 + 1] = 2; }
+          ADAPTIVE_TL(if (next < 8192) { g_adaptive_half[next * 4 + 0] = __builtin_amdgcn_s_memrealtime(); g_adaptive_half[next * 4 + 1] = 2; })
           break;
         }
       }
@@ -363,11 +411,13 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
   __syncthreads();
   const int next = s_next[0];
   if (next < 0) {
+#ifdef DVMVS_ADAPTIVE_TIMELINE
     if (tid == 0 && work.group < 8192) {
       unsigned long long* t = g_adaptive_wg + static_cast<size_t>(work.group) * 8;
       t[0] = tx_start; t[1] = tx_first; t[2] = __builtin_amdgcn_s_memrealtime(); t[3] = static_cast<unsigned long long>(tx_tasks);
       t[4] = static_cast<unsigned long long>(tx_first_runs); t[5] = tx_publish; t[6] = static_cast<unsigned long long>(tx_published) | (light ? 2ull : 0ull);
     }
+#endif
     break;
   }
   task_group = next;
@@ -378,7 +428,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_adaptive_kernel(Cos
 
 }  // namespace dvmvs
 // bit 0: leave out the second pass; bit 1: launch the shipped first-pass kernel instead of the adaptive one (so that the two
-// first passes can be timed alone, side by side); bit 2: a workgroup claims at most one published half
+// first passes can be timed alone, side by side); bit 2: a workgroup claims at most one published half; bit 3 (8): the kernel
+// with PREPOS instead of the adaptive one; bit 4 (16): the plain kernel (shipped first pass, no trace instrumentation)
 extern "C" int dvmvs_debug_mode = 0;
 extern "C" int dvmvs_debug_adaptive_trace(unsigned long long* wg, unsigned long long* half, int groups) {
   if (groups > 8192) groups = 8192;
@@ -393,7 +444,7 @@ int launch_sweep_adaptive(const CostVolumeArgs& a, unsigned int* steal, hipStrea
   const long long total = tiles * ((a.D + Cfg::DP - 1) / Cfg::DP) * a.B;
   const unsigned int grid = static_cast<unsigned int>((total + 7) / 8 * 8);
   static bool configured[kMaxDevices] = {};
-  auto kernel = sweep_adaptive_kernel<Cfg>;
+  auto kernel = sweep_adaptive_kernel<Cfg, true, false>;
   const int rc = raise_dynamic_lds_limit(kernel, Cfg::kLdsBytes, configured);
   if (rc != 0) return rc;
   if (dvmvs_debug_mode & 2) {
@@ -402,6 +453,14 @@ int launch_sweep_adaptive(const CostVolumeArgs& a, unsigned int* steal, hipStrea
     const int rc3 = raise_dynamic_lds_limit(shipped, Cfg::kLdsBytes, configured2);
     if (rc3 != 0) return rc3;
     hipLaunchKernelGGL(shipped, dim3(grid), dim3(Cfg::NT), Cfg::kLdsBytes, stream, a);
+  } else if (dvmvs_debug_mode & 24) {
+    static bool configured3[kMaxDevices] = {}, configured4[kMaxDevices] = {};
+    auto prepos = sweep_adaptive_kernel<Cfg, false, true>;
+    auto plain = sweep_adaptive_kernel<Cfg, false, false>;
+    int rc4 = raise_dynamic_lds_limit(prepos, Cfg::kLdsBytes, configured3);
+    if (rc4 == 0) rc4 = raise_dynamic_lds_limit(plain, Cfg::kLdsBytes, configured4);
+    if (rc4 != 0) return rc4;
+    hipLaunchKernelGGL((dvmvs_debug_mode & 8) ? prepos : plain, dim3(grid), dim3(Cfg::NT), Cfg::kLdsBytes, stream, a, steal, 0);
   } else {
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(Cfg::NT), Cfg::kLdsBytes, stream, a, steal, (dvmvs_debug_mode & 4) ? 1 : 0);
   }

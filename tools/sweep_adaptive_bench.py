@@ -1,5 +1,6 @@
 """EXPERIMENT: the sweep with adaptive plane counts and claimable half units (csrc/sweep_experimental.hip) against the shipped
-sweep, on keyframe geometries of the sample scene (needs `make -C deep-video-mvs_amd/csrc trace`; GPU box).
+sweep, on keyframe geometries of the sample scene (needs `make -C deep-video-mvs_amd/csrc trace`, or `trace-timeline` for
+--timeline: the timeline's bookkeeping spills registers, so timings are taken without it; GPU box).
 
     python tools/sweep_adaptive_bench.py [--lines=-1,0,35,118,153,177,201]
 
@@ -146,7 +147,7 @@ def main():
         diff_generic, diff_shipped = (out_a - out_g).abs().max().item(), (out_a - out_p).abs().max().item()
         mode = ctypes.c_int.in_dll(lib, "dvmvs_debug_mode")
         extra = {}
-        for name, value in (("adaptive first pass", 1), ("shipped first pass", 3), ("adaptive, one claim", 4), ("adaptive first pass, one claim", 5)):
+        for name, value in (("adaptive first pass", 1), ("shipped first pass", 3), ("plain (uninstrumented shipped) op", 16), ("positions-in-tap-blocks op", 8)):
             mode.value = value
             extra[name] = timed(adaptive)
         mode.value = 0
