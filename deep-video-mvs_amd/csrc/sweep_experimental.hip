@@ -488,7 +488,9 @@ extern "C" int dvmvs_debug_sweep_adaptive(const float* image1, const float* cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t groups = static_cast<size_t>((W + 31) / 32) * ((H + 7) / 8) * ((D + 7) / 8) * B;
   if (workspace == nullptr || steal == nullptr || steal_bytes < sizeof(unsigned int) * (kStealHeaderWords + 2 * groups)) return DVMVS_EINVAL;
-  if (hipMemsetAsync(workspace, 0, workspace_bytes, s) != hipSuccess) return DVMVS_EINVAL;
-  if (hipMemsetAsync(steal, 0, steal_bytes, s) != hipSuccess) return DVMVS_EINVAL;
+  if (!(dvmvs_debug_mode & 32)) {   // bit 5 (32): the caller vouches for zeroed scratch (geometries where nothing spills)
+    if (hipMemsetAsync(workspace, 0, workspace_bytes, s) != hipSuccess) return DVMVS_EINVAL;
+    if (hipMemsetAsync(steal, 0, steal_bytes, s) != hipSuccess) return DVMVS_EINVAL;
+  }
   return launch_sweep_adaptive<SweepDefault>(a, steal, s);
 }

@@ -147,7 +147,8 @@ def main():
         diff_generic, diff_shipped = (out_a - out_g).abs().max().item(), (out_a - out_p).abs().max().item()
         mode = ctypes.c_int.in_dll(lib, "dvmvs_debug_mode")
         extra = {}
-        for name, value in (("adaptive first pass", 1), ("shipped first pass", 3), ("plain (uninstrumented shipped) op", 16), ("positions-in-tap-blocks op", 8)):
+        for name, value in (("adaptive first pass", 1), ("shipped first pass", 3), ("plain (uninstrumented shipped) op", 16), ("positions-in-tap-blocks op", 8),
+                            ("plain op, no clears", 48), ("instrumented shipped op, no clears", 34)):
             mode.value = value
             extra[name] = timed(adaptive)
         mode.value = 0
