@@ -116,12 +116,12 @@ def golden_rel_l1(modules, device, args):
     z = np.load(os.path.join(ROOT, "tests", "golden", "fusionnet_e2e.npz"))
     engine = DepthEngine(*modules, device=device, fold_bn=not args.no_fold_bn, cache_features=not args.no_feature_cache,
                          use_graphs=False, channels_last=args.channels_last, lstm_channels_last=not args.no_lstm_channels_last)
-    fullK = syn.full_K().to(device)
+    fullK = syn.full_K()
     out = []
     with torch.no_grad():
         for n, (r, ms) in enumerate(syn.E2E_FRAMES):
-            depth = engine.step(syn.e2e_image(r).to(device), syn.pose(r).to(device), [syn.e2e_image(i).to(device) for i in ms],
-                                [syn.pose(i).to(device) for i in ms], fullK, frame_id=r, measurement_ids=list(ms))
+            depth = engine.step(syn.e2e_image(r).to(device), syn.pose(r), [syn.e2e_image(i).to(device) for i in ms],
+                                [syn.pose(i) for i in ms], fullK, frame_id=r, measurement_ids=list(ms))
             d = depth[0, ::4, ::4].cpu().numpy().astype(np.float64)
             ref = z[f"f{n}_depth_sub4"].astype(np.float64)
             out.append({"frame": n, "engine_vs_reference": float(np.mean(np.abs(d - ref) / ref)),
@@ -141,9 +141,9 @@ def batched_throughput(modules, device, args, S, M):
     n_images, warmup, steps = 16, 6, args.batched_steps
     per_seq = [synthetic_sequence(sid, n_images, warmup + steps + M + 1, M) for sid in range(S)]
     images = [torch.cat([per_seq[sid][0][i] for sid in range(S)]).to(device) for i in range(n_images)]
-    seq = [(torch.cat([per_seq[sid][1][j][0] for sid in range(S)]).to(device),
-            [torch.cat([per_seq[sid][1][j][1][m] for sid in range(S)]).to(device) for m in range(M)]) for j in range(len(per_seq[0][1]))]
-    full_K = per_seq[0][2].repeat(S, 1, 1).to(device)
+    seq = [(torch.cat([per_seq[sid][1][j][0] for sid in range(S)]),
+            [torch.cat([per_seq[sid][1][j][1][m] for sid in range(S)]) for m in range(M)]) for j in range(len(per_seq[0][1]))]
+    full_K = per_seq[0][2].repeat(S, 1, 1)      # poses / intrinsics stay on the host (DepthEngine.step)
     cache = not args.no_feature_cache
 
     def run_frame(k):
@@ -168,7 +168,7 @@ def batched_throughput(modules, device, args, S, M):
         elapsed = time.perf_counter() - t0
     assert np.isfinite(float(engine._static["depth"].mean()))
     _, pose_sets = index_pose_sets(M, 9)
-    pose_sets = [(r.repeat(S, 1, 1).to(device), [p.repeat(S, 1, 1).to(device) for p in ms]) for r, ms in pose_sets]
+    pose_sets = [(r.repeat(S, 1, 1), [p.repeat(S, 1, 1) for p in ms]) for r, ms in pose_sets]
     kernel_s, alg_bytes, _ = measure_cost_volume_kernel(engine, M, max(2, args.kernel_reps // 2), pose_sets)
     return S * steps / elapsed, 1e3 * elapsed / steps, kernel_s, alg_bytes
 
@@ -180,7 +180,9 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
     (how large the LDS-staged footprint of a tile is, how many runs of planes spill), so one geometry is not
     representative.  For each, a hipGraph of ``reps`` back-to-back ops (no host gaps) is timed with HIP events on the
     stream it is replayed on.  Returns (mean seconds per op, algorithmic bytes per op, [per-geometry seconds])."""
+    from dvmvs import pose_algebra, utils
     from dvmvs.hip import _capi
+    from dvmvs.hip import ops as _ops
     s = engine._static
     ref = s["ref_half"]
     B, C, H, W = ref.shape
@@ -189,18 +191,24 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
     img_ptrs = _capi.pointer_array([t.data_ptr() for t in s["meas_feat"][:n_meas]])
     layout = _capi.LAYOUT_NHWC if all(t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
                                       for t in s["meas_feat"][:n_meas]) else _capi.LAYOUT_NCHW
-    pose_ptrs = _capi.pointer_array([t.data_ptr() for t in s["meas_pose"][:n_meas]])
+    Hm = torch.zeros(B, n_meas, 9, device=ref.device)
+    kt = torch.zeros(B, n_meas, 3, device=ref.device)
+    half_K = s["half_K"].cpu()
     lib = _capi.lib()
-    from dvmvs import utils
-    from dvmvs.hip import ops as _ops
     workspace, ws_bytes = _ops.sweep_workspace(ref.device, B, n_meas, H, W, D)
 
+    def set_geometry(ref_pose, meas_poses):
+        h, k = pose_algebra.sweep_matrices(ref_pose, meas_poses[:n_meas], half_K, ref.device, engine.pose_algebra)
+        Hm.copy_(h)
+        kt.copy_(k)
+
     def launch():
-        rc = lib.dvmvs_cost_volume_fwd(ref.data_ptr(), img_ptrs, s["pose"].data_ptr(), pose_ptrs, s["half_K"].data_ptr(), out.data_ptr(),
+        rc = lib.dvmvs_cost_volume_fwd(ref.data_ptr(), img_ptrs, Hm.data_ptr(), kt.data_ptr(), out.data_ptr(),
                                        B, n_meas, C, H, W, D, engine.min_depth, engine.max_depth, 1, utils.COST_VOLUME_VARIANT, layout,
                                        workspace.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
         _capi.check(rc, "dvmvs_cost_volume_fwd")
 
+    set_geometry(*pose_sets[0])
     launch()
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
@@ -210,9 +218,7 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
     per_geometry = []
     rounds = 3
     for ref_pose, meas_poses in pose_sets:
-        s["pose"].copy_(ref_pose)
-        for i in range(n_meas):
-            s["meas_pose"][i].copy_(meas_poses[i])
+        set_geometry(ref_pose, meas_poses)
         graph.replay()
         torch.cuda.synchronize()
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -307,7 +313,8 @@ def train_mode(args, world, rank, device):
     images = [syn.smooth_noise((B, 3, H, W), seed=5000 + 100 * rank + i).to(device) for i in range(T)]
     depths = [(torch.rand(B, H, W, generator=g) * 4.5 + 0.5).to(device) for _ in range(T)]
     all_poses = torch.from_numpy(syn.sample_poses()).float()
-    poses = [torch.stack([all_poses[(40 * b + 3 * i + 7 * rank) % len(all_poses)] for b in range(B)]).to(device) for i in range(T)]
+    # poses stay on the host (read by the host-side pose algebra only, dvmvs.pose_algebra)
+    poses = [torch.stack([all_poses[(40 * b + 3 * i + 7 * rank) % len(all_poses)] for b in range(B)]) for i in range(T)]
     K = torch.cat([syn.full_K(width=W, height=H)] * B).to(device)
     for _ in range(max(args.warmup, 1)):
         train_step(model, opt, reducer, images, depths, poses, K)
@@ -376,8 +383,8 @@ def main():
     total = args.warmup + args.steps
     images, seq, full_K = synthetic_sequence(rank, n_images, total + M + 1, M)   # one independent sequence per rank
     images = [im.to(device) for im in images]
-    seq = [(r.to(device), [p.to(device) for p in ms]) for r, ms in seq]
-    full_K = full_K.to(device)
+    # poses and intrinsics stay on the host: that is where they come from and where the engine evaluates the frame's small
+    # matrices (dvmvs.pose_algebra, "reference" mode) before its single per-frame upload
 
     def run_frame(k):
         ids = [k - 1 - i for i in range(M)]
@@ -428,7 +435,6 @@ def main():
             kernel_s, alg_bytes, per_geometry = float("nan"), (1 + M) * 32 * 128 * 160 * 4 + 64 * 128 * 160 * 4, []
         else:
             picks, pose_sets = index_pose_sets(M, ROOFLINE_GEOMETRIES)
-            pose_sets = [(r.to(device), [p.to(device) for p in ms]) for r, ms in pose_sets]
             kernel_s, alg_bytes, per_geometry = measure_cost_volume_kernel(engine, M, args.kernel_reps, pose_sets)
         achieved = alg_bytes / kernel_s / 1e9
         # HBM bytes per op from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: only when the committed measurement was taken on

@@ -110,9 +110,8 @@ extern "C" size_t dvmvs_cost_volume_workspace_bytes(int B, int M, int H, int W, 
   return sizeof(unsigned int) * dvmvs::sweep_spill_words(B, M, H, W, D);
 }
 
-extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, const float* pose1,
-                                     const float* const* pose2s, const float* K, float* cost_volume,
-                                     int B, int M, int C, int H, int W, int D,
+extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, const float* Hm, const float* kt,
+                                     float* cost_volume, int B, int M, int C, int H, int W, int D,
                                      double min_depth, double max_depth, int dot_product, int variant, int image2_layout,
                                      float* workspace, size_t workspace_bytes, dvmvs_stream_t stream) {
   using namespace dvmvs;
@@ -120,7 +119,7 @@ extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* im
   if (variant < 0 || (variant > 2 && variant < 32) || variant > 63) return DVMVS_EINVAL;
   if (variant == 2 && !dot_product) return DVMVS_EUNSUPPORTED;
   CostVolumeArgs a;
-  const int rc = fill_sweep_args(&a, image1, image2s, pose1, pose2s, K, cost_volume, B, M, C, H, W, D, min_depth, max_depth, true);
+  const int rc = fill_sweep_args(&a, image1, image2s, Hm, kt, cost_volume, B, M, C, H, W, D, min_depth, max_depth, true);
   if (rc != 0) return rc;
   a.image2_nhwc = image2_layout == DVMVS_LAYOUT_NHWC ? 1 : 0;
   // channels-last measurement maps are understood by the LDS-tiled dot-product kernel only (16-byte channel quads)

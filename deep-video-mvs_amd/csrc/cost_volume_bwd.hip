@@ -278,14 +278,13 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_meas_kernel(CostVolumeBwd
 }  // namespace dvmvs
 
 extern "C" int dvmvs_cost_volume_bwd(const float* grad_cost, const float* image1, const float* const* image2s,
-                                     const float* pose1, const float* const* pose2s, const float* K,
-                                     float* grad_image1, float* const* grad_image2s,
+                                     const float* Hm, const float* kt, float* grad_image1, float* const* grad_image2s,
                                      int B, int M, int C, int H, int W, int D,
                                      double min_depth, double max_depth, dvmvs_stream_t stream) {
   using namespace dvmvs;
   if (!grad_cost || !grad_image1 || !grad_image2s) return DVMVS_EINVAL;
   CostVolumeBwdArgs a;
-  int rc = fill_sweep_args(&a.fwd, image1, image2s, pose1, pose2s, K, /*out=*/nullptr, B, M, C, H, W, D, min_depth, max_depth,
+  int rc = fill_sweep_args(&a.fwd, image1, image2s, Hm, kt, /*out=*/nullptr, B, M, C, H, W, D, min_depth, max_depth,
                            /*need_out=*/false);
   if (rc != 0) return rc;
   a.grad_cost = grad_cost;

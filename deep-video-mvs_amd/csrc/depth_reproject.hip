@@ -11,19 +11,14 @@ namespace dvmvs {
 
 constexpr float kReprojEps = 1e-8f;
 
-__global__ __launch_bounds__(256) void depth_splat_kernel(const float* __restrict__ ref_pose, const float* __restrict__ meas_pose,
-                                                          const float* __restrict__ prev_depth, const float* __restrict__ full_K,
-                                                          const float* __restrict__ half_K, unsigned int* __restrict__ out_bits,
-                                                          int B, int Hf, int Wf) {
+// `trans` = inverse(reference_pose) * measurement_pose (utils.py:121) is the caller's (ABI 3): the reference's own fp32 matrix by
+// default, dvmvs_relative_pose's fp64 one in "exact" mode.  Uniform per batch item: the loads below are scalar (SGPR) loads.
+__global__ __launch_bounds__(256) void depth_splat_kernel(const float* __restrict__ trans, const float* __restrict__ prev_depth,
+                                                          const float* __restrict__ full_K, const float* __restrict__ half_K,
+                                                          unsigned int* __restrict__ out_bits, int B, int Hf, int Wf) {
 #pragma clang fp contract(off)
-  __shared__ float s_T[16];
   const int b = blockIdx.y;
-  if (threadIdx.x == 0) {
-    double T[16];
-    relative_pose_f64(ref_pose + b * 16, meas_pose + b * 16, T);  // inverse(reference_pose) * measurement_pose
-    for (int i = 0; i < 16; ++i) s_T[i] = static_cast<float>(T[i]);
-  }
-  __syncthreads();
+  const float* s_T = trans + b * 16;
   const int HWf = Hf * Wf;
   const int hw = Wf / 2, hh = Hf / 2;
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,12 +64,11 @@ __global__ void nearest_decimate_kernel(const float* __restrict__ in, float* __r
 
 }  // namespace dvmvs
 
-extern "C" int dvmvs_depth_reproject_fwd(const float* reference_pose, const float* measurement_pose,
-                                         const float* previous_depth, const float* full_K, const float* half_K,
-                                         float* out, float* out_lowres, int lowres_factor,
+extern "C" int dvmvs_depth_reproject_fwd(const float* transformation, const float* previous_depth, const float* full_K,
+                                         const float* half_K, float* out, float* out_lowres, int lowres_factor,
                                          int B, int full_height, int full_width, dvmvs_stream_t stream) {
   using namespace dvmvs;
-  if (!reference_pose || !measurement_pose || !previous_depth || !full_K || !half_K || !out) return DVMVS_EINVAL;
+  if (!transformation || !previous_depth || !full_K || !half_K || !out) return DVMVS_EINVAL;
   if (B <= 0 || full_height < 2 || full_width < 2 || B > 65535) return DVMVS_EINVAL;
   if (out_lowres && lowres_factor <= 0) return DVMVS_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -84,7 +78,7 @@ extern "C" int dvmvs_depth_reproject_fwd(const float* reference_pose, const floa
   int rc = launch_status();
   if (rc != 0) return rc;
   const int HWf = full_height * full_width;
-  hipLaunchKernelGGL(depth_splat_kernel, dim3((HWf + 255) / 256, B), dim3(256), 0, s, reference_pose, measurement_pose,
+  hipLaunchKernelGGL(depth_splat_kernel, dim3((HWf + 255) / 256, B), dim3(256), 0, s, transformation,
                      previous_depth, full_K, half_K, reinterpret_cast<unsigned int*>(out), B, full_height, full_width);
   rc = launch_status();
   if (rc != 0) return rc;

@@ -92,15 +92,6 @@ __global__ __launch_bounds__(256) void hidden_warp_bwd_kernel(const float* __res
   }
 }
 
-__global__ void relative_pose_kernel(const float* __restrict__ a, const float* __restrict__ c, float* __restrict__ out, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  double r[16];
-  relative_pose_f64(a + b * 16, c + b * 16, r);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) out[b * 16 + i] = static_cast<float>(r[i]);
-}
-
 inline int elementwise_grid(long long total, int block) {
   long long g = (total + block - 1) / block;
   const long long cap = 256LL * 8;  // CUs x resident workgroups; grid-stride beyond
@@ -131,12 +122,5 @@ extern "C" int dvmvs_hidden_warp_bwd(const float* grad_out, const float* depth_d
   const long long total = static_cast<long long>(B) * C * H * W;
   hipLaunchKernelGGL(hidden_warp_bwd_kernel, dim3(elementwise_grid(total, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), grad_out, depth_dst, src_trans_dst, camera_matrix, grad_src, B, C, H, W);
-  return launch_status();
-}
-
-extern "C" int dvmvs_relative_pose(const float* a, const float* c, float* out, int B, dvmvs_stream_t stream) {
-  using namespace dvmvs;
-  if (!a || !c || !out || B <= 0) return DVMVS_EINVAL;
-  hipLaunchKernelGGL(relative_pose_kernel, dim3((B + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), a, c, out, B);
   return launch_status();
 }

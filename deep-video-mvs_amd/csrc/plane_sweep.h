@@ -9,9 +9,8 @@ namespace dvmvs {
 struct CostVolumeArgs {
   const float* image1;
   const float* image2[DVMVS_MAX_MEASUREMENTS];
-  const float* pose1;
-  const float* pose2[DVMVS_MAX_MEASUREMENTS];
-  const float* K;
+  const float* Hm;   // [B,M,9]  K R K^-1, computed by the caller (reference rounding) or by dvmvs_sweep_matrices (fp64)
+  const float* kt;   // [B,M,3]  K t
   float* out;
   int B, M, C, H, W, D;
   double inv_depth_base, inv_depth_step;
@@ -19,7 +18,7 @@ struct CostVolumeArgs {
   unsigned int* spill;   // optional spill workspace of the two-pass tiled sweep (layout: sweep_tiled.hip); nullptr = gather inline
 };
 
-// Per-(batch, measurement) sweep constants, evaluated once per workgroup into LDS.
+// Per-(batch, measurement) sweep constants in fp64, rounded once (dvmvs_sweep_matrices: the opt-in "exact" pose algebra).
 //   Hm = K R K^-1 (row-major 3x3), kt = K t   with [R|t] = inverse(pose2) * pose1     (utils.py:51-56)
 __device__ inline void sweep_matrices(const float* pose1, const float* pose2, const float* K, float* Hm, float* kt) {
   double E[16];
@@ -46,17 +45,20 @@ __device__ inline float plane_depth(double inv_base, double inv_step, int d) {
   return static_cast<float>(1.0 / (inv_base + static_cast<double>(d) * inv_step));
 }
 
-// Fills s_H[M][9], s_kt[M][3] and s_ktd[M][planes][3] (= kt / depth_d for d in [d_begin, d_begin+planes)).
+// Fills s_H[M][9], s_kt[M][3] (copies of the caller's matrices for batch item b) and s_ktd[M][planes][3] (= kt / depth_d for d
+// in [d_begin, d_begin+planes): the reference's `Kt / this_depth`, utils.py:66-68, an IEEE fp32 division by the fp32-rounded depth).
 __device__ inline void sweep_setup(const CostVolumeArgs& a, int b, int d_begin, int planes, int tid, int nthreads,
                                    float* s_H, float* s_kt, float* s_ktd) {
-  if (tid < a.M) sweep_matrices(a.pose1 + b * 16, a.pose2[tid] + b * 16, a.K + b * 9, s_H + tid * 9, s_kt + tid * 3);
-  __syncthreads();
+  const float* Hm = a.Hm + static_cast<size_t>(b) * a.M * 9;
+  const float* kt = a.kt + static_cast<size_t>(b) * a.M * 3;
+  for (int i = tid; i < a.M * 9; i += nthreads) s_H[i] = Hm[i];
+  for (int i = tid; i < a.M * 3; i += nthreads) s_kt[i] = kt[i];
   for (int i = tid; i < a.M * planes * 3; i += nthreads) {
     const int k = i % 3;
     const int dl = (i / 3) % planes;
     const int m = i / (3 * planes);
     const int d = d_begin + dl;
-    s_ktd[i] = (d < a.D) ? s_kt[m * 3 + k] / plane_depth(a.inv_depth_base, a.inv_depth_step, d) : 0.0f;
+    s_ktd[i] = (d < a.D) ? kt[m * 3 + k] / plane_depth(a.inv_depth_base, a.inv_depth_step, d) : 0.0f;
   }
   __syncthreads();
 }
@@ -79,22 +81,20 @@ __device__ inline void sweep_position(const float* Hm, const float* ktd, float x
 }
 
 // Validates the shared arguments of the forward / backward entry points and fills the kernel argument block.
-inline int fill_sweep_args(CostVolumeArgs* a, const float* image1, const float* const* image2s, const float* pose1,
-                           const float* const* pose2s, const float* K, float* out, int B, int M, int C, int H, int W, int D,
-                           double min_depth, double max_depth, bool need_out) {
-  if (!image1 || !image2s || !pose1 || !pose2s || !K || (need_out && !out)) return DVMVS_EINVAL;
+inline int fill_sweep_args(CostVolumeArgs* a, const float* image1, const float* const* image2s, const float* Hm, const float* kt,
+                           float* out, int B, int M, int C, int H, int W, int D, double min_depth, double max_depth, bool need_out) {
+  if (!image1 || !image2s || !Hm || !kt || (need_out && !out)) return DVMVS_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || D <= 0 || M <= 0) return DVMVS_EINVAL;
   if (M > DVMVS_MAX_MEASUREMENTS || D > DVMVS_MAX_DEPTH_LEVELS || B > 65535) return DVMVS_EUNSUPPORTED;
   if (static_cast<long long>(C) * H * W >= (1LL << 31)) return DVMVS_EUNSUPPORTED;
   if (!(min_depth > 0.0) || !(max_depth > 0.0)) return DVMVS_EINVAL;
   a->image1 = image1;
-  a->pose1 = pose1;
-  a->K = K;
+  a->Hm = Hm;
+  a->kt = kt;
   a->out = out;
   for (int m = 0; m < DVMVS_MAX_MEASUREMENTS; ++m) {
-    if (m < M && (!image2s[m] || !pose2s[m])) return DVMVS_EINVAL;
+    if (m < M && !image2s[m]) return DVMVS_EINVAL;
     a->image2[m] = m < M ? image2s[m] : nullptr;
-    a->pose2[m] = m < M ? pose2s[m] : nullptr;
   }
   a->B = B; a->M = M; a->C = C; a->H = H; a->W = W; a->D = D;
   // utils.py:59-60, python doubles

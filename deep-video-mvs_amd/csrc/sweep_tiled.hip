@@ -330,14 +330,13 @@ __device__ inline void tap_plane(const char* tile_bytes, int row_bytes, int addr
 
 // ---- spill groups ------------------------------------------------------------------------------------------------------
 // Spill workspace words: [0] = number of registered groups, [1] = finished workgroups of the second pass, [2..3] unused,
-// then `groups` group ids, then one slot per workgroup of (1 + M * DP + 12 M) words: item count, items, and the workgroup's
-// sweep constants Hm (9) + K t (3) per frame, so that the second pass does not repeat the fp64 pose algebra.  An item packs
+// then `groups` group ids, then one slot per workgroup of (1 + M * DP) words: item count and items.  An item packs
 // (m, seg_lo, seg_len); a workgroup queues its items in (measurement frame, plane) order.
 // The header must be zero when a call starts; the second pass restores that (its last workgroup to finish clears words 0 and
 // 1), so the caller zero-fills a workspace once, when it allocates it, and never again.
 constexpr int kSpillHeaderWords = 4;
 
-__host__ __device__ inline int spill_slot_words(int M, int DP) { return 1 + M * DP + 12 * M; }
+__host__ __device__ inline int spill_slot_words(int M, int DP) { return 1 + M * DP; }
 __device__ inline unsigned int spill_pack(int m, int seg_lo, int seg_len) {
   return (static_cast<unsigned int>(m) << 16) | (static_cast<unsigned int>(seg_lo) << 8) | static_cast<unsigned int>(seg_len);
 }
@@ -425,19 +424,23 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
     const int rank = ((blockIdx.x >> 3) / 32) % 3;
     for (int i = 0; i < rank * Cfg::STAGGER; i += 32) __builtin_amdgcn_s_sleep(32);
   }
-  // ---- per-workgroup tables: Hm = K R K^-1 and K t per measurement frame (fp64 on the first M lanes), K t / depth per plane ----
-  if (tid < a.M) sweep_matrices(a.pose1 + b * 16, a.pose2[tid] + b * 16, a.K + b * 9, s_H + tid * 9, s_kt + tid * 3);
-  __syncthreads();
-  for (int i = tid; i < a.M * DP; i += NT) {
-    const int m = i / DP, j = i - m * DP;
-    float4v k = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (j < planes) {
-      const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j);
-      k.x = s_kt[m * 3 + 0] / depth;
-      k.y = s_kt[m * 3 + 1] / depth;
-      k.z = s_kt[m * 3 + 2] / depth;
+  // ---- per-workgroup tables: the caller's Hm = K R K^-1 and K t per measurement frame, K t / depth per plane (utils.py:66-68) ----
+  {
+    gcfloat_p Hm_g = as_global(a.Hm) + static_cast<size_t>(b) * a.M * 9;
+    gcfloat_p kt_g = as_global(a.kt) + static_cast<size_t>(b) * a.M * 3;
+    for (int i = tid; i < a.M * 9; i += NT) s_H[i] = Hm_g[i];
+    for (int i = tid; i < a.M * 3; i += NT) s_kt[i] = kt_g[i];
+    for (int i = tid; i < a.M * DP; i += NT) {
+      const int m = i / DP, j = i - m * DP;
+      float4v k = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (j < planes) {
+        const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j);
+        k.x = kt_g[m * 3 + 0] / depth;
+        k.y = kt_g[m * 3 + 1] / depth;
+        k.z = kt_g[m * 3 + 2] / depth;
+      }
+      s_ktd[i] = k;
     }
-    s_ktd[i] = k;
   }
   __syncthreads();
 
@@ -709,11 +712,6 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   }
 #endif
   if (!GATHER && n_spilled > 0) {
-    if (tid < a.M * 12) {
-      const int m = tid / 12, k = tid - m * 12;
-      slot[1 + a.M * DP + tid] = __float_as_uint(k < 9 ? s_H[m * 9 + k] : s_kt[m * 3 + (k - 9)]);
-    }
-    __syncthreads();   // the constants are written before the group becomes visible to the second pass (a later launch anyway)
     if (tid == 0) {
       slot[0] = static_cast<unsigned int>(n_spilled);
       const unsigned int at = atomicAdd(a.spill, 1u);
@@ -762,14 +760,14 @@ __global__ __launch_bounds__(Cfg::NT) void sweep_spill_kernel(CostVolumeArgs a) 
       const int m = static_cast<int>(w >> 16), seg_lo = static_cast<int>((w >> 8) & 0xffu), seg_len = static_cast<int>(w & 0xffu);
       if (j < seg_lo || j >= seg_lo + seg_len) continue;   // workgroup-uniform
       if (!live) continue;
-      const guint_p setup = slot + 1 + a.M * DP + m * 12;   // Hm (9) + K t (3), as the first pass used them
+      gcfloat_p Hm_g = as_global(a.Hm) + (static_cast<size_t>(b) * a.M + m) * 9;   // the matrices the first pass used
+      gcfloat_p kt_g = as_global(a.kt) + (static_cast<size_t>(b) * a.M + m) * 3;
       float Hm[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Hm[k] = __uint_as_float(setup[k]);
+      for (int k = 0; k < 9; ++k) Hm[k] = Hm_g[k];
       const SweepRay ray = sweep_ray(Hm, xf, yf);
       const float part = gather_plane<NHWC>(a, as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW, ref, HW, ray,
-                                            __uint_as_float(setup[9]) / depth, __uint_as_float(setup[10]) / depth,
-                                            __uint_as_float(setup[11]) / depth, sc);
+                                            kt_g[0] / depth, kt_g[1] / depth, kt_g[2] / depth, sc);
       if (!touched) value = *out;
       touched = true;
       value += (part / static_cast<float>(a.C)) / static_cast<float>(a.M);   // same scaling order as the first pass
@@ -854,6 +852,7 @@ size_t sweep_spill_words(int B, int M, int H, int W, int D) {
 
 int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream) { return launch_sweep_tiled<SweepDefault>(a, stream); }
 
+#ifdef DVMVS_SWEEP_TUNING   // tools-only builds (`make tuning`, `make trace`); the product library carries the shipped configuration only
 // tuning configurations for tools/cv_microbench.py (TW, TH, DP, CCH, CAP, MINSEG, WAVES, XCD); the spill workspace is sized
 // for the 32x8 and 16x4 tilings, other tile shapes run single-pass (inline gather)
 int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream) {
@@ -881,6 +880,9 @@ int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream) 
     default: return DVMVS_EINVAL;
   }
 }
+#else
+int launch_sweep_tuning(int, const CostVolumeArgs&, hipStream_t) { return DVMVS_EINVAL; }
+#endif
 
 }  // namespace dvmvs
 

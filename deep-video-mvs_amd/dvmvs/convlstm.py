@@ -3,7 +3,8 @@
 Surface of /root/reference/dvmvs/convlstm.py:7-64 (same constructor, ``forward`` and ``init_hidden`` signatures, same
 parameter name ``conv.weight``).  Per step: three HIP launches around one MIOpen convolution --
 
-1. ``dvmvs_relative_pose``   T = inverse(previous_pose) @ current_pose (fp64 on device, no torch.inverse, no sync)
+1. ``dvmvs.pose_algebra``    T = inverse(previous_pose) @ current_pose (the reference's fp32 expression by default; callers that
+                             already hold it -- the frame engine -- pass it as ``transformation``)
 2. ``dvmvs_hidden_warp_fwd`` depth-conditioned warp of h with the ``depth <= 0.01`` zeroing fused in
 3. ``conv``                  3x3, 1024 -> 2048 channels, no bias (MIOpen / rocBLAS)
 4. ``dvmvs_lstm_gates_fwd``  sigmoids, both spatial LayerNorms, CELUs and the cell update in one pass
@@ -12,6 +13,7 @@ import torch
 from torch import nn
 
 from dvmvs.hip import ops as _ops
+from dvmvs import pose_algebra as _pose_algebra
 
 
 class MVSLayernormConvLSTMCell(nn.Module):
@@ -27,10 +29,14 @@ class MVSLayernormConvLSTMCell(nn.Module):
         self.padding = kernel_size[0] // 2, kernel_size[1] // 2
         self.conv = nn.Conv2d(input_dim + hidden_dim, 4 * hidden_dim, kernel_size, padding=self.padding, bias=False)
 
-    def forward(self, input_tensor, cur_state, previous_pose, current_pose, estimated_current_depth, camera_matrix):
+    def forward(self, input_tensor, cur_state, previous_pose, current_pose, estimated_current_depth, camera_matrix,
+                transformation=None):
+        """Reference signature plus the optional ``transformation`` [B,4,4] = inverse(previous_pose) @ current_pose for callers
+        that have already evaluated it (``previous_pose`` must still be non-None to request the warp)."""
         h_cur, c_cur = cur_state
         if previous_pose is not None:
-            transformation = _ops.relative_pose(previous_pose, current_pose)
+            if transformation is None:
+                transformation = _pose_algebra.relative_pose(previous_pose, current_pose, h_cur.device)
             # The reference zeroes h where depth <= 0.01 by writing through .data, i.e. the forward value is masked
             # but the gradient is not; the op's backward reproduces exactly that.
             h_cur = _ops.hidden_warp(h_cur, estimated_current_depth, transformation, camera_matrix, True)

@@ -16,7 +16,12 @@ MI355X-specific execution choices (none of them changes results beyond fp32 roun
   the 2x bilinear up-sampling of the decoder is a HIP kernel (ATen's takes ~80 us on the 512 x 8 x 10 bottleneck map);
 * **hipGraph replay** -- after a warm-up frame (MIOpen solver search) the whole frame is captured once per
   (number of measurement frames, has-previous-state) and replayed; the HIP ops are capture-safe (no host sync,
-  no allocation inside the C ABI), poses / intrinsics / images live in static device buffers.
+  no allocation inside the C ABI), images and the frame's small matrices live in static device buffers;
+* **pose algebra on the host, one upload per frame** -- poses arrive from the host (a tracker, ``poses.txt``); the sweep
+  constants and the two relative poses of the frame are evaluated there with the reference's own fp32 expressions
+  (``dvmvs.pose_algebra``, default mode "reference": the kernels then sample where the reference samples, bit for bit), packed
+  with the intrinsics into one pinned staging slot and sent to the device with a single asynchronous copy ahead of the graph
+  launch.  ``pose_algebra="exact"`` evaluates them on the device in fp64 inside the captured frame instead.
 """
 import copy
 from collections import OrderedDict
@@ -26,7 +31,11 @@ from torch import nn
 
 from dvmvs.config import Config
 from dvmvs.hip import ops as _ops
+from dvmvs import pose_algebra as _pose_algebra
 from dvmvs import utils as _utils
+
+_MAX_MEAS = 8            # DVMVS_MAX_MEASUREMENTS of the C ABI
+_STAGING_SLOTS = 8       # pinned staging ring: the host may run this many frames ahead of the device
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -150,7 +159,8 @@ class DepthEngine:
 
     def __init__(self, feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder,
                  device="cuda", min_depth=0.25, max_depth=20.0, n_depth_levels=64, fold_bn=True, cache_features=True,
-                 use_graphs=True, cache_size=None, channels_last=False, fuse=True, lstm_channels_last=True, sequences=1):
+                 use_graphs=True, cache_size=None, channels_last=False, fuse=True, lstm_channels_last=True, sequences=1,
+                 pose_algebra=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DepthEngine runs on an MI355X; there is no CPU execution path in this package")
@@ -177,6 +187,10 @@ class DepthEngine:
         self.sequences = int(sequences)
         if self.sequences < 1:
             raise ValueError("sequences must be >= 1")
+        self.pose_algebra = _pose_algebra._mode(pose_algebra)
+        self._prev_pose_host = torch.eye(4).repeat(self.sequences, 1, 1)
+        self._no_previous = torch.ones(self.sequences, dtype=torch.bool)   # sequences whose next frame has no previous frame
+        self._ring, self._ring_pos = None, 0
         self._feature_cache = OrderedDict()
         self._graphs = {}
         self._static = None
@@ -193,12 +207,15 @@ class DepthEngine:
         sequences or of one (S > 1)."""
         if sequence is None or self.sequences == 1:
             self.has_previous = False
+            self._no_previous[:] = True
             if self._static is not None:
                 for k in ("h", "c", "prev_depth"):
                     self._static[k].zero_()
-        elif self._static is not None:
-            for k in ("h", "c", "prev_depth"):
-                self._static[k][sequence].zero_()
+        else:
+            self._no_previous[sequence] = True
+            if self._static is not None:
+                for k in ("h", "c", "prev_depth"):
+                    self._static[k][sequence].zero_()
 
     def clear_feature_cache(self):
         self._feature_cache.clear()
@@ -233,13 +250,76 @@ class DepthEngine:
         d, H, W, S = self.device, self.height, self.width, self.sequences
         z = lambda *s: torch.zeros(*s, device=d, dtype=torch.float32)
         if self._static is None:
-            self._static = dict(image=z(S, 3, H, W), pose=z(S, 4, 4), full_K=z(S, 3, 3), half_K=z(S, 3, 3), lstm_K=z(S, 3, 3),
-                                prev_pose=torch.eye(4, device=d).repeat(S, 1, 1), prev_depth=z(S, 1, H, W), h=z(S, 512, H // 32, W // 32),
-                                c=z(S, 512, H // 32, W // 32), meas_feat=[], meas_pose=[],
+            # the frame's small matrices: one device buffer (one upload per frame), fixed offsets so that captured graphs keep
+            # pointing at the right place; Hm / kt are sized for the ABI's maximum number of measurement frames
+            sizes = [("Hm", S * _MAX_MEAS * 9), ("kt", S * _MAX_MEAS * 3), ("reproject_T", S * 16), ("lstm_T", S * 16),
+                     ("full_K", S * 9), ("half_K", S * 9), ("lstm_K", S * 9), ("pose", S * 16), ("prev_pose", S * 16),
+                     ("meas_pose", _MAX_MEAS * S * 16)]
+            self._param_offsets, total = {}, 0
+            for name, n in sizes:
+                self._param_offsets[name] = (total, n)
+                total += n
+            params = z(total)
+            view = lambda name, *shape: params[self._param_offsets[name][0]:self._param_offsets[name][0] + self._param_offsets[name][1]].view(*shape)
+            self._static = dict(image=z(S, 3, H, W), params=params,
+                                reproject_T=view("reproject_T", S, 4, 4), lstm_T=view("lstm_T", S, 4, 4),
+                                full_K=view("full_K", S, 3, 3), half_K=view("half_K", S, 3, 3), lstm_K=view("lstm_K", S, 3, 3),
+                                pose=view("pose", S, 4, 4), prev_pose=view("prev_pose", S, 4, 4),
+                                meas_pose=[view("meas_pose", _MAX_MEAS, S, 4, 4)[i] for i in range(_MAX_MEAS)],
+                                prev_depth=z(S, 1, H, W), h=z(S, 512, H // 32, W // 32),
+                                c=z(S, 512, H // 32, W // 32), meas_feat=[],
                                 ref_half=z(S, 32, H // 2, W // 2), depth=z(S, H, W))
+            self._ring = [(torch.zeros(total, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(_STAGING_SLOTS)]
         while len(self._static["meas_feat"]) < n_meas:
             self._static["meas_feat"].append(z(S, 32, H // 2, W // 2))
-            self._static["meas_pose"].append(z(S, 4, 4))
+
+    def _sweep_views(self, n_meas):
+        """Hm [S,n_meas,9] and kt [S,n_meas,3] views of the parameter buffer (contiguous prefixes of their regions)."""
+        S, p = self.sequences, self._static["params"]
+        o_h, o_k = self._param_offsets["Hm"][0], self._param_offsets["kt"][0]
+        return p[o_h:o_h + S * n_meas * 9].view(S, n_meas, 9), p[o_k:o_k + S * n_meas * 3].view(S, n_meas, 3)
+
+    def _upload_frame_parameters(self, n_meas, pose, measurement_poses, full_K):
+        """Evaluates the frame's small matrices on the host (reference mode) and sends them, the intrinsics and the poses to
+        the device with ONE asynchronous copy out of a pinned staging slot.  The slot's previous copy (issued _STAGING_SLOTS
+        frames ago) must have executed before it is overwritten: its event is waited for, which never blocks in practice."""
+        S = self.sequences
+        host = _pose_algebra._host
+        pose, full_K = host(pose).reshape(S, 4, 4), host(full_K).reshape(S, 3, 3)
+        measurement_poses = [host(p).reshape(S, 4, 4) for p in measurement_poses]
+        half_K, lstm_K = full_K.clone(), full_K.clone()
+        half_K[:, 0:2, :] = half_K[:, 0:2, :] / 2.0       # run-testing.py:139-140
+        lstm_K[:, 0:2, :] = lstm_K[:, 0:2, :] / 32.0      # run-testing.py:142-143
+        # A sequence without a previous frame (S > 1 runs every sequence through the previous-frame path) gets the identity as
+        # relative pose: its previous depth is all zero, and under the identity every zero-depth point stays at z = 0, which the
+        # splat never writes -- an exactly empty depth estimate, as on the reference's first-frame path.
+        previous = torch.where(self._no_previous.view(S, 1, 1), pose, self._prev_pose_host)
+        staging, event = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        event.synchronize()
+
+        def put(name, tensor):
+            o, n = self._param_offsets[name]
+            flat = tensor.reshape(-1)
+            staging[o:o + flat.numel()].copy_(flat)
+
+        if self.pose_algebra == "reference":
+            Hm, kt = _pose_algebra.sweep_matrices_host(pose, measurement_poses, half_K)
+            put("Hm", Hm)
+            put("kt", kt)
+            if self.is_fusionnet:
+                put("reproject_T", _pose_algebra.relative_pose_host(pose, previous))   # utils.py:121
+                put("lstm_T", _pose_algebra.relative_pose_host(previous, pose))        # convlstm.py:30
+        put("full_K", full_K)
+        put("half_K", half_K)
+        put("lstm_K", lstm_K)
+        put("pose", pose)
+        put("prev_pose", previous)
+        put("meas_pose", torch.stack(measurement_poses))
+        self._static["params"].copy_(staging, non_blocking=True)
+        event.record()
+        self._prev_pose_host = pose.clone()
+        self._no_previous[:] = False
 
     def _frame_body(self, n_meas, has_previous):
         """The per-frame computation on the static buffers (this is what gets captured into a hipGraph)."""
@@ -247,14 +327,19 @@ class DepthEngine:
         feats = self._features(s["image"])
         ref_half = feats[0].contiguous()
         s["ref_half"].copy_(ref_half)
-        cost_volume = _ops.cost_volume(ref_half, s["meas_feat"][:n_meas], s["pose"], s["meas_pose"][:n_meas], s["half_K"],
-                                       self.min_depth, self.max_depth, self.n_depth_levels, True, _utils.COST_VOLUME_VARIANT)
+        Hm, kt = self._sweep_views(n_meas)
+        exact = self.pose_algebra == "exact"
+        if exact:
+            Hm, kt = _ops.sweep_matrices(s["pose"], s["meas_pose"][:n_meas], s["half_K"])
+        cost_volume = _ops.cost_volume(ref_half, s["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, self.n_depth_levels,
+                                       True, _utils.COST_VOLUME_VARIANT)
         skip0, skip1, skip2, skip3, bottom = self.enc(ref_half, feats[1], feats[2], feats[3], cost_volume)
         if self.is_fusionnet:
             if has_previous:
-                _, depth_estimation = _ops.depth_reproject_lowres(s["pose"], s["prev_pose"], s["prev_depth"], s["full_K"],
-                                                                  s["half_K"], 16)
-                state = self.lstm(bottom, (s["h"], s["c"]), s["prev_pose"], s["pose"], depth_estimation, s["lstm_K"])
+                reproject_T = _ops.relative_pose(s["pose"], s["prev_pose"]) if exact else s["reproject_T"]
+                lstm_T = _ops.relative_pose(s["prev_pose"], s["pose"]) if exact else s["lstm_T"]
+                _, depth_estimation = _ops.depth_reproject_lowres(reproject_T, s["prev_depth"], s["full_K"], s["half_K"], 16)
+                state = self.lstm(bottom, (s["h"], s["c"]), s["prev_pose"], s["pose"], depth_estimation, s["lstm_K"], transformation=lstm_T)
             else:
                 depth_estimation = torch.zeros(self.sequences, 1, self.height // 32, self.width // 32, device=self.device)
                 state = self.lstm(bottom, None, None, s["pose"], depth_estimation, s["lstm_K"])
@@ -265,22 +350,22 @@ class DepthEngine:
         s["depth"].copy_(prediction)
         if self.is_fusionnet:
             s["prev_depth"].copy_(prediction.view(self.sequences, 1, self.height, self.width))
-            s["prev_pose"].copy_(s["pose"])
 
     # ---- public -----------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, reference_image, reference_pose, measurement_images, measurement_poses, full_K, frame_id=None,
              measurement_ids=None):
-        """One keyframe (of each of the S sequences).  Images [S,3,H,W] normalised, poses [S,4,4] cam-to-world, ``full_K``
-        [S,3,3]; all on the GPU.  With S > 1 the sequences advance in lockstep: ``frame_id`` / ``measurement_ids`` name the
-        step for all of them and a cached feature entry holds all S maps.
+        """One keyframe (of each of the S sequences).  Images [S,3,H,W] normalised, on the GPU; poses [S,4,4] cam-to-world and
+        ``full_K`` [S,3,3] preferably as HOST tensors (that is where they come from, and where the frame's small matrices are
+        evaluated; device tensors are copied back, which synchronises).  With S > 1 the sequences advance in lockstep:
+        ``frame_id`` / ``measurement_ids`` name the step for all of them and a cached feature entry holds all S maps.
 
         ``measurement_images[i]`` may be ``None`` when ``measurement_ids[i]`` is in the feature cache.
         Returns the full-resolution depth [S,H,W] (a static buffer that the next call overwrites: clone to keep).
         """
         n_meas = len(measurement_poses)
-        if n_meas < 1:
-            raise ValueError("need at least one measurement frame")
+        if n_meas < 1 or n_meas > _MAX_MEAS:
+            raise ValueError(f"need between 1 and {_MAX_MEAS} measurement frames")
         measurement_ids = measurement_ids or [None] * n_meas
         self._allocate_static(n_meas)
         s = self._static
@@ -301,16 +386,10 @@ class DepthEngine:
                 half = self._features(img)[0].contiguous()
                 fresh.append((mid, half))
             s["meas_feat"][i].copy_(half)
-            s["meas_pose"][i].copy_(measurement_poses[i])
         for mid, half in fresh:
             self._remember(mid, half)
         s["image"].copy_(reference_image)
-        s["pose"].copy_(reference_pose)
-        s["full_K"].copy_(full_K)
-        s["half_K"].copy_(full_K)
-        s["half_K"][:, 0:2, :] /= 2.0
-        s["lstm_K"].copy_(full_K)
-        s["lstm_K"][:, 0:2, :] /= 32.0
+        self._upload_frame_parameters(n_meas, reference_pose, measurement_poses, full_K)
 
         # S > 1: always the previous-state path (see the class docstring); S == 1: the reference's two frame kinds
         key = (n_meas, (self.has_previous or self.sequences > 1) and self.is_fusionnet)

@@ -24,11 +24,13 @@ class LSTMFusion(nn.Module):
         self.lstm_cell = MVSLayernormConvLSTMCell(input_dim=width, hidden_dim=width, kernel_size=(3, 3),
                                                   activation_function=torch.celu)
 
-    def forward(self, current_encoding, current_state, previous_pose, current_pose, estimated_current_depth, camera_matrix):
+    def forward(self, current_encoding, current_state, previous_pose, current_pose, estimated_current_depth, camera_matrix,
+                transformation=None):
         if current_state is None:
             batch, _, height, width = current_encoding.shape
             current_state = self.lstm_cell.init_hidden(batch_size=batch, image_size=(height, width))
         hidden_state, cell_state = current_state
         return self.lstm_cell(input_tensor=current_encoding, cur_state=[hidden_state, cell_state],
                               previous_pose=previous_pose, current_pose=current_pose,
-                              estimated_current_depth=estimated_current_depth, camera_matrix=camera_matrix)
+                              estimated_current_depth=estimated_current_depth, camera_matrix=camera_matrix,
+                              transformation=transformation)

@@ -16,7 +16,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVMVS_HIP_LIB", os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libdvmvs_hip.so")))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_MEASUREMENTS = 8
 MAX_DEPTH_LEVELS = 256
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
@@ -33,10 +33,11 @@ SIGNATURES = {
     "dvmvs_build_arch": (ctypes.c_char_p, []),
     "dvmvs_error_string": (ctypes.c_char_p, [_c_int]),
     "dvmvs_cost_volume_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int, _c_int]),
-    "dvmvs_cost_volume_fwd": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fpp, _c_fp, _c_fp,
+    "dvmvs_sweep_matrices": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_stream]),
+    "dvmvs_cost_volume_fwd": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fp, _c_fp,
                                        _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                        _c_dbl, _c_dbl, _c_int, _c_int, _c_int, _c_fp, ctypes.c_size_t, _c_stream]),
-    "dvmvs_cost_volume_bwd": (_c_int, [_c_fp, _c_fp, _c_fpp, _c_fp, _c_fpp, _c_fp, _c_fp, _c_fpp,
+    "dvmvs_cost_volume_bwd": (_c_int, [_c_fp, _c_fp, _c_fpp, _c_fp, _c_fp, _c_fp, _c_fpp,
                                        _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                        _c_dbl, _c_dbl, _c_stream]),
     "dvmvs_hidden_warp_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
@@ -44,7 +45,7 @@ SIGNATURES = {
     "dvmvs_relative_pose": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_stream]),
     "dvmvs_lstm_gates_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_lstm_gates_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
-    "dvmvs_depth_reproject_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int,
+    "dvmvs_depth_reproject_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int,
                                            _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_bias_act_inplace": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_upsample2x_fwd": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),

@@ -13,7 +13,7 @@ from torch import Tensor
 
 from dvmvs.hip import _capi
 
-__all__ = ["cost_volume", "hidden_warp", "relative_pose", "lstm_gates", "depth_reproject", "depth_reproject_lowres",
+__all__ = ["cost_volume", "sweep_matrices", "hidden_warp", "relative_pose", "lstm_gates", "depth_reproject", "depth_reproject_lowres",
            "bias_act_", "upsample2x", "depthwise_conv"]
 
 
@@ -43,6 +43,14 @@ def sweep_workspace(device, B, M, H, W, D):
     return entry
 
 
+def drop_sweep_workspace(device, B, M, H, W, D):
+    """Forgets the cached workspace of (device, shape).  Called when a cost-volume call fails: its contract (header words zero
+    between calls) may no longer hold, and a stale group count would silently corrupt every later volume of that shape."""
+    device = torch.device(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    _workspaces.pop((index, B, M, H, W, D), None)
+
+
 def _no_cpu(op):
     raise RuntimeError(f"dvmvs::{op} only runs as a HIP kernel on an MI355X; move the tensors to the GPU. "
                        f"There is deliberately no CPU fallback (the CPU oracle under oracle/ is for tests).")
@@ -67,14 +75,22 @@ def _ptr(t):
 # ----------------------------------------------------------------------------------------------------------------------
 # fused plane-sweep cost volume
 # ----------------------------------------------------------------------------------------------------------------------
+def _check_sweep_matrices(name, Hm, kt, B, M):
+    if tuple(Hm.shape) != (B, M, 9) or tuple(kt.shape) != (B, M, 3):
+        raise ValueError(f"dvmvs::{name}: expected Hm [{B},{M},9] and kt [{B},{M},3] (dvmvs.pose_algebra.sweep_matrices), "
+                         f"got {tuple(Hm.shape)} and {tuple(kt.shape)}")
+
+
 @torch.library.custom_op("dvmvs::cost_volume", mutates_args=(), device_types="cuda")
-def cost_volume(image1: Tensor, image2s: Sequence[Tensor], pose1: Tensor, pose2s: Sequence[Tensor], K: Tensor,
+def cost_volume(image1: Tensor, image2s: Sequence[Tensor], Hm: Tensor, kt: Tensor,
                 min_depth: float, max_depth: float, n_depth_levels: int, dot_product: bool, variant: int) -> Tensor:
-    _dev_f32("cost_volume", image1, pose1, K, *image2s, *pose2s)
+    """``Hm`` [B,M,9] = K R K^-1 and ``kt`` [B,M,3] = K t per (batch item, measurement frame): dvmvs.pose_algebra."""
+    _dev_f32("cost_volume", image1, Hm, kt, *image2s)
     M = len(image2s)
-    if M == 0 or M != len(pose2s):
-        raise ValueError("dvmvs::cost_volume: need as many measurement poses as measurement feature maps (>= 1)")
+    if M == 0:
+        raise ValueError("dvmvs::cost_volume: need at least one measurement feature map")
     B, C, H, W = image1.shape
+    _check_sweep_matrices("cost_volume", Hm, kt, B, M)
     for t in image2s:
         if t.shape != image1.shape:
             raise ValueError(f"dvmvs::cost_volume: measurement features {tuple(t.shape)} != reference {tuple(image1.shape)}")
@@ -84,68 +100,94 @@ def cost_volume(image1: Tensor, image2s: Sequence[Tensor], pose1: Tensor, pose2s
     nhwc_ok = bool(dot_product) and variant != 1 and C % 4 == 0 and C > 1 and H * W >= 64 * 64
     nhwc = nhwc_ok and all(t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous() for t in image2s)
     image2s = list(image2s) if nhwc else [t.contiguous() for t in image2s]
-    pose1 = pose1.contiguous()
-    pose2s = [t.contiguous() for t in pose2s]
-    K = K.contiguous()
+    Hm, kt = Hm.contiguous(), kt.contiguous()
     out = torch.empty((B, n_depth_levels, H, W), dtype=torch.float32, device=image1.device)
     lib = _capi.lib()
     workspace, ws_bytes = sweep_workspace(image1.device, B, M, H, W, n_depth_levels) if COST_VOLUME_TWO_PASS else (None, 0)
     with torch.cuda.device(image1.device):
         rc = lib.dvmvs_cost_volume_fwd(
-            _ptr(image1), _capi.pointer_array([_ptr(t) for t in image2s]), _ptr(pose1),
-            _capi.pointer_array([_ptr(t) for t in pose2s]), _ptr(K), _ptr(out),
+            _ptr(image1), _capi.pointer_array([_ptr(t) for t in image2s]), _ptr(Hm), _ptr(kt), _ptr(out),
             B, M, C, H, W, n_depth_levels, float(min_depth), float(max_depth), int(bool(dot_product)), int(variant),
             _capi.LAYOUT_NHWC if nhwc else _capi.LAYOUT_NCHW, _ptr(workspace) if workspace is not None else None, ws_bytes, _stream(image1))
+    if rc != 0 and workspace is not None:
+        drop_sweep_workspace(image1.device, B, M, H, W, n_depth_levels)
     _capi.check(rc, "dvmvs_cost_volume_fwd")
     return out
 
 
 @cost_volume.register_fake
-def _(image1, image2s, pose1, pose2s, K, min_depth, max_depth, n_depth_levels, dot_product, variant):
+def _(image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant):
     B, C, H, W = image1.shape
     return image1.new_empty((B, n_depth_levels, H, W))
 
 
 @cost_volume.register_kernel("cpu")
-def _(image1, image2s, pose1, pose2s, K, min_depth, max_depth, n_depth_levels, dot_product, variant):
+def _(image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant):
     _no_cpu("cost_volume")
 
 
 def _cost_volume_setup(ctx, inputs, output):
-    image1, image2s, pose1, pose2s, K, min_depth, max_depth, n_depth_levels, dot_product, variant = inputs
+    image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant = inputs
     if not dot_product and (image1.requires_grad or any(t.requires_grad for t in image2s)):
         raise NotImplementedError("dvmvs::cost_volume: gradients are implemented for dot_product=True only")
     ctx.M = len(image2s)
     ctx.depth_range = (min_depth, max_depth, n_depth_levels)
-    ctx.save_for_backward(image1, pose1, K, *image2s, *pose2s)
+    ctx.save_for_backward(image1, Hm, kt, *image2s)
 
 
 def _cost_volume_backward(ctx, grad):
     saved = ctx.saved_tensors
     M = ctx.M
-    image1, pose1, K = saved[0], saved[1], saved[2]
-    image2s, pose2s = list(saved[3:3 + M]), list(saved[3 + M:3 + 2 * M])
+    image1, Hm, kt = saved[0], saved[1], saved[2]
+    image2s = list(saved[3:3 + M])
     min_depth, max_depth, D = ctx.depth_range
     grad = grad.contiguous()
     B, C, H, W = image1.shape
     image1c = image1.contiguous()
     image2c = [t.contiguous() for t in image2s]
-    pose2c = [t.contiguous() for t in pose2s]
     g1 = torch.empty_like(image1c)
     flags = ctx.needs_input_grad[1]   # a tensor-list input: one flag per measurement map
     need2 = any(flags) if isinstance(flags, (list, tuple)) else bool(flags)
     g2 = [torch.zeros_like(t) for t in image2c] if need2 else []
     with torch.cuda.device(image1.device):
         rc = _capi.lib().dvmvs_cost_volume_bwd(
-            _ptr(grad), _ptr(image1c), _capi.pointer_array([_ptr(t) for t in image2c]), _ptr(pose1.contiguous()),
-            _capi.pointer_array([_ptr(t) for t in pose2c]), _ptr(K.contiguous()), _ptr(g1),
-            _capi.pointer_array([_ptr(t) for t in g2] if need2 else [None] * M),
+            _ptr(grad), _ptr(image1c), _capi.pointer_array([_ptr(t) for t in image2c]), _ptr(Hm.contiguous()), _ptr(kt.contiguous()),
+            _ptr(g1), _capi.pointer_array([_ptr(t) for t in g2] if need2 else [None] * M),
             B, M, C, H, W, D, float(min_depth), float(max_depth), _stream(image1))
     _capi.check(rc, "dvmvs_cost_volume_bwd")
-    return g1, (g2 if need2 else [None] * M), None, [None] * M, None, None, None, None, None, None
+    return g1, (g2 if need2 else [None] * M), None, None, None, None, None, None, None
 
 
 torch.library.register_autograd("dvmvs::cost_volume", _cost_volume_backward, setup_context=_cost_volume_setup)
+
+
+@torch.library.custom_op("dvmvs::sweep_matrices", mutates_args=(), device_types="cuda")
+def sweep_matrices(pose1: Tensor, pose2s: Sequence[Tensor], K: Tensor) -> Tuple[Tensor, Tensor]:
+    """"exact" pose algebra: (Hm [B,M,9], kt [B,M,3]) in fp64 on the device, rounded once (dvmvs_sweep_matrices)."""
+    _dev_f32("sweep_matrices", pose1, K, *pose2s)
+    B, M = pose1.shape[0], len(pose2s)
+    if M == 0 or tuple(pose1.shape) != (B, 4, 4) or tuple(K.shape) != (B, 3, 3) or any(tuple(p.shape) != (B, 4, 4) for p in pose2s):
+        raise ValueError("dvmvs::sweep_matrices: expected pose1 [B,4,4], M >= 1 measurement poses [B,4,4] and K [B,3,3]")
+    pose1, K = pose1.contiguous(), K.contiguous()
+    pose2s = [p.contiguous() for p in pose2s]
+    Hm = torch.empty((B, M, 9), dtype=torch.float32, device=pose1.device)
+    kt = torch.empty((B, M, 3), dtype=torch.float32, device=pose1.device)
+    with torch.cuda.device(pose1.device):
+        rc = _capi.lib().dvmvs_sweep_matrices(_ptr(pose1), _capi.pointer_array([_ptr(p) for p in pose2s]), _ptr(K), _ptr(Hm), _ptr(kt),
+                                              B, M, _stream(pose1))
+    _capi.check(rc, "dvmvs_sweep_matrices")
+    return Hm, kt
+
+
+@sweep_matrices.register_fake
+def _(pose1, pose2s, K):
+    B, M = pose1.shape[0], len(pose2s)
+    return pose1.new_empty((B, M, 9)), pose1.new_empty((B, M, 3))
+
+
+@sweep_matrices.register_kernel("cpu")
+def _(pose1, pose2s, K):
+    _no_cpu("sweep_matrices")
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -199,7 +241,7 @@ torch.library.register_autograd("dvmvs::hidden_warp", _hidden_warp_backward, set
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# inverse(a) @ c for 4x4 poses
+# inverse(a) @ c for 4x4 poses, fp64 on the device ("exact" pose algebra; the default path is dvmvs.pose_algebra's host fp32)
 # ----------------------------------------------------------------------------------------------------------------------
 @torch.library.custom_op("dvmvs::relative_pose", mutates_args=(), device_types="cuda")
 def relative_pose(a: Tensor, c: Tensor) -> Tensor:
@@ -276,12 +318,15 @@ torch.library.register_autograd("dvmvs::lstm_gates", _lstm_gates_backward, setup
 # ----------------------------------------------------------------------------------------------------------------------
 # depth re-projection (forward splat)
 # ----------------------------------------------------------------------------------------------------------------------
-def _reproject(name, reference_pose, measurement_pose, previous_depth, full_K, half_K, factor):
-    _dev_f32(name, reference_pose, measurement_pose, previous_depth, full_K, half_K)
+def _reproject(name, transformation, previous_depth, full_K, half_K, factor):
+    _dev_f32(name, transformation, previous_depth, full_K, half_K)
     B, one, Hf, Wf = previous_depth.shape
     if one != 1:
         raise ValueError(f"dvmvs::{name}: previous depth must be [B,1,H,W], got {tuple(previous_depth.shape)}")
-    args = [t.contiguous() for t in (reference_pose, measurement_pose, previous_depth, full_K, half_K)]
+    if tuple(transformation.shape) != (B, 4, 4):
+        raise ValueError(f"dvmvs::{name}: transformation must be [{B},4,4] (inverse(reference_pose) @ measurement_pose), "
+                         f"got {tuple(transformation.shape)}")
+    args = [t.contiguous() for t in (transformation, previous_depth, full_K, half_K)]
     out = torch.empty((B, 1, Hf // 2, Wf // 2), dtype=torch.float32, device=previous_depth.device)
     low = None
     if factor > 0:
@@ -294,41 +339,41 @@ def _reproject(name, reference_pose, measurement_pose, previous_depth, full_K, h
 
 
 @torch.library.custom_op("dvmvs::depth_reproject", mutates_args=(), device_types="cuda")
-def depth_reproject(reference_pose: Tensor, measurement_pose: Tensor, previous_depth: Tensor, full_K: Tensor,
-                    half_K: Tensor) -> Tensor:
-    return _reproject("depth_reproject", reference_pose, measurement_pose, previous_depth, full_K, half_K, 0)[0]
+def depth_reproject(transformation: Tensor, previous_depth: Tensor, full_K: Tensor, half_K: Tensor) -> Tensor:
+    """``transformation`` [B,4,4] = inverse(reference_pose) @ measurement_pose (dvmvs.pose_algebra.relative_pose)."""
+    return _reproject("depth_reproject", transformation, previous_depth, full_K, half_K, 0)[0]
 
 
 @depth_reproject.register_fake
-def _(reference_pose, measurement_pose, previous_depth, full_K, half_K):
+def _(transformation, previous_depth, full_K, half_K):
     B, _, Hf, Wf = previous_depth.shape
     return previous_depth.new_empty((B, 1, Hf // 2, Wf // 2))
 
 
 @depth_reproject.register_kernel("cpu")
-def _(reference_pose, measurement_pose, previous_depth, full_K, half_K):
+def _(transformation, previous_depth, full_K, half_K):
     _no_cpu("depth_reproject")
 
 
 @torch.library.custom_op("dvmvs::depth_reproject_lowres", mutates_args=(), device_types="cuda")
-def depth_reproject_lowres(reference_pose: Tensor, measurement_pose: Tensor, previous_depth: Tensor, full_K: Tensor,
-                           half_K: Tensor, factor: int) -> Tuple[Tensor, Tensor]:
+def depth_reproject_lowres(transformation: Tensor, previous_depth: Tensor, full_K: Tensor, half_K: Tensor,
+                           factor: int) -> Tuple[Tensor, Tensor]:
     """Splat plus the nearest /factor decimation the fusionnet call site applies next (one C-ABI call)."""
     if factor <= 0:
         raise ValueError("dvmvs::depth_reproject_lowres: factor must be positive")
-    out, low = _reproject("depth_reproject_lowres", reference_pose, measurement_pose, previous_depth, full_K, half_K, factor)
+    out, low = _reproject("depth_reproject_lowres", transformation, previous_depth, full_K, half_K, factor)
     return out, low
 
 
 @depth_reproject_lowres.register_fake
-def _(reference_pose, measurement_pose, previous_depth, full_K, half_K, factor):
+def _(transformation, previous_depth, full_K, half_K, factor):
     B, _, Hf, Wf = previous_depth.shape
     return (previous_depth.new_empty((B, 1, Hf // 2, Wf // 2)),
             previous_depth.new_empty((B, 1, (Hf // 2) // factor, (Wf // 2) // factor)))
 
 
 @depth_reproject_lowres.register_kernel("cpu")
-def _(reference_pose, measurement_pose, previous_depth, full_K, half_K, factor):
+def _(transformation, previous_depth, full_K, half_K, factor):
     _no_cpu("depth_reproject_lowres")
 
 

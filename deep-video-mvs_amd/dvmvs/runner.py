@@ -52,8 +52,8 @@ def _run_frame(engine, scene, timer, device, reference_index, measurement_indice
     raw = images[reference_index] if images is not None and reference_index in images else scene.image(reference_index)
     pre = _preprocessor(scene, raw)
     ref_image = _to_device(pre.apply_rgb(raw, SCALE_RGB, MEAN_RGB, STD_RGB), device)
-    ref_pose = torch.from_numpy(scene.poses[reference_index]).float().unsqueeze(0).to(device)
-    full_K = torch.from_numpy(pre.get_updated_intrinsics()).float().unsqueeze(0).to(device)
+    ref_pose = torch.from_numpy(scene.poses[reference_index]).float().unsqueeze(0)   # poses / K stay on the host (engine.step)
+    full_K = torch.from_numpy(pre.get_updated_intrinsics()).float().unsqueeze(0)
     meas_images, meas_poses = [], []
     for m in measurement_indices:
         if engine.cache_features and m in engine._feature_cache:
@@ -61,7 +61,7 @@ def _run_frame(engine, scene, timer, device, reference_index, measurement_indice
         else:
             raw_m = images[m] if images is not None and m in images else scene.image(m)
             meas_images.append(_to_device(pre.apply_rgb(raw_m, SCALE_RGB, MEAN_RGB, STD_RGB), device))
-        meas_poses.append(torch.from_numpy(scene.poses[m]).float().unsqueeze(0).to(device))
+        meas_poses.append(torch.from_numpy(scene.poses[m]).float().unsqueeze(0))
     timer.record_start_time()
     depth = engine.step(ref_image, ref_pose, meas_images, meas_poses, full_K, frame_id=reference_index,
                         measurement_ids=list(measurement_indices))
@@ -145,6 +145,9 @@ def predict_sharded(make_engine, scene_folders, keyframe_index_files, evaluate=T
     results = run_sharded(len(scene_folders), run_scene, rank=rank, world=world)
     seconds = time.perf_counter() - t0
     frames = sum(len(r[0]) for r in results.values())
-    device = state["engine"].device if state["engine"] is not None and torch.distributed.is_initialized() and \
-        torch.distributed.get_backend() == "nccl" else "cpu"
+    # The reduction's device follows the BACKEND, not whether this rank built an engine: a rank that owns no scene (more ranks
+    # than scenes) must still join an RCCL collective with a device tensor, or every other rank blocks in all_reduce.
+    device = "cpu"
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
     return results, reduce_throughput(frames, seconds, device=device)

@@ -18,6 +18,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from dvmvs.config import Config
+from dvmvs.pose_algebra import _host
 from dvmvs.utils import calculate_cost_volume_by_warping, get_warp_grid_for_cost_volume_calculation
 
 
@@ -53,9 +54,12 @@ def fusionnet_subsequence_loss(model, images, depths, poses, K, warp_grid=None):
     Returns (loss summed over frames 1..n-1, list of full-resolution predictions)."""
     fe, fs, enc, lstm, dec = model
     B, _, H, W = images[0].shape
-    half_K = K.clone()
+    # poses and the sweep's intrinsics are only read by the small pose algebra (dvmvs.pose_algebra), which by default runs on the
+    # host: hold them there once per step instead of copying them back once per frame
+    poses = [_host(p) for p in poses]
+    half_K = _host(K).clone()
     half_K[:, 0:2, :] = half_K[:, 0:2, :] * 0.5
-    lstm_K = K.clone()
+    lstm_K = K.to(images[0].device).clone()
     lstm_K[:, 0:2, :] = lstm_K[:, 0:2, :] / 32.0
     if warp_grid is None:
         warp_grid = get_warp_grid_for_cost_volume_calculation(W // 2, H // 2, images[0].device)
@@ -100,12 +104,11 @@ def forward_pass(images, depths, poses, K, model, is_training):
     device = next(fe.parameters()).device
     images = [t.to(device) for t in images]
     depths = [t.to(device) for t in depths]
-    poses = [t.to(device) for t in poses]
-    K = K.to(device)
+    poses = [_host(t) for t in poses]          # read by the host-side pose algebra only (dvmvs.pose_algebra)
     B, _, H, W = images[0].shape
-    half_K = K.clone()
+    half_K = _host(K).clone()
     half_K[:, 0:2, :] = half_K[:, 0:2, :] * 0.5
-    lstm_K = K.clone()
+    lstm_K = K.to(device).clone()
     lstm_K[:, 0:2, :] = lstm_K[:, 0:2, :] / 32.0
     warp_grid = get_warp_grid_for_cost_volume_calculation(W // 2, H // 2, device)
     feats = [fs(*fe(img)) for img in images]

@@ -14,6 +14,10 @@ get_non_differentiable_rectangle_depth_estimation    dvmvs_depth_reproject_fwd (
 warp_frame_depth                  :205-258           dvmvs_hidden_warp_fwd
 ===================================================  ==========================================================
 
+The few 3x3 / 4x4 matrices these functions derive from the poses (utils.py:51-56, :121) are evaluated by
+``dvmvs.pose_algebra`` -- by default with the reference's own fp32 expressions, so that the kernels sample at the
+reference's positions bit for bit -- and handed to the kernels as device arrays.
+
 There is no CPU implementation in this package; CPU tensors raise.  ``cv2``/``kornia``/``path``/``pytorch3d`` are
 not imported.
 """
@@ -25,6 +29,7 @@ import numpy as np
 import torch
 
 from dvmvs.hip import ops as _ops
+from dvmvs import pose_algebra as _pose_algebra
 
 # kernel selector for the cost volume: 0 = automatic, 1 = generic reference-order kernel, 2 = tap-reuse kernel
 COST_VOLUME_VARIANT = int(os.environ.get("DVMVS_COST_VOLUME_VARIANT", "0"))
@@ -75,8 +80,12 @@ def cost_volume_fusion(image1, image2s, pose1, pose2s, K, warp_grid, min_depth, 
     computation happens where the tensors live (which must be the GPU).
     """
     _check_warp_grid(warp_grid, image1.shape[2], image1.shape[3])
-    return _ops.cost_volume(image1, list(image2s), pose1, list(pose2s), K, float(min_depth), float(max_depth),
-                            int(n_depth_levels), bool(dot_product), COST_VOLUME_VARIANT)
+    image2s, pose2s = list(image2s), list(pose2s)
+    if len(image2s) == 0 or len(image2s) != len(pose2s):
+        raise ValueError("cost_volume_fusion: need as many measurement poses as measurement feature maps (>= 1)")
+    Hm, kt = _pose_algebra.sweep_matrices(pose1, pose2s, K, image1.device)
+    return _ops.cost_volume(image1, image2s, Hm, kt, float(min_depth), float(max_depth), int(n_depth_levels), bool(dot_product),
+                            COST_VOLUME_VARIANT)
 
 
 def calculate_cost_volume_by_warping(image1, image2, pose1, pose2, K, warp_grid, min_depth, max_depth, n_depth_levels,
@@ -93,8 +102,8 @@ def get_non_differentiable_rectangle_depth_estimation(reference_pose_torch, meas
     if (H, W) != (int(original_height), int(original_width)):
         raise ValueError(f"previous depth is {W}x{H} but original size was given as {original_width}x{original_height}")
     with torch.no_grad():
-        return _ops.depth_reproject(reference_pose_torch, measurement_pose_torch, previous_depth_torch, full_K_torch,
-                                    half_K_torch)
+        transformation = _pose_algebra.relative_pose(reference_pose_torch, measurement_pose_torch, previous_depth_torch.device)
+        return _ops.depth_reproject(transformation, previous_depth_torch, full_K_torch, half_K_torch)
 
 
 def warp_frame_depth(image_src, depth_dst, src_trans_dst, camera_matrix, normalize_points=False, sampling_mode="bilinear"):

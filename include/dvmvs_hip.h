@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DVMVS_ABI_VERSION 2
+#define DVMVS_ABI_VERSION 3
 #define DVMVS_MAX_MEASUREMENTS 8      /* measurement frames fused per launch */
 #define DVMVS_MAX_DEPTH_LEVELS 256    /* sweep planes per launch */
 
@@ -42,20 +42,45 @@ const char* dvmvs_build_arch(void);   /* "gfx950" */
 const char* dvmvs_error_string(int code);
 
 /*
+ * Small pose algebra: WHERE IT IS EVALUATED, AND WHY IT IS AN ARGUMENT (ABI 3).
+ *
+ * The reference derives three tiny matrices per frame from the camera poses with fp32 torch ops on the host side of its
+ * hot functions:
+ *   sweep constants   E = inverse(pose2) * pose1,  Hm = K R K^-1,  kt = K t        (/root/reference/dvmvs/utils.py:51-56)
+ *   splat transform   inverse(reference_pose) * measurement_pose                   (utils.py:121)
+ *   warp transform    inverse(previous_pose) * current_pose                        (dvmvs/convlstm.py:30)
+ * Their fp32 round-off (cancellation in the relative translation, ~5e-7 m) moves sample positions by up to 3e-4 px on the
+ * nearest plane -- more than everything else on the path together -- so "results identical to the reference" requires
+ * the very same matrices.  The entry points below therefore take them as DEVICE ARRAYS, computed by the caller exactly as
+ * the reference computes them (the Python surface does it with the reference's own torch expressions, see
+ * deep-video-mvs_amd/dvmvs/pose_algebra.py), and do no pose algebra themselves.
+ *   Hm  [B,M,9]   row-major 3x3 per (batch item, measurement frame)
+ *   kt  [B,M,3]
+ * For callers that prefer accuracy over bit-parity (or want no host involvement at all) dvmvs_sweep_matrices and
+ * dvmvs_relative_pose evaluate the same algebra on the device in fp64 and round once ("exact" mode).
+ */
+
+/*
+ * Hm[b,m] = K[b] R K[b]^-1, kt[b,m] = K[b] t with [R|t] = inverse(pose2s[m][b]) * pose1[b]; fp64 on the device, rounded once.
+ * Opt-in alternative to the reference's fp32 host algebra (utils.py:51-56).
+ *   pose1 [B,4,4]   pose2s host array of M device pointers, each [B,4,4]   K [B,3,3]   Hm [B,M,9] out   kt [B,M,3] out
+ */
+int dvmvs_sweep_matrices(const float* pose1, const float* const* pose2s, const float* K, float* Hm, float* kt,
+                         int B, int M, dvmvs_stream_t stream);
+
+/*
  * Fused plane-sweep warp + feature correlation over all planes and all measurement frames, written once.
  * Replaces dvmvs.utils.calculate_cost_volume_by_warping (M == 1) and dvmvs.utils.cost_volume_fusion (M >= 1):
- *   /root/reference/dvmvs/utils.py:45-86 and :89-107.
+ *   /root/reference/dvmvs/utils.py:45-86 and :89-107 (everything after the small pose algebra of :51-56, see above).
  *
  *   image1      [B,C,H,W]   reference-frame features
  *   image2s     host array of M device pointers, each [B,C,H,W] measurement-frame features
- *   pose1       [B,4,4]     reference camera-to-world pose
- *   pose2s      host array of M device pointers, each [B,4,4]
- *   K           [B,3,3]     intrinsics at the feature resolution
+ *   Hm          [B,M,9]     K R K^-1 per (batch item, measurement frame)
+ *   kt          [B,M,3]     K t
  *   cost_volume [B,D,H,W]   out; plane 0 = max_depth ... plane D-1 = min_depth, uniform in inverse depth
  *   dot_product 1: sum_c(f1*warp(f2))/C   0: sum_c|f1-warp(f2)|  (utils.py:81-84); result is the mean over M
  *   variant     0 = pick the fastest kernel for the shape; 1 = force the generic reference-order kernel (taps through
- *               the vector L1); 2 = force the LDS-tiled sweep (dot_product only); 32.. = tuning configurations of the
- *               sweep for tools/cv_microbench.py, not part of the stable interface
+ *               the vector L1); 2 = force the LDS-tiled sweep (dot_product only)
  *   image2_layout DVMVS_LAYOUT_NCHW, or DVMVS_LAYOUT_NHWC when the MEASUREMENT maps are stored channels-last (a keyframe's
  *               features are reused as measurement features by later frames, so a runner converts them once per
  *               keyframe).  Supported by the LDS-tiled dot-product kernel (C % 4 == 0, H*W >= 4096); image1 and
@@ -68,13 +93,10 @@ const char* dvmvs_error_string(int code);
  *               owner zero-fills the buffer once, when it allocates it; a buffer must not be shared by calls that may
  *               overlap in time (different streams).  With workspace == NULL (or too small) such runs are gathered inline
  *               by the sweep kernel itself (one launch, long tail on wide-baseline / forward-motion pairs).
- *   All pose algebra (inverse(pose2) * pose1, K R K^-1, K t: utils.py:51-56) is evaluated on the device, in fp64, by the
- *   kernels themselves: no host round trip and no set-up launch.
  */
 size_t dvmvs_cost_volume_workspace_bytes(int B, int M, int H, int W, int D);
-int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, const float* pose1,
-                          const float* const* pose2s, const float* K, float* cost_volume,
-                          int B, int M, int C, int H, int W, int D,
+int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, const float* Hm, const float* kt,
+                          float* cost_volume, int B, int M, int C, int H, int W, int D,
                           double min_depth, double max_depth, int dot_product, int variant, int image2_layout,
                           float* workspace, size_t workspace_bytes, dvmvs_stream_t stream);
 
@@ -82,13 +104,13 @@ int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, cons
  * Gradient of the fused cost volume (dot_product mode) w.r.t. both feature maps; poses/K carry no gradient
  * (autograd through utils.py:75-82; the sampling grid is data).
  *   grad_cost   [B,D,H,W]
+ *   Hm, kt      as for the forward
  *   grad_image1 [B,C,H,W]   out (overwritten)
  *   grad_image2s host array of M device pointers, each [B,C,H,W]; MUST be zero-filled by the caller
  *               (accumulated with atomics); an entry may be NULL to skip that frame's gradient.
  */
 int dvmvs_cost_volume_bwd(const float* grad_cost, const float* image1, const float* const* image2s,
-                          const float* pose1, const float* const* pose2s, const float* K,
-                          float* grad_image1, float* const* grad_image2s,
+                          const float* Hm, const float* kt, float* grad_image1, float* const* grad_image2s,
                           int B, int M, int C, int H, int W, int D,
                           double min_depth, double max_depth, dvmvs_stream_t stream);
 
@@ -115,8 +137,8 @@ int dvmvs_hidden_warp_bwd(const float* grad_out, const float* depth_dst, const f
                           dvmvs_stream_t stream);
 
 /*
- * out[b] = inverse(a[b]) * c[b] for 4x4 matrices (evaluated in fp64, rounded once to fp32).
- * Replaces torch.bmm(torch.inverse(previous_pose), current_pose): dvmvs/convlstm.py:30, utils.py:51,:121.
+ * out[b] = inverse(a[b]) * c[b] for 4x4 matrices (evaluated in fp64, rounded once to fp32): the "exact" alternative to
+ * the reference's fp32 torch.bmm(torch.inverse(previous_pose), current_pose) (dvmvs/convlstm.py:30, utils.py:121).
  */
 int dvmvs_relative_pose(const float* a, const float* c, float* out, int B, dvmvs_stream_t stream);
 
@@ -142,14 +164,14 @@ int dvmvs_lstm_gates_bwd(const float* grad_h, const float* grad_c, const float* 
  * Forward splat (z-buffer, farthest wins) of the previous full-resolution depth into the current view at half
  * resolution; untouched pixels are 0.  No host round trip, order-independent (atomic max on the float bits).
  * Replaces dvmvs.utils.get_non_differentiable_rectangle_depth_estimation (/root/reference/dvmvs/utils.py:110-154).
- *   reference_pose, measurement_pose [B,4,4]   previous_depth [B,1,Hf,Wf]   full_K, half_K [B,3,3]
+ *   transformation [B,4,4]  inverse(reference_pose) * measurement_pose (utils.py:121), computed by the caller (see above)
+ *   previous_depth [B,1,Hf,Wf]   full_K, half_K [B,3,3]
  *   out [B,1,Hf/2,Wf/2]  (zeroed by this call)
  * If out_lowres != NULL it also receives the nearest-neighbour down-sampling by `lowres_factor` that the call
  * site applies next (fusionnet/run-testing.py:187-189): [B,1,(Hf/2)/f,(Wf/2)/f].
  */
-int dvmvs_depth_reproject_fwd(const float* reference_pose, const float* measurement_pose,
-                              const float* previous_depth, const float* full_K, const float* half_K,
-                              float* out, float* out_lowres, int lowres_factor,
+int dvmvs_depth_reproject_fwd(const float* transformation, const float* previous_depth, const float* full_K,
+                              const float* half_K, float* out, float* out_lowres, int lowres_factor,
                               int B, int full_height, int full_width, dvmvs_stream_t stream);
 
 /*

@@ -321,6 +321,52 @@ def end_to_end_goldens(ref):
     save("pairnet_e2e", **parr)
 
 
+def long_sequence_goldens(ref):
+    """The REFERENCE's fusionnet loop (fusionnet/run-testing.py:86-101,151-204) over syn.LONG_SCHEDULE: 14 keyframes of the
+    sample scene's nmeas+2 index incl. a "TRACKING LOST" and the wide-baseline lines, same seeded weights + BatchNorm statistics
+    as the 3-frame golden.  Stored per frame: the depth (4x sub-sampled), the 8x10 depth estimate fed to the ConvLSTM, the
+    number of z-buffer pixels of the half-resolution re-projection, sampled cost-volume / hidden-state entries."""
+    m = ref.fusionnet_model
+    ctors = (m.FeatureExtractor, m.FeatureShrinker, m.CostVolumeEncoder, m.LSTMFusion, m.CostVolumeDecoder)
+    fe, fs, enc, lstm, dec = syn.build_e2e_modules(ctors, with_bn_stats=True)
+    for mod in (fe, fs, enc, lstm, dec):
+        mod.eval()
+    fullK = syn.full_K()
+    halfK = syn.scaled_K(fullK, 2.0)
+    lK = syn.scaled_K(fullK, 32.0)
+    grid = ref.utils.get_warp_grid_for_cost_volume_calculation(160, 128, CPU)
+    lines = syn.keyframe_index_lines(2)
+    arrays = {"schedule": np.array([-1 if item is None else item for item in syn.LONG_SCHEDULE])}
+    lstm_state, prev_depth, prev_pose = None, None, None
+    with torch.no_grad():
+        for n, item in enumerate(syn.LONG_SCHEDULE):
+            if item is None:                                  # run-testing.py:97-101
+                lstm_state, prev_depth, prev_pose = None, None, None
+                continue
+            r, ms = lines[item]
+            meas_feats = [fs(*fe(syn.e2e_image(i)))[0] for i in ms]
+            ref_feats = fs(*fe(syn.e2e_image(r)))
+            cv = ref.utils.cost_volume_fusion(ref_feats[0], meas_feats, syn.pose(r), [syn.pose(i) for i in ms], halfK, grid,
+                                              0.25, 20.0, 64, CPU, True)
+            skip0, skip1, skip2, skip3, bottom = enc(*ref_feats, cv)
+            if prev_depth is not None:
+                de_half = ref.utils.get_non_differentiable_rectangle_depth_estimation(syn.pose(r), prev_pose, prev_depth, fullK, halfK, 320, 256)
+                de = torch.nn.functional.interpolate(de_half, scale_factor=1.0 / 16.0, mode="nearest")
+            else:
+                de_half, de = torch.zeros(1, 1, 128, 160), torch.zeros(1, 1, 8, 10)
+            lstm_state = lstm(bottom, lstm_state, prev_pose, syn.pose(r), de, lK)
+            pred = dec(syn.e2e_image(r), skip0, skip1, skip2, skip3, lstm_state[0])[0]
+            prev_depth, prev_pose = pred.view(1, 1, 256, 320), syn.pose(r)
+            arrays[f"s{n}_depth_sub4"] = pred[0, ::4, ::4]
+            arrays[f"s{n}_depth_estimation"] = de
+            arrays[f"s{n}_estimate_half_nonzero"] = int((de_half != 0).sum())
+            arrays[f"s{n}_cost_volume_samples"] = cv.reshape(-1)[syn.sample_indices(cv.numel())]
+            arrays[f"s{n}_h_samples"] = lstm_state[0].reshape(-1)[syn.sample_indices(lstm_state[0].numel())]
+            print(f"long sequence step {n} (index line {item}: {r} <- {ms}): depth {pred.min().item():.3f} .. {pred.max().item():.3f}, "
+                  f"estimate pixels {int((de != 0).sum())}/80")
+    save("fusionnet_long", **arrays)
+
+
 def keyframe_goldens(ref):
     """Replays the reference KeyframeBuffer over the sample poses; must reproduce the shipped index files."""
     poses = syn.sample_poses()
@@ -442,10 +488,14 @@ def main():
     if "--only-losses" in sys.argv:
         loss_goldens(ref)
         return
+    if "--only-long-sequence" in sys.argv:
+        long_sequence_goldens(ref)
+        return
     cost_volume_goldens(ref)
     de16 = reprojection_goldens(ref)
     lstm_goldens(ref, de16)
     end_to_end_goldens(ref)
+    long_sequence_goldens(ref)
     keyframe_goldens(ref)
     error_metric_goldens(ref)
     loss_goldens(ref)

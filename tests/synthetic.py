@@ -216,6 +216,24 @@ def build_e2e_modules(constructors, with_bn_stats=True):
 E2E_FRAMES = ((9, (6, 0)), (10, (9, 6)), (11, (9, 10)))
 
 
+# Long reference-run sequence (tests/golden/fusionnet_long.npz): lines of the sample scene's nmeas+2 keyframe index, None =
+# "TRACKING LOST" (fusionnet/run-testing.py:97-101).  Openings, a tracking loss, an easy stretch, the wide-baseline lines
+# 200-204 whose footprints spill, and 249-251.
+LONG_SCHEDULE = (0, 1, 2, None, 117, 118, 119, 200, 201, 202, 203, 204, 249, 250, 251)
+
+
+def keyframe_index_lines(n_meas=2):
+    """[(reference pose index, (measurement pose indices))] of the committed keyframe index, "TRACKING LOST" lines dropped."""
+    names = {n: i for i, n in enumerate(sample_image_names())}
+    out = []
+    with open(os.path.join(GOLDEN_DIR, "indices", f"keyframe+hololens-dataset+000+nmeas+{n_meas}")) as f:
+        for line in f:
+            parts = line.split()
+            if len(parts) == n_meas + 1 and all(p in names for p in parts):
+                out.append((names[parts[0]], tuple(names[p] for p in parts[1:])))
+    return out
+
+
 def sample_image_names():
     """Sorted image file names of the sample scene (row i of poses.txt belongs to the i-th name)."""
     with open(os.path.join(GOLDEN_DIR, "hololens_000_image_names.txt")) as f:

@@ -29,7 +29,7 @@ def test_header_declares_the_four_ops():
     syms = declared_symbols()
     for op in ("cost_volume", "hidden_warp", "lstm_gates"):
         assert f"dvmvs_{op}_fwd" in syms and f"dvmvs_{op}_bwd" in syms
-    assert "dvmvs_depth_reproject_fwd" in syms and "dvmvs_relative_pose" in syms
+    assert "dvmvs_depth_reproject_fwd" in syms and "dvmvs_relative_pose" in syms and "dvmvs_sweep_matrices" in syms
 
 
 def test_library_exports_every_declared_symbol(library):
@@ -54,16 +54,18 @@ def test_argument_validation_without_gpu(library):
     assert lib.dvmvs_lstm_gates_fwd(null, null, null, null, 1, 512, 8, 10, null) == -1
     assert lib.dvmvs_hidden_warp_fwd(null, null, null, null, null, 1, 512, 8, 10, 1, null) == -1
     arr = library.pointer_array([None])
-    assert lib.dvmvs_cost_volume_fwd(null, arr, null, arr, null, null, 1, 1, 32, 128, 160, 64, 0.25, 20.0, 1, 0, 0, null, 0, null) == -1
+    assert lib.dvmvs_cost_volume_fwd(null, arr, null, null, null, 1, 1, 32, 128, 160, 64, 0.25, 20.0, 1, 0, 0, null, 0, null) == -1
+    assert lib.dvmvs_sweep_matrices(null, arr, null, null, null, 1, 1, null) == -1
+    assert lib.dvmvs_depth_reproject_fwd(null, null, null, null, null, null, 16, 1, 256, 320, null) == -1
     assert lib.dvmvs_cost_volume_workspace_bytes(0, 3, 128, 160, 64) == 0
 
 
 def test_workspace_sizes(library):
     lib = library.lib()
-    # spill workspace of the two-pass sweep: 4 header words + per workgroup one id and one slot of (1 + 8 M + 12 M) words,
+    # spill workspace of the two-pass sweep: 4 header words + per workgroup one id and one slot of (1 + 8 M) words,
     # sized for the finest tiling that may use it (16x4-pixel tiles x 8-plane chunks)
     groups = (160 // 16) * (128 // 4) * 8
-    assert lib.dvmvs_cost_volume_workspace_bytes(1, 2, 128, 160, 64) == 4 * (4 + groups + groups * (1 + 2 * 8 + 2 * 12))
+    assert lib.dvmvs_cost_volume_workspace_bytes(1, 2, 128, 160, 64) == 4 * (4 + groups + groups * (1 + 2 * 8))
     assert lib.dvmvs_cost_volume_workspace_bytes(0, 2, 128, 160, 64) == 0
     assert lib.dvmvs_cost_volume_workspace_bytes(2, 3, 33, 47, 10) > 0
 

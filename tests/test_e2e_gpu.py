@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+import hipcall
 import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -50,6 +51,7 @@ def build(dev, fusion=True, **kw):   # kw: DepthEngine options (fold_bn, cache_f
 # (b) engine-vs-reference <= the sum of the two noise floors (2.5e-4), on every frame whose re-projected depth estimate
 # agrees with the reference's; frames where that discrete input differs are only sanity-bounded (1e-2).
 REL_L1_TARGET = 1e-4
+ENGINE_VS_REFERENCE = 2.5e-4      # provisional: two float32 evaluations of ~50 convolution layers (MIOpen vs oneDNN summation order)
 
 
 @pytest.mark.parametrize("mode", ["eager_unfolded", "graphs_folded_cached"])
@@ -58,7 +60,7 @@ def test_fusionnet_three_frames_match_the_reference(hip_device, golden_dir, mode
     dev = hip_device
     fast = mode == "graphs_folded_cached"
     mods, engine = build(dev, fusion=True, fold_bn=fast, cache_features=fast, use_graphs=fast)
-    fullK = syn.full_K().to(dev)
+    fullK = syn.full_K()          # poses and intrinsics stay on the host: that is where the engine evaluates the small matrices
     report = []
     # with graphs the first frame of each kind runs eagerly and the next replays: run the sequence twice so that
     # the second pass exercises captured graphs for both frame kinds, and check both passes
@@ -66,7 +68,7 @@ def test_fusionnet_three_frames_match_the_reference(hip_device, golden_dir, mode
         engine.reset()
         for n, (r, ms) in enumerate(syn.E2E_FRAMES):
             images = [syn.e2e_image(i).to(dev) for i in ms]
-            depth = engine.step(syn.e2e_image(r).to(dev), syn.pose(r).to(dev), images, [syn.pose(i).to(dev) for i in ms], fullK,
+            depth = engine.step(syn.e2e_image(r).to(dev), syn.pose(r), images, [syn.pose(i) for i in ms], fullK,
                                 frame_id=r, measurement_ids=list(ms))
             s = engine._static
             pins_close(s["ref_half"], z, f"f{n}_feat_half", 2e-5)
@@ -76,8 +78,8 @@ def test_fusionnet_three_frames_match_the_reference(hip_device, golden_dir, mode
             report.append((sweep, n, vs_ref, vs_f64, ref_vs_f64))
             same_estimate = True
             if n > 0:
-                _, low = __import__("dvmvs.hip.ops", fromlist=["x"]).depth_reproject_lowres(
-                    syn.pose(r).to(dev), syn.pose(syn.E2E_FRAMES[n - 1][0]).to(dev), prev_depth, fullK, syn.scaled_K(fullK, 2.0), 16)
+                _, low = hipcall.depth_reproject(__import__("dvmvs.hip.ops", fromlist=["x"]), syn.pose(r), syn.pose(syn.E2E_FRAMES[n - 1][0]),
+                                                 prev_depth, fullK.to(dev), syn.scaled_K(fullK, 2.0).to(dev), 16)
                 exp_low = z[f"f{n}_depth_estimation_full"]
                 same_estimate = bool(np.all(np.abs(low.cpu().numpy() - exp_low) <= 1e-3 * np.maximum(exp_low, 1e-3)))
             prev_depth = depth.clone().view(1, 1, 256, 320)
@@ -97,12 +99,58 @@ def test_fusionnet_three_frames_match_the_reference(hip_device, golden_dir, mode
     assert report[0][2] <= 2.5 * REL_L1_TARGET
 
 
+def test_fusionnet_long_reference_run(hip_device, golden_dir):
+    """The engine as benchmarked (BN folded, feature cache, hipGraph replay) over the REFERENCE's 14-keyframe run
+    (tests/golden/fusionnet_long.npz: tracking loss, wide-baseline lines 200-204, 249-251).  Per frame: depth rel-L1 vs the
+    reference and the number of low-resolution estimate pixels that differ from the reference's.  What separates the two runs
+    is the convolutions' float32 summation order (MIOpen vs the reference's oneDNN) and nothing on the hot path
+    (tests/test_hybrid_parity.py holds the convolutions fixed and gets ~1e-6 with 0 flipped pixels on the same run)."""
+    import json
+    from dvmvs.hip import ops
+    z = np.load(os.path.join(golden_dir, "fusionnet_long.npz"))
+    dev = hip_device
+    mods, engine = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
+    lines = syn.keyframe_index_lines(2)
+    fullK = syn.full_K()
+    fullK_dev, halfK_dev = fullK.to(dev), syn.scaled_K(fullK, 2.0).to(dev)
+    rows, previous = [], None
+    for n, item in enumerate(syn.LONG_SCHEDULE):
+        if item is None:
+            engine.reset()
+            previous = None
+            continue
+        r, ms = lines[item]
+        flipped = 0
+        if previous is not None:
+            _, low = hipcall.depth_reproject(ops, syn.pose(r), previous[0], previous[1], fullK_dev, halfK_dev, 16)
+            a, b = low.cpu().numpy().astype(np.float64), z[f"s{n}_depth_estimation"].astype(np.float64)
+            flipped = int(np.sum(np.abs(a - b) > 1e-3 * np.maximum(np.maximum(a, b), 1e-3)))
+        depth = engine.step(syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK,
+                            frame_id=r, measurement_ids=list(ms))
+        previous = (syn.pose(r), depth.clone().view(1, 1, 256, 320))
+        rows.append({"step": n, "index_line": item, "engine_vs_reference": rel_l1(depth[0, ::4, ::4].cpu().numpy().astype(np.float64),
+                                                                                  z[f"s{n}_depth_sub4"].astype(np.float64)),
+                     "flipped_estimate_pixels_vs_reference": flipped})
+        print("long run step %2d (index line %3d): engine depth rel-L1 vs reference %.3e, %d flipped estimate pixels"
+              % (n, item, rows[-1]["engine_vs_reference"], flipped))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "engine_long_run.json"), "w") as f:
+            json.dump(rows, f, indent=1)
+    clean = True          # no estimate pixel has differed yet since the last (re)start: the run still sees the reference's inputs
+    for row, item in zip(rows, [i for i in syn.LONG_SCHEDULE if i is not None]):
+        if row["flipped_estimate_pixels_vs_reference"] == 0 and row["step"] in (0, 4):
+            clean = True  # first frame of the run / after the tracking loss
+        clean = clean and row["flipped_estimate_pixels_vs_reference"] == 0
+        assert row["engine_vs_reference"] <= (ENGINE_VS_REFERENCE if clean else 1e-1), row
+    assert sum(r["flipped_estimate_pixels_vs_reference"] for r in rows) <= 8, rows
+
+
 def test_pairnet_frame_matches_the_reference(hip_device, golden_dir):
     z = np.load(os.path.join(golden_dir, "pairnet_e2e.npz"))
     dev = hip_device
     mods, engine = build(dev, fusion=False, fold_bn=True, cache_features=False, use_graphs=False)
-    depth = engine.step(syn.e2e_image(12).to(dev), syn.pose(12).to(dev), [syn.e2e_image(9).to(dev)], [syn.pose(9).to(dev)],
-                        syn.full_K().to(dev))
+    depth = engine.step(syn.e2e_image(12).to(dev), syn.pose(12), [syn.e2e_image(9).to(dev)], [syn.pose(9)], syn.full_K())
     err = rel_l1(depth[0, ::4, ::4].cpu().numpy(), z["depth_sub4"])
     print(f"pairnet depth rel-L1 vs reference {err:.3e}")
     assert err <= 2.5 * REL_L1_TARGET
@@ -125,8 +173,8 @@ def test_engine_matches_cpu_oracle_pipeline_stage_by_stage(hip_device):
         rec = {}
         cpu.step(syn.e2e_image(r), syn.pose(r), [syn.e2e_image(i) for i in ms], [syn.pose(i) for i in ms], fullK,
                  record=lambda **kw: rec.update(kw))
-        depth = engine.step(syn.e2e_image(r).to(dev), syn.pose(r).to(dev), [syn.e2e_image(i).to(dev) for i in ms],
-                            [syn.pose(i).to(dev) for i in ms], fullK.to(dev), frame_id=r, measurement_ids=list(ms))
+        depth = engine.step(syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms],
+                            [syn.pose(i) for i in ms], fullK, frame_id=r, measurement_ids=list(ms))
         # two float32 evaluations of the same network (MIOpen vs oneDNN convolutions): both ~1e-4 from exact, see above
         assert rel_l1(depth.cpu().numpy(), rec["depth"].numpy()) <= (2.5 * REL_L1_TARGET if item != frames[2] else 1e-2)
         assert (engine._static["h"].cpu() - rec["h"]).abs().mean().item() <= 2e-3 * rec["h"].abs().mean().item()
@@ -140,18 +188,18 @@ def test_lockstep_sequences_equal_single_sequence_runs(hip_device):
     from dvmvs.hip import ops
     dev = hip_device
     S = 3
-    fullK = syn.full_K().to(dev)
+    fullK = syn.full_K()
     frames = [(9, (6, 0)), (10, (9, 6)), (11, (9, 10)), (12, (11, 9))]
     image = lambda s, i: syn.smooth_noise((1, 3, 256, 320), seed=7000 + 100 * s + i).to(dev)
 
     # op level, bit for bit: cost volume, re-projection, hidden warp, gates at batch S vs batch 1
     feats = [syn.smooth_noise((S, 32, 128, 160), seed=90 + i).to(dev) for i in range(3)]
-    poses = [torch.cat([syn.pose(9 + 3 * s + i) for s in range(S)]).to(dev) for i in range(3)]
-    halfK = syn.scaled_K(syn.full_K(), 2.0).repeat(S, 1, 1).to(dev)
-    cv = ops.cost_volume(feats[0], feats[1:], poses[0], poses[1:], halfK, 0.25, 20.0, 64, True, 0)
+    poses = [torch.cat([syn.pose(9 + 3 * s + i) for s in range(S)]) for i in range(3)]
+    halfK = syn.scaled_K(syn.full_K(), 2.0).repeat(S, 1, 1)
+    cv = hipcall.cost_volume(ops, feats[0], feats[1:], poses[0], poses[1:], halfK, 0.25, 20.0, 64, True, 0)
     for s in range(S):
-        one = ops.cost_volume(feats[0][s:s + 1], [f[s:s + 1] for f in feats[1:]], poses[0][s:s + 1], [p[s:s + 1] for p in poses[1:]],
-                              halfK[s:s + 1], 0.25, 20.0, 64, True, 0)
+        one = hipcall.cost_volume(ops, feats[0][s:s + 1], [f[s:s + 1] for f in feats[1:]], poses[0][s:s + 1], [p[s:s + 1] for p in poses[1:]],
+                                  halfK[s:s + 1], 0.25, 20.0, 64, True, 0)
         assert torch.equal(one[0], cv[s])
     cc, c0 = torch.randn(S, 2048, 8, 10, device=dev), torch.randn(S, 512, 8, 10, device=dev)
     h_b, c_b = ops.lstm_gates(cc, c0)
@@ -163,7 +211,7 @@ def test_lockstep_sequences_equal_single_sequence_runs(hip_device):
     mods, batched = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True, sequences=S)
     singles = [build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=False)[1] for _ in range(S)]
     tainted, previous, tight = [False] * S, [None] * S, 0
-    halfK1 = syn.scaled_K(fullK, 2.0)
+    fullK_dev, halfK1 = fullK.to(dev), syn.scaled_K(fullK, 2.0).to(dev)
     for n, (r, ms) in enumerate(frames):
         if n == 2:                       # sequence 1 loses tracking before its third frame
             batched.reset(sequence=1)
@@ -171,14 +219,14 @@ def test_lockstep_sequences_equal_single_sequence_runs(hip_device):
             tainted[1], previous[1] = False, None
         ref = torch.cat([image(s, r) for s in range(S)])
         meas = [torch.cat([image(s, i) for s in range(S)]) for i in ms]
-        pose = torch.cat([syn.pose(r + 20 * s) for s in range(S)]).to(dev)
-        mposes = [torch.cat([syn.pose(i + 20 * s) for s in range(S)]).to(dev) for i in ms]
+        pose = torch.cat([syn.pose(r + 20 * s) for s in range(S)])
+        mposes = [torch.cat([syn.pose(i + 20 * s) for s in range(S)]) for i in ms]
         depth = batched.step(ref, pose, meas, mposes, fullK.repeat(S, 1, 1), frame_id=r, measurement_ids=list(ms)).clone()
         for s in range(S):
             d1 = singles[s].step(ref[s:s + 1], pose[s:s + 1], [m[s:s + 1] for m in meas], [p[s:s + 1] for p in mposes], fullK,
                                  frame_id=r, measurement_ids=list(ms)).clone()
             if previous[s] is not None:   # did the two runs feed their ConvLSTMs the same (discrete) low-resolution estimate?
-                lows = [ops.depth_reproject_lowres(pose[s:s + 1], previous[s][0], d.view(1, 1, 256, 320), fullK, halfK1, 16)[1].cpu().numpy()
+                lows = [hipcall.depth_reproject(ops, pose[s:s + 1], previous[s][0], d.view(1, 1, 256, 320), fullK_dev, halfK1, 16)[1].cpu().numpy()
                         for d in previous[s][1:]]
                 tainted[s] = tainted[s] or bool(np.any(np.abs(lows[0] - lows[1]) > 1e-3 * np.maximum(np.maximum(lows[0], lows[1]), 1e-3)))
             err = rel_l1(depth[s].cpu().numpy(), d1[0].cpu().numpy())

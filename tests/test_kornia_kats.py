@@ -228,6 +228,7 @@ def test_hip_depth_reprojection_known_answers(hip_device, name):
     depth, T, fK, hK = splat_cases()[name]
     exp = by_the_book_splat(depth, T, fK, hK)
     dev = hip_device
-    got = ops.depth_reproject(torch.eye(4)[None].to(dev), t32(T)[None].to(dev), t32(depth)[None, None].to(dev), t32(fK)[None].to(dev),
+    # reference pose = identity, measurement pose = T: the splat transform inverse(reference) @ measurement is T itself
+    got = ops.depth_reproject(t32(T)[None].to(dev), t32(depth)[None, None].to(dev), t32(fK)[None].to(dev),
                               t32(hK)[None].to(dev))
     np.testing.assert_allclose(got[0, 0].cpu().numpy(), exp, atol=1e-6)

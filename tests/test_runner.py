@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+import hipcall
 import synthetic as syn
 
 
@@ -131,8 +132,8 @@ def test_runners_match_the_cpu_pipeline_and_the_keyframe_simulation(hip_device, 
         # the comparison is only a sanity bound (tests/test_e2e_gpu.py explains the float32-vs-float64 version of the same)
         if previous is not None:
             prev_pose, prev_depth = previous
-            _, low = ops.depth_reproject_lowres(pose(r).to(dev), prev_pose.to(dev), torch.from_numpy(prev_depth).view(1, 1, 256, 320).to(dev),
-                                                fullK.to(dev), syn.scaled_K(fullK, 2.0).to(dev), 16)
+            _, low = hipcall.depth_reproject(ops, pose(r), prev_pose, torch.from_numpy(prev_depth).view(1, 1, 256, 320).to(dev),
+                                             fullK.to(dev), syn.scaled_K(fullK, 2.0).to(dev), 16)
             a, b = low.cpu().numpy(), rec["depth_estimation"].numpy()
             tainted = tainted or bool(np.any(np.abs(a - b) > 1e-3 * np.maximum(np.maximum(a, b), 1e-3)))
         err = float(np.mean(np.abs(preds[k] - d_cpu) / d_cpu))

@@ -81,8 +81,11 @@ def test_function_signatures_match_the_reference():
         "original_height"]
     assert sig(utils.warp_frame_depth) == ["image_src", "depth_dst", "src_trans_dst", "camera_matrix", "normalize_points", "sampling_mode"]
     assert sig(utils.get_warp_grid_for_cost_volume_calculation) == ["width", "height", "device"]
-    assert sig(MVSLayernormConvLSTMCell.forward)[1:] == ["input_tensor", "cur_state", "previous_pose", "current_pose",
-                                                         "estimated_current_depth", "camera_matrix"]
+    assert sig(MVSLayernormConvLSTMCell.forward)[1:7] == ["input_tensor", "cur_state", "previous_pose", "current_pose",
+                                                          "estimated_current_depth", "camera_matrix"]
+    # anything beyond the reference's six arguments must be optional (the engine passes a precomputed relative pose)
+    extra = list(inspect.signature(MVSLayernormConvLSTMCell.forward).parameters.values())[7:]
+    assert all(p.default is not inspect.Parameter.empty for p in extra)
     assert sig(MVSLayernormConvLSTMCell.__init__)[1:] == ["input_dim", "hidden_dim", "kernel_size", "activation_function"]
     grid = utils.get_warp_grid_for_cost_volume_calculation(5, 3, "cpu")
     assert tuple(grid.shape) == (3, 15) and grid[:, 7].tolist() == [2.0, 1.0, 1.0]
@@ -107,12 +110,14 @@ def test_op_shape_inference_with_meta_tensors():
     """register_fake implementations (what torch.compile / shape propagation sees)."""
     from dvmvs.hip import ops
     m = lambda *s: torch.empty(*s, device="meta")
-    assert tuple(ops.cost_volume(m(2, 32, 128, 160), [m(2, 32, 128, 160)] * 2, m(2, 4, 4), [m(2, 4, 4)] * 2, m(2, 3, 3), 0.25, 20.0, 64,
+    assert tuple(ops.cost_volume(m(2, 32, 128, 160), [m(2, 32, 128, 160)] * 2, m(2, 2, 9), m(2, 2, 3), 0.25, 20.0, 64,
                                  True, 0).shape) == (2, 64, 128, 160)
+    Hm, kt = ops.sweep_matrices(m(2, 4, 4), [m(2, 4, 4)] * 3, m(2, 3, 3))
+    assert tuple(Hm.shape) == (2, 3, 9) and tuple(kt.shape) == (2, 3, 3)
     assert tuple(ops.hidden_warp(m(1, 512, 8, 10), m(1, 1, 8, 10), m(1, 4, 4), m(1, 3, 3), True).shape) == (1, 512, 8, 10)
     h, c = ops.lstm_gates(m(4, 2048, 8, 8), m(4, 512, 8, 8))
     assert tuple(h.shape) == tuple(c.shape) == (4, 512, 8, 8)
-    full, low = ops.depth_reproject_lowres(m(1, 4, 4), m(1, 4, 4), m(1, 1, 256, 320), m(1, 3, 3), m(1, 3, 3), 16)
+    full, low = ops.depth_reproject_lowres(m(1, 4, 4), m(1, 1, 256, 320), m(1, 3, 3), m(1, 3, 3), 16)
     assert tuple(full.shape) == (1, 1, 128, 160) and tuple(low.shape) == (1, 1, 8, 10)
 
 

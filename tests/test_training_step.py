@@ -9,6 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import hipcall
 import synthetic as syn
 
 
@@ -225,7 +226,7 @@ def test_training_step_at_the_config5_size(hip_device):
     with orc.exact_pose_algebra():   # float64 pose algebra like the kernels (see tests/test_hybrid_parity.py)
         (orc.cost_volume(f1, f2, p1, p2, halfK, 0.25, 20.0, 64, True) * w).sum().backward()
     g1, g2 = f1.detach().to(dev).requires_grad_(True), f2.detach().to(dev).requires_grad_(True)
-    (ops.cost_volume(g1, [g2], p1.to(dev), [p2.to(dev)], halfK.to(dev), 0.25, 20.0, 64, True, 0) * w.to(dev)).sum().backward()
+    (hipcall.cost_volume(ops, g1, [g2], p1, [p2], halfK, 0.25, 20.0, 64, True, 0) * w.to(dev)).sum().backward()
     for got, exp in ((g1.grad, f1.grad), (g2.grad, f2.grad)):
         err = (got.cpu() - exp).abs()
         print(f"cost-volume gradient at 128x128: max |err| {err.max().item():.2e} (max |g| {exp.abs().max().item():.2e}), mean {err.mean().item():.2e}")
