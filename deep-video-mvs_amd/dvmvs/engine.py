@@ -217,6 +217,26 @@ class DepthEngine:
                 for k in ("h", "c", "prev_depth"):
                     self._static[k][sequence].zero_()
 
+    def load_state(self, hidden, cell, previous_depth, previous_pose):
+        """Installs a recurrent state (h, c [S,512,H/32,W/32]), previous depth [S,1,H,W] or [S,H,W] and previous pose [S,4,4], e.g. a
+        checkpointed one: the next ``step`` continues from it as if this engine had produced it (the state the reference's loop
+        carries in lstm_state / previous_depth / previous_pose, fusionnet/run-testing.py:86-88,201-202)."""
+        if not self.is_fusionnet:
+            raise RuntimeError("pairnet keeps no state between frames")
+        self._allocate_static(1)
+        s, S = self._static, self.sequences
+        s["h"].copy_(hidden.reshape(s["h"].shape))
+        s["c"].copy_(cell.reshape(s["c"].shape))
+        s["prev_depth"].copy_(previous_depth.reshape(S, 1, self.height, self.width))
+        self._prev_pose_host = _pose_algebra._host(previous_pose).reshape(S, 4, 4).clone().float()
+        self._no_previous[:] = False
+        self.has_previous = True
+
+    def state(self):
+        """(h, c, previous depth, previous pose) as ``load_state`` takes them (clones; the pose lives on the host)."""
+        s = self._static
+        return s["h"].clone(), s["c"].clone(), s["prev_depth"].clone(), self._prev_pose_host.clone()
+
     def clear_feature_cache(self):
         self._feature_cache.clear()
 

@@ -42,69 +42,142 @@ def build(dev, fusion=True, **kw):   # kw: DepthEngine options (fold_bn, cache_f
     return mods, DepthEngine(*mods, device=dev, **kw)
 
 
-# Tolerance (written here as the north star asks).  Target: depth rel-L1 <= 1e-4 against the reference forward.  On these
-# inputs the reference's OWN float32 forward sits 0.95e-4 / 1.17e-4 / 2.4e-3 (frames 0 / 1 / 2) away from the same network
-# evaluated in float64 (tests/golden/PINNING_REPORT.json, "e2e_frame*_reference_fp32_vs_float64_depth_rel_l1"): ~50 fp32
-# convolution layers with reductions of up to 9216 terms, and from frame 2 on a discrete z-buffer/nearest-sample decision
-# that float32 and float64 take differently.  "Equal to the reference" can therefore only mean "as close to the exact
-# result as the reference is", which is what is asserted: (a) engine-vs-float64 <= 1.5 x reference-vs-float64 + 2e-5 and
-# (b) engine-vs-reference <= the sum of the two noise floors (2.5e-4), on every frame whose re-projected depth estimate
-# agrees with the reference's; frames where that discrete input differs are only sanity-bounded (1e-2).
+# Tolerances (written here as the north star asks).  Target: depth rel-L1 <= 1e-4 against the reference forward.
+#
+# What the kernels contribute is pinned in tests/test_hybrid_parity.py (convolutions held fixed on the CPU): ~1e-6, 0 flipped
+# z-buffer pixels, on every frame of the 3-frame and the 14-frame reference runs -- since ABI 3 the kernels sample exactly where
+# the reference samples.  What is left for the full-GPU engine is the float32 SUMMATION ORDER OF THE CONVOLUTIONS (MIOpen here,
+# oneDNN in the reference run; ~50 layers, reductions of up to 9216 terms): given the same inputs and the same recurrent state,
+# one frame's depth lands 0.8-1.2e-4 from the reference's (measured; the reference's own float32 forward is 0.95-1.2e-4 from
+# the float64 evaluation of the same network, tests/golden/PINNING_REPORT.json).  Two consequences for what can be asserted:
+# * frame by frame, from the REFERENCE's state (teacher forcing: previous depth, h, c of the reference run installed before
+#   each step): <= ENGINE_VS_REFERENCE on every frame of both golden runs -- the defensible per-frame statement;
+# * free-running: the same bound until the low-resolution depth estimate -- a discrete z-buffer + nearest-sample decision fed
+#   by the previous DEPTH (utils.py:136-154) -- takes one pixel from a different source point than the reference did, which a
+#   1e-4 perturbation of the previous depth does on some frames; from there on the two runs see different inputs and only a
+#   sanity bound applies.  Which frame that is depends on MIOpen's algorithm choice; it is reported, not asserted.
 REL_L1_TARGET = 1e-4
-ENGINE_VS_REFERENCE = 2.5e-4      # provisional: two float32 evaluations of ~50 convolution layers (MIOpen vs oneDNN summation order)
+ENGINE_VS_REFERENCE = 2.5e-4      # two float32 evaluations of the same ~50-layer network, each ~1e-4 from exact
+AFTER_A_FLIPPED_PIXEL = 5e-2      # sanity bound once the discrete depth estimate differs
+
+
+def flipped_pixels(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return int(np.sum(np.abs(a - b) > 1e-3 * np.maximum(np.maximum(a, b), 1e-3)))
+
+
+def reference_pipeline(mods):
+    """The all-CPU oracle pipeline with the engine's weights: the hybrid tests show it reproduces the reference goldens to ~1e-6
+    with the same discrete decisions, so its (full-resolution) state stands in for the reference's where the fixtures only hold
+    sub-sampled depth."""
+    from fusionnet_cpu import CpuDepthPipeline
+    return CpuDepthPipeline(*syn.build_e2e_modules(tuple(type(m) for m in mods)))
 
 
 @pytest.mark.parametrize("mode", ["eager_unfolded", "graphs_folded_cached"])
 def test_fusionnet_three_frames_match_the_reference(hip_device, golden_dir, mode):
+    """Free-running engine over the 3 golden frames (twice in the graph mode, so that both frame kinds are replayed graphs)."""
+    from dvmvs.hip import ops
     z = np.load(os.path.join(golden_dir, "fusionnet_e2e.npz"))
     dev = hip_device
     fast = mode == "graphs_folded_cached"
     mods, engine = build(dev, fusion=True, fold_bn=fast, cache_features=fast, use_graphs=fast)
     fullK = syn.full_K()          # poses and intrinsics stay on the host: that is where the engine evaluates the small matrices
     report = []
-    # with graphs the first frame of each kind runs eagerly and the next replays: run the sequence twice so that
-    # the second pass exercises captured graphs for both frame kinds, and check both passes
     for sweep in range(2 if fast else 1):
         engine.reset()
+        clean = True
         for n, (r, ms) in enumerate(syn.E2E_FRAMES):
             images = [syn.e2e_image(i).to(dev) for i in ms]
+            flipped = 0
+            if n > 0:
+                _, low = hipcall.depth_reproject(ops, syn.pose(r), syn.pose(syn.E2E_FRAMES[n - 1][0]), prev_depth, fullK.to(dev),
+                                                 syn.scaled_K(fullK, 2.0).to(dev), 16)
+                flipped = flipped_pixels(low.cpu().numpy(), z[f"f{n}_depth_estimation_full"])
+            clean = clean and flipped == 0
             depth = engine.step(syn.e2e_image(r).to(dev), syn.pose(r), images, [syn.pose(i) for i in ms], fullK,
                                 frame_id=r, measurement_ids=list(ms))
             s = engine._static
             pins_close(s["ref_half"], z, f"f{n}_feat_half", 2e-5)
             d = depth[0, ::4, ::4].cpu().numpy().astype(np.float64)
             ref32, ref64 = z[f"f{n}_depth_sub4"].astype(np.float64), z[f"f{n}_depth64_sub4"]
-            vs_ref, vs_f64, ref_vs_f64 = rel_l1(d, ref32), rel_l1(d, ref64), rel_l1(ref32, ref64)
-            report.append((sweep, n, vs_ref, vs_f64, ref_vs_f64))
-            same_estimate = True
-            if n > 0:
-                _, low = hipcall.depth_reproject(__import__("dvmvs.hip.ops", fromlist=["x"]), syn.pose(r), syn.pose(syn.E2E_FRAMES[n - 1][0]),
-                                                 prev_depth, fullK.to(dev), syn.scaled_K(fullK, 2.0).to(dev), 16)
-                exp_low = z[f"f{n}_depth_estimation_full"]
-                same_estimate = bool(np.all(np.abs(low.cpu().numpy() - exp_low) <= 1e-3 * np.maximum(exp_low, 1e-3)))
             prev_depth = depth.clone().view(1, 1, 256, 320)
             h_got = s["h"].detach().float().cpu().reshape(-1)[syn.sample_indices(s["h"].numel())].numpy()
             h_err = float(np.abs(h_got - z[f"f{n}_h_samples"]).mean() / (np.abs(z[f"f{n}_h_samples"]).mean() + 1e-12))
-            report[-1] = report[-1] + (same_estimate, h_err)
+            report.append((sweep, n, rel_l1(d, ref32), rel_l1(d, ref64), rel_l1(ref32, ref64), flipped, clean, h_err))
     for row in report:
-        print("%s sweep %d frame %d: rel-L1 vs reference %.3e, vs float64 %.3e (reference vs float64 %.3e), same depth estimate: %s, "
-              "hidden state rel err %.2e" % ((mode,) + row))
-    for sweep, n, vs_ref, vs_f64, ref_vs_f64, same_estimate, h_err in report:
-        if same_estimate and ref_vs_f64 < 1e-3:
+        print("%s sweep %d frame %d: rel-L1 vs reference %.3e, vs float64 %.3e (reference vs float64 %.3e), flipped estimate pixels: %d "
+              "(run still on the reference's inputs: %s), hidden state rel err %.2e" % ((mode,) + row))
+    for sweep, n, vs_ref, vs_f64, ref_vs_f64, flipped, clean, h_err in report:
+        if clean:
             assert h_err <= 1e-3, f"sweep {sweep} frame {n} ({mode}): hidden state differs from the reference by {h_err:.2e}"
-            assert vs_f64 <= 1.5 * ref_vs_f64 + 2e-5, f"sweep {sweep} frame {n} ({mode}): {vs_f64:.3e} from float64, reference is {ref_vs_f64:.3e}"
-            assert vs_ref <= 2.5 * REL_L1_TARGET, f"sweep {sweep} frame {n} ({mode}): depth rel-L1 {vs_ref:.3e} vs the reference"
+            assert vs_ref <= ENGINE_VS_REFERENCE, f"sweep {sweep} frame {n} ({mode}): depth rel-L1 {vs_ref:.3e} vs the reference"
         else:
-            assert vs_ref <= 1e-2, f"sweep {sweep} frame {n} ({mode}): depth rel-L1 {vs_ref:.3e} vs the reference"
-    assert report[0][2] <= 2.5 * REL_L1_TARGET
+            assert vs_ref <= AFTER_A_FLIPPED_PIXEL, f"sweep {sweep} frame {n} ({mode}): depth rel-L1 {vs_ref:.3e} vs the reference"
+    assert report[0][2] <= ENGINE_VS_REFERENCE
+
+
+def run_teacher_forced(engine, reference, dev, frames, expected_sub4):
+    """Every frame from the REFERENCE's state: (h, c, previous depth, previous pose) of the all-CPU reference pipeline are
+    installed in the engine before the step.  ``frames``: (reference pose index, measurement indices) or None = tracking loss.
+    Returns [(step, engine-vs-reference-pipeline rel-L1 (full resolution), engine-vs-golden rel-L1 (sub-sampled) or None,
+    flipped estimate pixels)]."""
+    from dvmvs.hip import ops
+    fullK = syn.full_K()
+    fullK_dev, halfK_dev = fullK.to(dev), syn.scaled_K(fullK, 2.0).to(dev)
+    rows = []
+    for n, item in enumerate(frames):
+        if item is None:
+            engine.reset()
+            reference.reset()
+            continue
+        r, ms = item
+        flipped = 0
+        if reference.previous_depth is not None:
+            h, c = reference.lstm_state
+            engine.load_state(h.to(dev), c.to(dev), reference.previous_depth.to(dev), reference.previous_pose)
+            _, low = hipcall.depth_reproject(ops, syn.pose(r), reference.previous_pose, reference.previous_depth.to(dev), fullK_dev, halfK_dev, 16)
+        rec = {}
+        d_ref = reference.step(syn.e2e_image(r), syn.pose(r), [syn.e2e_image(i) for i in ms], [syn.pose(i) for i in ms], fullK,
+                               record=lambda **kw: rec.update(kw))
+        if rec["depth_estimation"] is not None and float(rec["depth_estimation"].abs().max()) > 0:
+            flipped = flipped_pixels(low.cpu().numpy(), rec["depth_estimation"].numpy())
+        depth = engine.step(syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK,
+                            frame_id=r, measurement_ids=list(ms))
+        d = depth.cpu().numpy().astype(np.float64)
+        golden = expected_sub4(n)
+        rows.append((n, rel_l1(d, d_ref.numpy().astype(np.float64)),
+                     None if golden is None else rel_l1(d[0, ::4, ::4], golden.astype(np.float64)), flipped))
+    return rows
+
+
+@pytest.mark.parametrize("mode", ["eager_unfolded", "graphs_folded_cached"])
+def test_fusionnet_frames_from_the_reference_state(hip_device, golden_dir, mode):
+    """Teacher forcing over the 3 golden frames and the 14-keyframe reference run (tracking loss, wide-baseline lines 200-204,
+    249-251): given the reference's inputs and state, EVERY frame's depth is within ENGINE_VS_REFERENCE of the reference's, and
+    the engine's z-buffer decision on the reference's previous depth has 0 flipped pixels."""
+    dev = hip_device
+    fast = mode == "graphs_folded_cached"
+    z3 = np.load(os.path.join(golden_dir, "fusionnet_e2e.npz"))
+    zl = np.load(os.path.join(golden_dir, "fusionnet_long.npz"))
+    lines = syn.keyframe_index_lines(2)
+    runs = [("3 golden frames", list(syn.E2E_FRAMES), lambda n: z3[f"f{n}_depth_sub4"]),
+            ("long reference run", [None if i is None else lines[i] for i in syn.LONG_SCHEDULE], lambda n: zl[f"s{n}_depth_sub4"])]
+    for name, frames, expected in runs:
+        mods, engine = build(dev, fusion=True, fold_bn=fast, cache_features=fast, use_graphs=fast)
+        rows = run_teacher_forced(engine, reference_pipeline(mods), dev, frames, expected)
+        for n, vs_pipeline, vs_golden, flipped in rows:
+            print("%s, %s step %2d: engine depth rel-L1 vs the reference pipeline %.3e, vs the reference golden %.3e, flipped estimate pixels %d"
+                  % (mode, name, n, vs_pipeline, vs_golden, flipped))
+            assert vs_pipeline <= ENGINE_VS_REFERENCE and vs_golden <= ENGINE_VS_REFERENCE, (name, n, vs_pipeline, vs_golden)
+            assert flipped == 0, (name, n, flipped)
 
 
 def test_fusionnet_long_reference_run(hip_device, golden_dir):
-    """The engine as benchmarked (BN folded, feature cache, hipGraph replay) over the REFERENCE's 14-keyframe run
-    (tests/golden/fusionnet_long.npz: tracking loss, wide-baseline lines 200-204, 249-251).  Per frame: depth rel-L1 vs the
-    reference and the number of low-resolution estimate pixels that differ from the reference's.  What separates the two runs
-    is the convolutions' float32 summation order (MIOpen vs the reference's oneDNN) and nothing on the hot path
-    (tests/test_hybrid_parity.py holds the convolutions fixed and gets ~1e-6 with 0 flipped pixels on the same run)."""
+    """Free-running engine as benchmarked (BN folded, feature cache, hipGraph replay) over the REFERENCE's 14-keyframe run
+    (tests/golden/fusionnet_long.npz).  Per frame: depth rel-L1 vs the reference and the number of low-resolution estimate pixels
+    that differ from the reference's; tight bound while the run is on the reference's inputs, sanity bound after the first
+    flipped pixel until the next restart (see the tolerance note above)."""
     import json
     from dvmvs.hip import ops
     z = np.load(os.path.join(golden_dir, "fusionnet_long.npz"))
@@ -113,37 +186,33 @@ def test_fusionnet_long_reference_run(hip_device, golden_dir):
     lines = syn.keyframe_index_lines(2)
     fullK = syn.full_K()
     fullK_dev, halfK_dev = fullK.to(dev), syn.scaled_K(fullK, 2.0).to(dev)
-    rows, previous = [], None
+    rows, previous, clean = [], None, True
     for n, item in enumerate(syn.LONG_SCHEDULE):
         if item is None:
             engine.reset()
-            previous = None
+            previous, clean = None, True
             continue
         r, ms = lines[item]
         flipped = 0
         if previous is not None:
             _, low = hipcall.depth_reproject(ops, syn.pose(r), previous[0], previous[1], fullK_dev, halfK_dev, 16)
-            a, b = low.cpu().numpy().astype(np.float64), z[f"s{n}_depth_estimation"].astype(np.float64)
-            flipped = int(np.sum(np.abs(a - b) > 1e-3 * np.maximum(np.maximum(a, b), 1e-3)))
+            flipped = flipped_pixels(low.cpu().numpy(), z[f"s{n}_depth_estimation"])
+        clean = clean and flipped == 0
         depth = engine.step(syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK,
                             frame_id=r, measurement_ids=list(ms))
         previous = (syn.pose(r), depth.clone().view(1, 1, 256, 320))
         rows.append({"step": n, "index_line": item, "engine_vs_reference": rel_l1(depth[0, ::4, ::4].cpu().numpy().astype(np.float64),
                                                                                   z[f"s{n}_depth_sub4"].astype(np.float64)),
-                     "flipped_estimate_pixels_vs_reference": flipped})
-        print("long run step %2d (index line %3d): engine depth rel-L1 vs reference %.3e, %d flipped estimate pixels"
-              % (n, item, rows[-1]["engine_vs_reference"], flipped))
+                     "flipped_estimate_pixels_vs_reference": flipped, "on_reference_inputs": clean})
+        print("long run step %2d (index line %3d): engine depth rel-L1 vs reference %.3e, %d flipped estimate pixels%s"
+              % (n, item, rows[-1]["engine_vs_reference"], flipped, "" if clean else "  [after a flipped pixel]"))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "engine_long_run.json"), "w") as f:
             json.dump(rows, f, indent=1)
-    clean = True          # no estimate pixel has differed yet since the last (re)start: the run still sees the reference's inputs
-    for row, item in zip(rows, [i for i in syn.LONG_SCHEDULE if i is not None]):
-        if row["flipped_estimate_pixels_vs_reference"] == 0 and row["step"] in (0, 4):
-            clean = True  # first frame of the run / after the tracking loss
-        clean = clean and row["flipped_estimate_pixels_vs_reference"] == 0
-        assert row["engine_vs_reference"] <= (ENGINE_VS_REFERENCE if clean else 1e-1), row
-    assert sum(r["flipped_estimate_pixels_vs_reference"] for r in rows) <= 8, rows
+    for row in rows:
+        assert row["engine_vs_reference"] <= (ENGINE_VS_REFERENCE if row["on_reference_inputs"] else AFTER_A_FLIPPED_PIXEL), row
+    assert sum(r["on_reference_inputs"] for r in rows) >= 4
 
 
 def test_pairnet_frame_matches_the_reference(hip_device, golden_dir):
@@ -153,31 +222,43 @@ def test_pairnet_frame_matches_the_reference(hip_device, golden_dir):
     depth = engine.step(syn.e2e_image(12).to(dev), syn.pose(12), [syn.e2e_image(9).to(dev)], [syn.pose(9)], syn.full_K())
     err = rel_l1(depth[0, ::4, ::4].cpu().numpy(), z["depth_sub4"])
     print(f"pairnet depth rel-L1 vs reference {err:.3e}")
-    assert err <= 2.5 * REL_L1_TARGET
+    assert err <= ENGINE_VS_REFERENCE
 
 
 def test_engine_matches_cpu_oracle_pipeline_stage_by_stage(hip_device):
-    """Same weights, same inputs: HIP engine vs oracle/fusionnet_cpu.py, including the state reset rule."""
-    from fusionnet_cpu import CpuDepthPipeline
+    """Same weights, same inputs, free-running: HIP engine vs oracle/fusionnet_cpu.py, including the state reset rule.  Tight while
+    both runs feed their ConvLSTMs the same discrete depth estimate, sanity-bounded after a flipped pixel (tolerance note above)."""
+    from dvmvs.hip import ops
     dev = hip_device
     mods, engine = build(dev, fusion=True, fold_bn=False, cache_features=True, use_graphs=False)
-    cpu = CpuDepthPipeline(*syn.build_e2e_modules(tuple(type(m) for m in mods)))
+    cpu = reference_pipeline(mods)
     fullK = syn.full_K()
-    frames = list(syn.E2E_FRAMES) + [None, (13, (12, 10))]   # None = "TRACKING LOST"
+    fullK_dev, halfK_dev = fullK.to(dev), syn.scaled_K(fullK, 2.0).to(dev)
+    frames = list(syn.E2E_FRAMES) + [None, (13, (12, 10)), (16, (13, 12))]   # None = "TRACKING LOST"
+    previous, clean, tight = None, True, 0
     for item in frames:
         if item is None:
             engine.reset()
             cpu.reset()
+            previous, clean = None, True
             continue
         r, ms = item
         rec = {}
         cpu.step(syn.e2e_image(r), syn.pose(r), [syn.e2e_image(i) for i in ms], [syn.pose(i) for i in ms], fullK,
                  record=lambda **kw: rec.update(kw))
+        if previous is not None:
+            _, low = hipcall.depth_reproject(ops, syn.pose(r), previous[0], previous[1], fullK_dev, halfK_dev, 16)
+            clean = clean and flipped_pixels(low.cpu().numpy(), rec["depth_estimation"].numpy()) == 0
         depth = engine.step(syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms],
                             [syn.pose(i) for i in ms], fullK, frame_id=r, measurement_ids=list(ms))
-        # two float32 evaluations of the same network (MIOpen vs oneDNN convolutions): both ~1e-4 from exact, see above
-        assert rel_l1(depth.cpu().numpy(), rec["depth"].numpy()) <= (2.5 * REL_L1_TARGET if item != frames[2] else 1e-2)
-        assert (engine._static["h"].cpu() - rec["h"]).abs().mean().item() <= 2e-3 * rec["h"].abs().mean().item()
+        previous = (syn.pose(r), depth.clone().view(1, 1, 256, 320))
+        err = rel_l1(depth.cpu().numpy(), rec["depth"].numpy())
+        print(f"engine vs CPU pipeline, frame {item}: depth rel-L1 {err:.3e}" + ("" if clean else "  [after a flipped estimate pixel]"))
+        assert err <= (ENGINE_VS_REFERENCE if clean else AFTER_A_FLIPPED_PIXEL), (item, err)
+        if clean:
+            assert (engine._static["h"].cpu() - rec["h"]).abs().mean().item() <= 2e-3 * rec["h"].abs().mean().item()
+        tight += clean
+    assert tight >= 2      # the first frame of the run and the first one after the tracking loss are always on equal inputs
 
 
 def test_lockstep_sequences_equal_single_sequence_runs(hip_device):
@@ -210,29 +291,29 @@ def test_lockstep_sequences_equal_single_sequence_runs(hip_device):
     # engine level
     mods, batched = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True, sequences=S)
     singles = [build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=False)[1] for _ in range(S)]
-    tainted, previous, tight = [False] * S, [None] * S, 0
-    fullK_dev, halfK1 = fullK.to(dev), syn.scaled_K(fullK, 2.0).to(dev)
+    fresh = [True] * S                   # sequences whose next frame has no previous frame
     for n, (r, ms) in enumerate(frames):
         if n == 2:                       # sequence 1 loses tracking before its third frame
             batched.reset(sequence=1)
             singles[1].reset()
-            tainted[1], previous[1] = False, None
+            fresh[1] = True
         ref = torch.cat([image(s, r) for s in range(S)])
         meas = [torch.cat([image(s, i) for s in range(S)]) for i in ms]
         pose = torch.cat([syn.pose(r + 20 * s) for s in range(S)])
         mposes = [torch.cat([syn.pose(i + 20 * s) for s in range(S)]) for i in ms]
+        # teacher forcing: every one-sequence engine starts the frame from the batched run's state of its sequence, so that a
+        # per-sequence state bug in the batched engine (wrong previous pose after reset(sequence), state leaking between
+        # sequences) cannot hide behind the loose bound a free-running comparison needs after a flipped z-buffer pixel
+        if n > 0:
+            h, c, prev_depth, prev_pose = batched.state()
+            for s in range(S):
+                if not fresh[s]:
+                    singles[s].load_state(h[s:s + 1], c[s:s + 1], prev_depth[s:s + 1], prev_pose[s:s + 1])
         depth = batched.step(ref, pose, meas, mposes, fullK.repeat(S, 1, 1), frame_id=r, measurement_ids=list(ms)).clone()
         for s in range(S):
             d1 = singles[s].step(ref[s:s + 1], pose[s:s + 1], [m[s:s + 1] for m in meas], [p[s:s + 1] for p in mposes], fullK,
                                  frame_id=r, measurement_ids=list(ms)).clone()
-            if previous[s] is not None:   # did the two runs feed their ConvLSTMs the same (discrete) low-resolution estimate?
-                lows = [hipcall.depth_reproject(ops, pose[s:s + 1], previous[s][0], d.view(1, 1, 256, 320), fullK_dev, halfK1, 16)[1].cpu().numpy()
-                        for d in previous[s][1:]]
-                tainted[s] = tainted[s] or bool(np.any(np.abs(lows[0] - lows[1]) > 1e-3 * np.maximum(np.maximum(lows[0], lows[1]), 1e-3)))
             err = rel_l1(depth[s].cpu().numpy(), d1[0].cpu().numpy())
-            print(f"lockstep frame {n} sequence {s}: depth rel-L1 vs its own one-sequence engine {err:.3e}"
-                  + ("  [after a flipped estimate pixel]" if tainted[s] else ""))
-            assert err <= (1e-1 if tainted[s] else 2.5 * REL_L1_TARGET), (n, s, err)
-            tight += not tainted[s]
-            previous[s] = (pose[s:s + 1].clone(), depth[s].clone(), d1[0].clone())
-    assert tight >= 8
+            print(f"lockstep frame {n} sequence {s}: depth rel-L1 vs a one-sequence engine started from the same state {err:.3e}")
+            assert err <= ENGINE_VS_REFERENCE, (n, s, err)
+            fresh[s] = False

@@ -43,6 +43,47 @@ def test_resampling_semantics():
     np.testing.assert_allclose(ours, ref, atol=1e-6)     # cv2.INTER_LINEAR and torch's align_corners=False agree on up-sampling
 
 
+def test_resampling_at_the_sample_scene_ratio(golden_dir):
+    """f2: the real 540x360 -> 320x256 DOWN-sampling (ratios 1.6875 x 1.40625 without crop, 1.40625 x 1.40625 with the 45-column
+    crop), against hand-computed values, torch's non-antialiased bilinear, cv2's documented index rules, and a committed
+    fixture of the pre-processed sample frame (tests/golden/make_preprocess_fixture.py; cv2 itself is absent: that is where
+    the pinning ends)."""
+    from dvmvs.dataset_loader import PreprocessImage, load_image, resize_bilinear, resize_nearest
+    # bilinear of a LINEAR image is the image at the source coordinate (x + 0.5) * scale - 0.5 (clamped at 0): hand values
+    ys, xs = np.meshgrid(np.arange(360, dtype=np.float32), np.arange(540, dtype=np.float32), indexing="ij")
+    plane = (xs + 1000.0 * ys).astype(np.float32)
+    down = resize_bilinear(plane, 320, 256)
+    assert down.shape == (256, 320)
+    for (y, x) in ((0, 0), (0, 1), (1, 0), (100, 200), (255, 319), (128, 160)):
+        sx, sy = max((x + 0.5) * 1.6875 - 0.5, 0.0), max((y + 0.5) * 1.40625 - 0.5, 0.0)
+        assert abs(down[y, x] - (sx + 1000.0 * sy)) <= 2e-2, (y, x)      # fp32 on values up to 3.6e5
+    np.testing.assert_allclose(down[0, :3], [0.34375 + 203.125, 2.03125 + 203.125, 3.71875 + 203.125], atol=2e-3)
+    assert abs(down[255, 319] - (538.65625 + 1000.0 * 358.796875)) <= 5e-2
+    # generic content: equal to torch's bilinear without antialiasing, with and without the crop
+    rgb = np.random.RandomState(1).rand(360, 540, 3).astype(np.float32) * 255.0
+    for crop in (0, 45):
+        src = rgb[:, crop:540 - crop]
+        ref = torch.nn.functional.interpolate(torch.from_numpy(np.ascontiguousarray(src)).permute(2, 0, 1)[None], size=(256, 320),
+                                              mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        np.testing.assert_allclose(resize_bilinear(src, 320, 256), ref, atol=1e-4)
+    # nearest: cv2 computes floor(dst * (1 / (dst_size / src_size))) in double; at these ratios that reciprocal is exact
+    for new, old in ((320, 450), (256, 360), (320, 540)):
+        cv2_rule = np.minimum(np.floor(np.arange(new) * (1.0 / (float(new) / old))).astype(int), old - 1)
+        got = resize_nearest(np.arange(old).reshape(1, old), new, 1)[0]
+        assert got.tolist() == cv2_rule.tolist()
+    assert resize_nearest(np.arange(540).reshape(1, 540), 320, 1)[0, [0, 1, 2, 319]].tolist() == [0, 1, 3, 538]
+    # the real frame through PreprocessImage.apply_rgb (dataset_loader.py:325-341) vs the committed fixture rows
+    z = np.load(os.path.join(golden_dir, "preprocess_rows.npz"))
+    image = load_image(os.path.join(golden_dir, "sample_scene", "images", "00012.png"))
+    K = np.loadtxt(os.path.join(golden_dir, "sample_scene", "K.txt")) if os.path.exists(os.path.join(golden_dir, "sample_scene", "K.txt")) \
+        else np.array([[500.0, 0, 270.0], [0, 500.0, 180.0], [0, 0, 1]])
+    for tag, crop in (("crop", True), ("nocrop", False)):
+        pre = PreprocessImage(K, 540, 360, 320, 256, distortion_crop=0, perform_crop=crop)
+        out = pre.apply_rgb(image, 255.0, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+        assert out.shape == (256, 320, 3) and out.dtype == np.float32
+        np.testing.assert_allclose(out[z["rows"]], z[f"{tag}_rows"], atol=2e-5)
+
+
 def _write_scene(folder, n_frames):
     from PIL import Image
     os.makedirs(os.path.join(folder, "images"))
