@@ -169,67 +169,7 @@ __device__ inline int sweep_pitch_residue(float ax, float ay) {
   return ((ax < 0.0f) != (ay < 0.0f)) ? 15 : 1;
 }
 
-// Every lane evaluates corner (lane & 7) -- bit 0: right edge, bit 1: bottom edge, bit 2: last plane of the run -- of
-// candidate run length number (lane >> 3): len0, then halved (rounding up, not below MINSEG) once per candidate.  Three
-// xor-shuffles leave each candidate's extrema in its eight lanes, every lane derives its candidate's box, and the longest
-// run that can be staged (or is entirely outside the image) is picked with one ballot and read into SGPRs -- one evaluation
-// where a retry loop took up to three (1.3 us each in the s_memtime timeline of wide-baseline workgroups).  All waves of a
-// workgroup execute this on identical inputs and therefore agree.  *len_out = planes in the chosen run.
-template <int TW, int TH, int CAP, int MINSEG>
-__device__ inline SampleBox wave_sample_box(const CostVolumeArgs& a, const float* Hm, const float4v* ktd_m, int tile_x, int tile_y,
-                                            int j_lo, int len0, const SweepScale& sc, int lane, int* len_out) {
-  int len = len0;
-  const int candidate = lane >> 3;
-#pragma unroll
-  for (int i = 0; i < 7; ++i)
-    if (i < candidate) len = max((len + 1) >> 1, MINSEG);
-  len = min(len, len0);   // (len0 itself may be below MINSEG at the end of a chunk)
-  const int cx = (lane & 1) ? min(tile_x * TW + TW - 1, a.W - 1) : tile_x * TW;
-  const int cy = (lane & 2) ? min(tile_y * TH + TH - 1, a.H - 1) : tile_y * TH;
-  const float4v k = ktd_m[(lane & 4) ? j_lo + len - 1 : j_lo];
-  const SweepRay ray = sweep_ray(Hm, static_cast<float>(cx), static_cast<float>(cy));
-  // un-clamped position (the box test has to see how far outside the image the corner is)
-  float ux, uy, denom;
-  sweep_position_exact(ray, k.x, k.y, k.z, sc, &ux, &uy, &denom);
-  // direction of a one-pixel step along the tile's top edge (lanes 0 and 1 hold its two ends on plane j_lo)
-  const float edge = static_cast<float>(max(1, min(tile_x * TW + TW - 1, a.W - 1) - tile_x * TW));
-  const float step_x = (__shfl(ux, 1) - __shfl(ux, 0)) / edge, step_y = (__shfl(uy, 1) - __shfl(uy, 0)) / edge;
-  float lo_x = ux, hi_x = ux, lo_y = uy, hi_y = uy;
-#pragma unroll
-  for (int off = 1; off < 8; off <<= 1) {
-    lo_x = fminf(lo_x, __shfl_xor(lo_x, off));
-    hi_x = fmaxf(hi_x, __shfl_xor(hi_x, off));
-    lo_y = fminf(lo_y, __shfl_xor(lo_y, off));
-    hi_y = fmaxf(hi_y, __shfl_xor(hi_y, off));
-  }
-  // NaN-safe: v_min/v_max drop NaNs, so test the corner values themselves as well
-  const bool corner_ok = (ux > -1e6f) && (ux < 1e6f) && (uy > -1e6f) && (uy < 1e6f) && (denom > 1e-6f);
-  const bool finite = ((__ballot(corner_ok) >> (lane & 56)) & 0xffull) == 0xffull;   // all eight corners of this candidate
-  const float Wf = sc.Wf, Hf = sc.Hf;
-  // 0.05 px of slack for round-off between the corner samples and interior pixels
-  const bool outside = (hi_x + 0.05f <= -1.0f) || (lo_x - 0.05f >= Wf) || (hi_y + 0.05f <= -1.0f) || (lo_y - 0.05f >= Hf);
-  const int x_lo = max(-1, static_cast<int>(floorf(fmaxf(lo_x - 0.05f, -1.0f))));
-  const int y_lo = max(-1, static_cast<int>(floorf(fmaxf(lo_y - 0.05f, -1.0f))));
-  const int x_hi = min(a.W, static_cast<int>(floorf(fminf(hi_x + 0.05f, Wf)))) + 1;
-  const int y_hi = min(a.H, static_cast<int>(floorf(fminf(hi_y + 0.05f, Hf)))) + 1;
-  const int RW = x_hi - x_lo + 1, RH = y_hi - y_lo + 1;
-  const int residue = __builtin_amdgcn_readfirstlane(sweep_pitch_residue(step_x, step_y));
-  const int pitch = RW + ((residue - RW) & 15);
-  const int state = !finite ? 0 : outside ? 2 : (pitch * RH <= CAP) ? 1 : 0;
-  // the first candidate that needs no further halving: stageable, outside, or already at the minimum run length
-  const unsigned long long settled = __ballot(state != 0 || len <= MINSEG);
-  const int pick = __builtin_amdgcn_readfirstlane(static_cast<int>(__builtin_ctzll(settled | (1ull << 63))));
-  SampleBox box;
-  box.state = __builtin_amdgcn_readlane(state, pick);
-  const bool staged = box.state == 1;
-  box.x_lo = staged ? __builtin_amdgcn_readlane(x_lo, pick) : 0;
-  box.y_lo = staged ? __builtin_amdgcn_readlane(y_lo, pick) : 0;
-  box.RW = staged ? __builtin_amdgcn_readlane(RW, pick) : 0;
-  box.RH = staged ? __builtin_amdgcn_readlane(RH, pick) : 0;
-  box.pitch = staged ? __builtin_amdgcn_readlane(pitch, pick) : 0;
-  *len_out = __builtin_amdgcn_readlane(len, pick);
-  return box;
-}
+// (the run plan that uses the box geometry above follows the tap helpers: plan_runs)
 
 // ---- gather path (no staging): taps straight from global memory ----------------------------------------------------------
 // One plane of one measurement frame for this thread's pixel: sum_c ref[c] * warped[c].  Used for runs of planes whose
@@ -328,10 +268,101 @@ __device__ inline void tap_plane(const char* tile_bytes, int row_bytes, int addr
   *acc = f;
 }
 
+// ---- run plan ------------------------------------------------------------------------------------------------------------
+// A "run" is a stretch of consecutive planes of one measurement frame whose sample footprint is handled as one unit: staged
+// through LDS as one box (state 1), skipped because the footprint lies entirely outside the image (state 2), or handed to the
+// gather path because even MINSEG planes do not fit (state 0).  The plan of a workgroup -- every run of every frame of its
+// (tile, chunk) -- is made up front by wave 0 and left in LDS, so that the execution loop below knows the NEXT run's box while
+// the current one is being tapped and can have its staging loads in flight.
+//
+// One evaluation serves TWO measurement frames (the common M = 2 needs a single one per workgroup): lane = corner (bits 0-2:
+// right edge, bottom edge, last plane of the run) + 8 * candidate run length (bits 3-4: len0, then halved, rounding up, not
+// below MINSEG, once per candidate) + 32 * frame of the pair.  Three xor-shuffles leave each candidate's extrema in its eight
+// lanes, every lane derives its candidate's box, one ballot per evaluation picks, per frame, the longest run that can be staged
+// (or lies entirely outside the image), and the picked lane writes its own values as the run's entry -- no LDS round trip, no
+// retry loop (1.3 us per evaluation in the s_memtime timeline of round 2, two to six of them per workgroup then).
+constexpr int kRunWords = 8;   // [0] m | seg_lo << 8 | seg_len << 16 | state << 24, [1] x_lo, [2] y_lo, [3] RW | RH << 16, [4] pitch
+
+template <int DP, int MINSEG>
+__host__ __device__ constexpr int max_runs() { return DVMVS_MAX_MEASUREMENTS * ((DP + MINSEG - 1) / MINSEG); }
+
+template <int TW, int TH, int DP, int CAP, int MINSEG>
+__device__ inline int plan_runs(const CostVolumeArgs& a, const float* s_H, const float4v* s_ktd, int tile_x, int tile_y, int planes,
+                                const SweepScale& sc, int lane, int* s_runs) {
+  int n_runs = 0;
+  const int half = lane >> 5, candidate = (lane >> 3) & 3;
+  const int x_first = tile_x * TW, x_last = min(tile_x * TW + TW - 1, a.W - 1);
+  const int cx = (lane & 1) ? x_last : x_first;
+  const int cy = (lane & 2) ? min(tile_y * TH + TH - 1, a.H - 1) : tile_y * TH;
+  const float edge = static_cast<float>(max(1, x_last - x_first));
+  const float Wf = sc.Wf, Hf = sc.Hf;
+  for (int m0 = 0; m0 < a.M; m0 += 2) {
+    const int m = min(m0 + half, a.M - 1);
+    const SweepRay ray = sweep_ray(s_H + m * 9, static_cast<float>(cx), static_cast<float>(cy));
+    int lo_a = 0, lo_b = (m0 + 1 < a.M) ? 0 : planes;   // wave-uniform progress of the two frames
+    int hint_a = DP, hint_b = DP;                        // planes per run that fitted last time: parallax per plane is uniform
+    while (lo_a < planes || lo_b < planes) {
+      const int j_lo = half ? lo_b : lo_a;
+      const int len0 = max(1, min(planes - j_lo, half ? hint_b : hint_a));   // (a finished frame evaluates a dummy run)
+      int len = len0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (i < candidate) len = max((len + 1) >> 1, MINSEG);
+      len = min(len, len0);   // (len0 itself may be below MINSEG at the end of a chunk)
+      const float4v k = s_ktd[m * DP + min((lane & 4) ? j_lo + len - 1 : j_lo, DP - 1)];
+      // un-clamped position (the box test has to see how far outside the image the corner is)
+      float ux, uy, denom;
+      sweep_position_exact(ray, k.x, k.y, k.z, sc, &ux, &uy, &denom);
+      // direction of a one-pixel step along the tile's top edge (the first two lanes of a frame's half hold its ends on plane j_lo)
+      const float step_x = (__shfl(ux, (lane & 32) + 1) - __shfl(ux, lane & 32)) / edge;
+      const float step_y = (__shfl(uy, (lane & 32) + 1) - __shfl(uy, lane & 32)) / edge;
+      float lo_x = ux, hi_x = ux, lo_y = uy, hi_y = uy;
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1) {
+        lo_x = fminf(lo_x, __shfl_xor(lo_x, off));
+        hi_x = fmaxf(hi_x, __shfl_xor(hi_x, off));
+        lo_y = fminf(lo_y, __shfl_xor(lo_y, off));
+        hi_y = fmaxf(hi_y, __shfl_xor(hi_y, off));
+      }
+      // NaN-safe: v_min/v_max drop NaNs, so test the corner values themselves as well
+      const bool corner_ok = (ux > -1e6f) && (ux < 1e6f) && (uy > -1e6f) && (uy < 1e6f) && (denom > 1e-6f);
+      const bool finite = ((__ballot(corner_ok) >> (lane & 56)) & 0xffull) == 0xffull;   // all eight corners of this candidate
+      // 0.05 px of slack for round-off between the corner samples and interior pixels
+      const bool outside = (hi_x + 0.05f <= -1.0f) || (lo_x - 0.05f >= Wf) || (hi_y + 0.05f <= -1.0f) || (lo_y - 0.05f >= Hf);
+      const int x_lo = max(-1, static_cast<int>(floorf(fmaxf(lo_x - 0.05f, -1.0f))));
+      const int y_lo = max(-1, static_cast<int>(floorf(fmaxf(lo_y - 0.05f, -1.0f))));
+      const int x_hi = min(a.W, static_cast<int>(floorf(fminf(hi_x + 0.05f, Wf)))) + 1;
+      const int y_hi = min(a.H, static_cast<int>(floorf(fminf(hi_y + 0.05f, Hf)))) + 1;
+      const int RW = x_hi - x_lo + 1, RH = y_hi - y_lo + 1;
+      const int pitch = RW + ((sweep_pitch_residue(step_x, step_y) - RW) & 15);
+      const int state = !finite ? 0 : outside ? 2 : (pitch * RH <= CAP) ? 1 : 0;
+      // per frame: the first candidate that needs no further halving -- stageable, outside, or already at the minimum run length
+      // (the last candidate always is)
+      const unsigned long long settled = __ballot(state != 0 || len <= MINSEG);
+      const int pick_a = __builtin_ctz(static_cast<unsigned int>(settled) | 0x80000000u);
+      const int pick_b = 32 + __builtin_ctz(static_cast<unsigned int>(settled >> 32) | 0x80000000u);
+      const bool act_a = lo_a < planes, act_b = lo_b < planes;
+      if ((act_a && lane == pick_a) || (act_b && lane == pick_b)) {
+        int* run = s_runs + (n_runs + ((half && act_a) ? 1 : 0)) * kRunWords;
+        const bool staged = state == 1;
+        run[0] = m | (j_lo << 8) | (len << 16) | (state << 24);
+        run[1] = staged ? x_lo : 0;
+        run[2] = staged ? y_lo : 0;
+        run[3] = staged ? (RW | (RH << 16)) : 0;
+        run[4] = staged ? pitch : 0;
+      }
+      const int len_a = __builtin_amdgcn_readlane(len, pick_a), len_b = __builtin_amdgcn_readlane(len, pick_b);
+      if (act_a) { lo_a += len_a; hint_a = max(len_a, MINSEG); ++n_runs; }
+      if (act_b) { lo_b += len_b; hint_b = max(len_b, MINSEG); ++n_runs; }
+    }
+  }
+  return n_runs;
+}
+
 // ---- spill groups ------------------------------------------------------------------------------------------------------
 // Spill workspace words: [0] = number of registered groups, [1] = finished workgroups of the second pass, [2..3] unused,
 // then `groups` group ids, then one slot per workgroup of (1 + M * DP) words: item count and items.  An item packs
-// (m, seg_lo, seg_len); a workgroup queues its items in (measurement frame, plane) order.
+// (m, seg_lo, seg_len); a workgroup queues its items in plan order.
 // The header must be zero when a call starts; the second pass restores that (its last workgroup to finish clears words 0 and
 // 1), so the caller zero-fills a workspace once, when it allocates it, and never again.
 constexpr int kSpillHeaderWords = 4;
@@ -351,14 +382,19 @@ __device__ unsigned long long g_sweep_trace[kTraceGroups * kTraceWords];
 #endif
 
 // ---- the kernel ----------------------------------------------------------------------------------------------------------
-template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, bool XCD_ = true, bool PREFETCH_ = false, int BATCH_ = 0, int STAGGER_ = 0>
+// PRE: staging pieces of the NEXT channel pass (or of the next run's first pass) whose loads are issued before the taps of the
+// current one and held in registers until the LDS tile is free again -- the global-load round trip of a pass (0.65 us of the
+// workgroup's dependency chain per pass in round 2's timeline, eight passes per workgroup) then overlaps the LDS-bound tap phase.
+// Pieces beyond PRE (boxes larger than PRE * NT records) are loaded after the taps as before.
+template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, bool XCD_ = true, int PRE_ = 2, bool PLAN0_ = true,
+          bool FASTFULL_ = true>
 struct SweepConfig {
-  static constexpr int STAGGER = STAGGER_;   // start offset between the workgroups that share a CU, in units of 64 shader clocks
-  static constexpr int BATCH = BATCH_;   // staging pieces whose loads are in flight together (0: 1 for NCHW, 4 for NHWC)
-  static constexpr bool PREFETCH = PREFETCH_;   // next pass's loads in flight during this pass's taps (measured: slower, see the kernel)
   static constexpr int TW = TW_, TH = TH_, DP = DP_, CCH = CCH_, CAP = CAP_, MINSEG = MINSEG_;
   static constexpr int WAVES = WAVES_;   // waves per SIMD the register allocation is held to
   static constexpr bool XCD = XCD_;      // XCD-aware workgroup numbering
+  static constexpr int PRE = PRE_;       // prefetched staging pieces per thread (NCHW; x2 for channels-last quads), 0 = none
+  static constexpr bool PLAN0 = PLAN0_;  // the run plan is made by wave 0 only (the other waves wait at the barrier)
+  static constexpr bool FASTFULL = FASTFULL_;   // straight-line tap block for runs that cover the whole chunk
   static constexpr int NT = TW * TH;
   static constexpr int REC = CCH + 4;                                  // floats per LDS record
   static constexpr size_t kLdsBytes = sizeof(float) * static_cast<size_t>(REC) * CAP;
@@ -398,10 +434,13 @@ template <class Cfg, bool NHWC, bool GATHER>
 __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_kernel(CostVolumeArgs a) {
   constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP, CCH = Cfg::CCH, CAP = Cfg::CAP, NT = Cfg::NT, REC = Cfg::REC;
   constexpr int QPR = CCH / 4;   // 16-byte quads per record
+  constexpr int kMaxRuns = max_runs<DP, Cfg::MINSEG>();
   extern __shared__ __attribute__((aligned(16))) float s_tile[];   // [CAP][REC]
   __shared__ float s_H[DVMVS_MAX_MEASUREMENTS * 9];
   __shared__ float s_kt[DVMVS_MAX_MEASUREMENTS * 3];
   __shared__ float4v s_ktd[DVMVS_MAX_MEASUREMENTS * DP];
+  __shared__ int s_runs[kMaxRuns * kRunWords];
+  __shared__ int s_n_runs;
 
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
   const int chunks = (a.D + DP - 1) / DP;
@@ -412,24 +451,16 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   const int d_block = work.chunk * DP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int planes = min(DP, a.D - d_block);
-  SWEEP_TRACE(unsigned long long tr_box = 0, tr_stage = 0, tr_taps = 0, tr_passes = 0, tr_records = 0, tr_box_a = 0, tr_box_b = 0, tr_loop_end = 0, tr_sync = 0;)
+  SWEEP_TRACE(unsigned long long tr_stage = 0, tr_taps = 0, tr_passes = 0, tr_records = 0, tr_switch = 0;)
   SWEEP_TRACE(const unsigned long long tr_start = __builtin_amdgcn_s_memtime(); const unsigned long long tr_real0 = __builtin_amdgcn_s_memrealtime();)
 
-  if (Cfg::STAGGER > 0) {
-    // Tuning option, off.  Workgroups that share a CU run their phases in lockstep (all on the VALU for positions, then all on
-    // the LDS for taps), so each pipe idles while the other is the bottleneck.  The dispatcher deals an XCD's workgroups round
-    // the XCD's 32 CUs: number k lands with k + 32 and k + 64 (confirmed with HW_ID in tools/sweep_trace.py).  Starting them one
-    // offset apart was measured: the launch gets longer by about the offset (37.3 -> 38.8 / 39.6 / 41.5 us for 2 / 4 / 6 us), the
-    // taps of a workgroup that has the LDS to itself are bound by its own LDS latency chain instead (1.6 us per pass either way).
-    const int rank = ((blockIdx.x >> 3) / 32) % 3;
-    for (int i = 0; i < rank * Cfg::STAGGER; i += 32) __builtin_amdgcn_s_sleep(32);
-  }
   // ---- per-workgroup tables: the caller's Hm = K R K^-1 and K t per measurement frame, K t / depth per plane (utils.py:66-68) ----
   {
     gcfloat_p Hm_g = as_global(a.Hm) + static_cast<size_t>(b) * a.M * 9;
     gcfloat_p kt_g = as_global(a.kt) + static_cast<size_t>(b) * a.M * 3;
     for (int i = tid; i < a.M * 9; i += NT) s_H[i] = Hm_g[i];
-    for (int i = tid; i < a.M * 3; i += NT) s_kt[i] = kt_g[i];
+    if (GATHER)
+      for (int i = tid; i < a.M * 3; i += NT) s_kt[i] = kt_g[i];
     for (int i = tid; i < a.M * DP; i += NT) {
       const int m = i / DP, j = i - m * DP;
       float4v k = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -443,8 +474,18 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
     }
   }
   __syncthreads();
-
   SWEEP_TRACE(const unsigned long long tr_setup = __builtin_amdgcn_s_memtime();)
+
+  const SweepScale sc = sweep_scale(a.W, a.H);
+  // ---- run plan (wave 0; with PLAN0 == false every wave evaluates it and wave 0's copy is the one written) ----
+  if (!Cfg::PLAN0 || tid < 64) {   // (all waves: identical values, benign identical writes)
+    const int n = plan_runs<TW, TH, DP, CAP, Cfg::MINSEG>(a, s_H, s_ktd, tile_x, tile_y, planes, sc, lane, s_runs);
+    if (tid == 0) s_n_runs = n;
+  }
+  __syncthreads();
+  const int n_runs = __builtin_amdgcn_readfirstlane(s_n_runs);
+  SWEEP_TRACE(const unsigned long long tr_plan = __builtin_amdgcn_s_memtime();)
+
   const int HW = a.H * a.W;
   // lane -> pixel: each 16-lane ds_read_b128 service group owns 16 consecutive pixels of one tile row (see sweep_lane_pixel)
   const int lane_pixel = sweep_lane_pixel(tid & 31);
@@ -454,7 +495,6 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   const float xf = static_cast<float>(x), yf = static_cast<float>(y);
   const int pix = live ? y * a.W + x : 0;
   gcfloat_p ref = as_global(a.image1) + static_cast<size_t>(b) * a.C * HW + pix;
-  const SweepScale sc = sweep_scale(a.W, a.H);
   const char* tile_bytes = reinterpret_cast<const char*>(s_tile);
   const unsigned int plane_bytes = static_cast<unsigned int>(HW) * 4u;
   const unsigned int map_bytes = static_cast<unsigned int>(a.C) * plane_bytes;
@@ -469,200 +509,218 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   int n_spilled = 0;      // workgroup-uniform
   int violated = 0;       // this thread saw a tap outside its staged box (round-off beyond the slack: not expected)
 
-  // even- and odd-channel partial sums of sum_m sum_c ref[c] * warped_m[c]: one accumulator over all measurement frames
-  // (sum over frames, then / C, then / M; for the usual power-of-two C this is bit-identical to the reference's
-  // per-frame / C followed by the sum, otherwise it is one rounding closer to exact)
+  // sum_m sum_c ref[c] * warped_m[c]: one accumulator over all measurement frames (sum over frames, then / C, then / M; for the
+  // usual power-of-two C this is bit-identical to the reference's per-frame / C followed by the sum, otherwise it is one
+  // rounding closer to exact).  Even- and odd-channel partial sums ride in the two halves of packed FMAs.
   float2v acc2[DP];
 #pragma unroll
   for (int j = 0; j < DP; ++j) acc2[j] = float2v{0.0f, 0.0f};
 
-  for (int m = 0; m < a.M; ++m) {
-    const float* Hm = s_H + m * 9;
-    const float4v* ktd_m = s_ktd + m * DP;
-    gcfloat_p meas = as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW;
-    const SweepRay ray = sweep_ray(Hm, xf, yf);
-    // This thread's sample positions on the chunk's planes do not depend on the box: with NCHW maps they are computed once per
-    // frame and kept (16 registers) for workgroups that need several runs; the channels-last instantiation has no registers to
-    // spare and recomputes them per run.  Either way all DP planes are evaluated without branches, so that the DP chains of
-    // dependent operations (three exact divisions each) sit in one basic block.
-    constexpr bool kKeepPositions = !NHWC;
-    float2v pos[DP];
-    auto sample_positions = [&]() {
+  // ---- runs that cannot be staged: queue them for the second pass, or gather them here when there is none ----
+  int first_staged = n_runs;
+  for (int e = n_runs - 1; e >= 0; --e)
+    if ((__builtin_amdgcn_readfirstlane(s_runs[e * kRunWords]) >> 24) == 1) first_staged = e;
+  for (int e = 0; e < n_runs; ++e) {
+    const int w0 = __builtin_amdgcn_readfirstlane(s_runs[e * kRunWords]);
+    if ((w0 >> 24) != 0) continue;
+    const int m = w0 & 0xff, seg_lo = (w0 >> 8) & 0xff, seg_len = (w0 >> 16) & 0xff;
+    if (!GATHER) {
+      if (tid == 0) slot[1 + n_spilled] = spill_pack(m, seg_lo, seg_len);
+      ++n_spilled;
+    } else {
+      const SweepRay ray = sweep_ray(s_H + m * 9, xf, yf);
+      const float* kt = s_kt + m * 3;
+      gcfloat_p meas = as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW;
 #pragma unroll
-      for (int j = 0; j < DP; ++j) {
+      for (int j = 0; j < DP; ++j)
+        if (j >= seg_lo && j < seg_lo + seg_len) {
+          const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j);
+          acc2[j].x += live ? gather_plane<NHWC>(a, meas, ref, HW, ray, kt[0] / depth, kt[1] / depth, kt[2] / depth, sc) : 0.0f;
+        }
+    }
+  }
+
+  // ---- staged runs, software-pipelined over (run, channel pass) stages ----
+  constexpr int kPieces = NHWC ? (CAP * QPR + NT - 1) / NT : (CAP + NT - 1) / NT;
+  constexpr int kPreWanted = NHWC ? 2 * Cfg::PRE : Cfg::PRE;
+  constexpr int kPre = kPreWanted < kPieces ? kPreWanted : kPieces;
+  constexpr int kPreRegs = NHWC ? 1 : QPR;   // float4 per piece
+  if (first_staged < n_runs) {
+    // state of the run being tapped
+    int m = 0, seg_lo = 0, seg_hi = 0, row_bytes = 0, n_pieces = 0;
+    int addr[DP];
+    float2v frac[DP];
+    // state of the run being staged (the same run, or the next one while the last pass of the current run is tapped)
+    __amdgpu_buffer_rsrc_t meas_rsrc;
+    unsigned int goff[kPieces];
+    int st_n_pieces = 0;
+    SampleBox st_box;
+    int st_m = 0, st_lo = 0, st_hi = 0;
+
+    auto read_run = [&](int e) {   // entry e -> the staging state: box, frame, planes, byte offset of every LDS piece in the measurement map
+      const int* run = s_runs + e * kRunWords;
+      const int w0 = __builtin_amdgcn_readfirstlane(run[0]), w3 = __builtin_amdgcn_readfirstlane(run[3]);
+      st_m = w0 & 0xff;
+      st_lo = (w0 >> 8) & 0xff;
+      st_hi = st_lo + ((w0 >> 16) & 0xff);
+      st_box.x_lo = __builtin_amdgcn_readfirstlane(run[1]);
+      st_box.y_lo = __builtin_amdgcn_readfirstlane(run[2]);
+      st_box.RW = w3 & 0xffff;
+      st_box.RH = w3 >> 16;
+      st_box.pitch = __builtin_amdgcn_readfirstlane(run[4]);
+      st_box.state = 1;
+      const int P = st_box.pitch, RS = P * st_box.RH;
+      // NHWC: a piece is one 16-byte channel quad of one box position; NCHW: a piece is one box position (CCH dword loads).
+      // Positions outside the image (zero apron), pad columns and pieces past the box get kBufferOutOfRange: the load
+      // then returns zeros by itself.
+      const unsigned int magic = 0xffffffffu / static_cast<unsigned int>(P) + 1u;   // r / P == mulhi(r, magic) for r < 2^16
+      st_n_pieces = NHWC ? RS * QPR : RS;
+#pragma unroll
+      for (int k = 0; k < kPieces; ++k) {
+        const int piece = tid + k * NT;
+        const int r = NHWC ? piece / QPR : piece;
+        const int ry = static_cast<int>(__umulhi(static_cast<unsigned int>(r), magic));
+        const int rx = r - ry * P;
+        const int gx = st_box.x_lo + rx, gy = st_box.y_lo + ry;
+        const bool in = (piece < st_n_pieces) && (rx < st_box.RW) && (gx >= 0) && (gx < a.W) && (gy >= 0) && (gy < a.H);
+        goff[k] = in ? static_cast<unsigned int>(NHWC ? (gy * a.W + gx) * a.C + (piece % QPR) * 4 : gy * a.W + gx) * 4u : kBufferOutOfRange;
+      }
+      meas_rsrc = map_resource(as_global(a.image2[st_m]) + static_cast<size_t>(b) * a.C * HW, map_bytes);
+      SWEEP_TRACE(tr_records += static_cast<unsigned long long>(RS);)
+    };
+    auto adopt_run = [&]() {   // the staged run becomes the tapped one: this thread's tap addresses and fractional positions on its planes
+      m = st_m; seg_lo = st_lo; seg_hi = st_hi; n_pieces = st_n_pieces;
+      const int P = st_box.pitch;
+      row_bytes = P * REC * 4;
+      const SweepRay ray = sweep_ray(s_H + m * 9, xf, yf);
+      const float4v* ktd_m = s_ktd + m * DP;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {   // all planes in one basic block (those outside the run get addresses that are never used)
         const float4v kd = ktd_m[j];   // zeros beyond the last plane of a ragged chunk
         float ix, iy;
         sweep_sample(ray, kd.x, kd.y, kd.z, sc, &ix, &iy);
-        pos[j] = float2v{ix, iy};
+        const bool in_run = j >= seg_lo && j < seg_hi;   // workgroup-uniform
+        const float fx = floorf(ix), fy = floorf(iy);
+        int rx = static_cast<int>(fx) - st_box.x_lo, ry = static_cast<int>(fy) - st_box.y_lo;
+        if (live && in_run) violated |= (static_cast<unsigned int>(rx) > static_cast<unsigned int>(st_box.RW - 2)) |
+                                        (static_cast<unsigned int>(ry) > static_cast<unsigned int>(st_box.RH - 2));
+        rx = min(max(rx, 0), st_box.RW - 2);
+        ry = min(max(ry, 0), st_box.RH - 2);
+        addr[j] = __mul24(__mul24(ry, P) + rx, REC * 4);   // full-rate 24-bit multiplies: ry, P, rx < 2^11
+        frac[j] = float2v{ix - fx, iy - fy};
       }
     };
-    if (kKeepPositions) sample_positions();
-    int seg_hint = DP;   // planes per segment that fitted last time: parallax per plane is uniform along the sweep
-    int seg_lo = 0;
-    while (seg_lo < planes) {
-      int seg_len = min(planes - seg_lo, seg_hint);
-      SWEEP_TRACE(const unsigned long long tr_b0 = __builtin_amdgcn_s_memtime();)
-      const SampleBox box = wave_sample_box<TW, TH, CAP, Cfg::MINSEG>(a, Hm, ktd_m, tile_x, tile_y, seg_lo, seg_len, sc, lane, &seg_len);
-      seg_hint = max(seg_len, Cfg::MINSEG);
-      const int seg_hi = seg_lo + seg_len;
-      SWEEP_TRACE(const unsigned long long tr_b1 = __builtin_amdgcn_s_memtime(); tr_box_a += tr_b1 - tr_b0;)
+    auto load_ref = [&](int c0, float2v* rv) {
+      // channels beyond C (last pass of a ragged channel count) re-read channel C-1 on both sides and are cancelled by rv = 0
+#pragma unroll
+      for (int c = 0; c < CCH; ++c) {
+        const float v = buffer_f32(ref_rsrc, ref_voffset, static_cast<unsigned int>(min(c0 + c, a.C - 1)) * plane_bytes);
+        rv[c / 2][c % 2] = (c0 + c < a.C) ? v : 0.0f;
+      }
+    };
+    auto load_piece = [&](int k, int c0, float4v* v) {   // piece k of pass c0 of the run being staged into kPreRegs float4
+      if (NHWC) {
+        const int piece = tid + k * NT;
+        unsigned int vo = goff[k];
+        if (c0 + CCH > a.C && c0 + (piece % QPR) * 4 >= a.C) vo = kBufferOutOfRange;
+        v[0] = buffer_f32x4(meas_rsrc, vo, static_cast<unsigned int>(c0) * 4u);
+      } else {
+#pragma unroll
+        for (int c = 0; c < CCH; ++c)
+          v[c / 4][c % 4] = buffer_f32(meas_rsrc, goff[k], static_cast<unsigned int>(min(c0 + c, a.C - 1)) * plane_bytes);
+      }
+    };
+    auto store_piece = [&](int k, const float4v* v, int limit) {
+      const int piece = tid + k * NT;
+      if (piece < limit) {
+        if (NHWC) {
+          *reinterpret_cast<float4v*>(s_tile + (piece / QPR) * REC + (piece % QPR) * 4) = v[0];
+        } else {
+#pragma unroll
+          for (int q = 0; q < QPR; ++q) *reinterpret_cast<float4v*>(s_tile + piece * REC + q * 4) = v[q];
+        }
+      }
+    };
 
-      if (box.state == 1) {
-        const int P = box.pitch, RS = box.pitch * box.RH;
-        const int row_bytes = P * REC * 4;
-        // ---- this thread's taps: byte address of the north-west record and the fractional position (ix - floor, iy - floor),
-        // per plane of the run; the four bilinear weights are re-formed from the fractions in every channel pass (16 registers
-        // instead of 32: what keeps this kernel at 3 waves per SIMD without scratch traffic) ----
-        int addr[DP];
-        float2v frac[DP];
-        if (!kKeepPositions) sample_positions();
+    float4v pre[kPre > 0 ? kPre * kPreRegs : 1];
+    float2v rv_next[CCH / 2];
+    auto prefetch = [&](int c0) {   // the staged run's pass c0: reference features and the first kPre pieces, requests only
+      load_ref(c0, rv_next);
 #pragma unroll
-        for (int j = 0; j < DP; ++j) {   // all planes (those outside the run get addresses that are never used)
-          const bool in_run = j >= seg_lo && j < seg_hi;   // workgroup-uniform
-          const float ix = pos[j].x, iy = pos[j].y;
-          const float fx = floorf(ix), fy = floorf(iy);
-          int rx = static_cast<int>(fx) - box.x_lo, ry = static_cast<int>(fy) - box.y_lo;
-          if (live && in_run) violated |= (static_cast<unsigned int>(rx) > static_cast<unsigned int>(box.RW - 2)) |
-                                          (static_cast<unsigned int>(ry) > static_cast<unsigned int>(box.RH - 2));
-          rx = min(max(rx, 0), box.RW - 2);
-          ry = min(max(ry, 0), box.RH - 2);
-          addr[j] = __mul24(__mul24(ry, P) + rx, REC * 4);   // full-rate 24-bit multiplies: ry, P, rx < 2^11
-          frac[j] = float2v{ix - fx, iy - fy};
-        }
-        // ---- staging plan: byte offset into the measurement map of each of this thread's LDS pieces ----
-        // NHWC: a piece is one 16-byte channel quad of one box position; NCHW: a piece is one box position (CCH dword loads).
-        // Positions outside the image (zero apron), pad columns and pieces past the box get kBufferOutOfRange: the load
-        // then returns zeros by itself.
-        SWEEP_TRACE(asm volatile("" :: "v"(addr[0]), "v"(addr[DP - 1]), "v"(frac[DP - 1])); tr_box_b += __builtin_amdgcn_s_memtime() - tr_b1;)
-        constexpr int kPieces = NHWC ? (CAP * QPR + NT - 1) / NT : (CAP + NT - 1) / NT;
-        const unsigned int magic = 0xffffffffu / static_cast<unsigned int>(P) + 1u;   // r / P == mulhi(r, magic) for r < 2^16
-        const int n_pieces = NHWC ? RS * QPR : RS;
-        unsigned int goff[kPieces];
-#pragma unroll
-        for (int k = 0; k < kPieces; ++k) {
-          const int piece = tid + k * NT;
-          const int r = NHWC ? piece / QPR : piece;
-          const int ry = static_cast<int>(__umulhi(static_cast<unsigned int>(r), magic));
-          const int rx = r - ry * P;
-          const int gx = box.x_lo + rx, gy = box.y_lo + ry;
-          const bool in = (piece < n_pieces) && (rx < box.RW) && (gx >= 0) && (gx < a.W) && (gy >= 0) && (gy < a.H);
-          goff[k] = in ? static_cast<unsigned int>(NHWC ? (gy * a.W + gx) * a.C + (piece % QPR) * 4 : gy * a.W + gx) * 4u : kBufferOutOfRange;
-        }
-        const __amdgpu_buffer_rsrc_t meas_rsrc = map_resource(meas, map_bytes);
-        SWEEP_TRACE(tr_box += __builtin_amdgcn_s_memtime() - tr_b0; tr_records += static_cast<unsigned long long>(RS);)
+      for (int k = 0; k < kPre; ++k)
+        if (k * NT < st_n_pieces) load_piece(k, c0, pre + k * kPreRegs);   // workgroup-uniform
+    };
 
-        // ---- channel passes.  All workgroups of a frame are resident at once, so the launch lasts about as long as one
-        // workgroup's dependency chain, and the global-load round trip of every pass sits on it (load -> wait -> ds_write ->
-        // barrier -> taps -> barrier).  PREFETCH (a tuning option, off) requests the first kPre pieces of the NEXT pass and its
-        // reference features before the taps of the current pass and holds them in registers until the buffer is free.
-        // Measured on MI355X: 39.6 us against 36.0 us without (sideways pair), 57 against 52 (index line 117): the 16-24
-        // extra live registers push the kernel past 168 VGPRs (scratch traffic), which costs more than the overlap gains.
-        constexpr int kPre = Cfg::PREFETCH ? (NHWC ? (kPieces < 4 ? kPieces : 4) : (kPieces < 2 ? kPieces : 2)) : 0;
-        constexpr int kPreRegs = NHWC ? 1 : QPR;   // float4 per piece
-        float4v pre[kPre > 0 ? kPre * kPreRegs : 1];
-        float2v rv_next[CCH / 2];
-        auto load_ref = [&](int c0, float2v* rv) {
-          // channels beyond C (last pass of a ragged channel count) re-read channel C-1 on both sides and are cancelled by rv = 0
+    int e = first_staged, c0 = 0;
+    read_run(e);
+    prefetch(0);
+    adopt_run();   // (overlaps the round trip of the first requests)
+    for (;;) {
+      SWEEP_TRACE(const unsigned long long tr_s0 = __builtin_amdgcn_s_memtime();)
+      // ---- stage (run e, pass c0): pieces beyond the prefetched ones, a few in flight at a time, then the prefetched ones ----
+      float2v rv[CCH / 2];
 #pragma unroll
-          for (int c = 0; c < CCH; ++c) {
-            const float v = buffer_f32(ref_rsrc, ref_voffset, static_cast<unsigned int>(min(c0 + c, a.C - 1)) * plane_bytes);
-            rv[c / 2][c % 2] = (c0 + c < a.C) ? v : 0.0f;
-          }
-        };
-        auto load_piece = [&](int k, int c0, float4v* v) {   // piece k of pass c0 into kPreRegs float4
-          if (NHWC) {
-            const int piece = tid + k * NT;
-            unsigned int vo = goff[k];
-            if (c0 + CCH > a.C && c0 + (piece % QPR) * 4 >= a.C) vo = kBufferOutOfRange;
-            v[0] = buffer_f32x4(meas_rsrc, vo, static_cast<unsigned int>(c0) * 4u);
-          } else {
+      for (int c = 0; c < CCH / 2; ++c) rv[c] = rv_next[c];
+      constexpr int kBatch = NHWC ? 4 : 1;
 #pragma unroll
-            for (int c = 0; c < CCH; ++c)
-              v[c / 4][c % 4] = buffer_f32(meas_rsrc, goff[k], static_cast<unsigned int>(min(c0 + c, a.C - 1)) * plane_bytes);
-          }
-        };
-        auto store_piece = [&](int k, const float4v* v) {
-          const int piece = tid + k * NT;
-          if (piece < n_pieces) {
-            if (NHWC) {
-              *reinterpret_cast<float4v*>(s_tile + (piece / QPR) * REC + (piece % QPR) * 4) = v[0];
-            } else {
+      for (int k0 = kPre; k0 < kPieces; k0 += kBatch) {
+        if (k0 * NT < n_pieces) {   // workgroup-uniform
+          float4v v[kBatch * kPreRegs];
 #pragma unroll
-              for (int q = 0; q < QPR; ++q) *reinterpret_cast<float4v*>(s_tile + piece * REC + q * 4) = v[q];
-            }
-          }
-        };
-        if (kPre > 0) {
-          load_ref(0, rv_next);
+          for (int kk = 0; kk < kBatch; ++kk)
+            load_piece(k0 + kk < kPieces ? k0 + kk : kPieces - 1, c0, v + kk * kPreRegs);
 #pragma unroll
-          for (int k = 0; k < kPre; ++k)
-            if (k * NT < n_pieces) load_piece(k, 0, pre + k * kPreRegs);   // workgroup-uniform
+          for (int kk = 0; kk < kBatch; ++kk)
+            if (k0 + kk < kPieces) store_piece(k0 + kk, v + kk * kPreRegs, n_pieces);
         }
-        for (int c0 = 0; c0 < a.C; c0 += CCH) {
-          SWEEP_TRACE(const unsigned long long tr_s0 = __builtin_amdgcn_s_memtime();)
-          float2v rv[CCH / 2];
-          if (kPre > 0) {
+      }
 #pragma unroll
-            for (int c = 0; c < CCH / 2; ++c) rv[c] = rv_next[c];
-          } else {
-            load_ref(c0, rv);   // first, so that its latency overlaps the copy
-          }
-          // pieces that were not prefetched: load now, a few in flight at a time
-          constexpr int kBatch = Cfg::BATCH > 0 ? Cfg::BATCH : (NHWC ? 4 : 1);
+      for (int k = 0; k < kPre; ++k)
+        if (k * NT < n_pieces) store_piece(k, pre + k * kPreRegs, n_pieces);
+      __syncthreads();
+      SWEEP_TRACE(const unsigned long long tr_s1 = __builtin_amdgcn_s_memtime(); tr_stage += tr_s1 - tr_s0;)
+
+      // ---- the next stage's requests go out before the taps of this one ----
+      int e_next = e, c_next = c0 + CCH;
+      bool next_run = false;
+      if (c_next >= a.C) {
+        c_next = 0;
+        next_run = true;
+        e_next = n_runs;
+        for (int i = n_runs - 1; i > e; --i)
+          if ((__builtin_amdgcn_readfirstlane(s_runs[i * kRunWords]) >> 24) == 1) e_next = i;
+      }
+      const bool more = e_next < n_runs;
+      if (more) {
+        if (next_run) read_run(e_next);
+        prefetch(c_next);
+      }
+
+      // ---- taps of (run e, pass c0) ----
+      if (Cfg::FASTFULL && seg_lo == 0 && seg_hi == DP) {   // the common case as one straight-line block
 #pragma unroll
-          for (int k0 = kPre; k0 < kPieces; k0 += kBatch) {
-            if (k0 * NT < n_pieces) {   // workgroup-uniform
-              float4v v[kBatch * kPreRegs];
-#pragma unroll
-              for (int kk = 0; kk < kBatch; ++kk)
-                load_piece(k0 + kk < kPieces ? k0 + kk : kPieces - 1, c0, v + kk * kPreRegs);
-#pragma unroll
-              for (int kk = 0; kk < kBatch; ++kk)
-                if (k0 + kk < kPieces) store_piece(k0 + kk, v + kk * kPreRegs);
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < kPre; ++k)
-            if (k * NT < n_pieces) store_piece(k, pre + k * kPreRegs);
-          __syncthreads();
-          SWEEP_TRACE(const unsigned long long tr_s1 = __builtin_amdgcn_s_memtime(); tr_stage += tr_s1 - tr_s0;)
-          if (kPre > 0 && c0 + CCH < a.C) {   // the next pass's requests go out before the taps of this one
-            load_ref(c0 + CCH, rv_next);
-#pragma unroll
-            for (int k = 0; k < kPre; ++k)
-              if (k * NT < n_pieces) load_piece(k, c0 + CCH, pre + k * kPreRegs);
-          }
-#pragma unroll
-          for (int j = 0; j < DP; ++j)
-            if (j >= seg_lo && j < seg_hi)   // workgroup-uniform
-              tap_plane<QPR, REC>(tile_bytes, row_bytes, addr[j], frac[j], rv, &acc2[j]);
-          __syncthreads();
-          SWEEP_TRACE(tr_taps += __builtin_amdgcn_s_memtime() - tr_s1; ++tr_passes;)
-        }
-      } else if (box.state == 0 && !GATHER) {
-        // cannot be staged: queue the run for the second pass (this workgroup contributes nothing for it)
-        if (tid == 0) slot[1 + n_spilled] = spill_pack(m, seg_lo, seg_len);
-        ++n_spilled;
-      } else if (box.state == 0) {
-        const float* kt = s_kt + m * 3;
+        for (int j = 0; j < DP; ++j) tap_plane<QPR, REC>(tile_bytes, row_bytes, addr[j], frac[j], rv, &acc2[j]);
+      } else {
 #pragma unroll
         for (int j = 0; j < DP; ++j)
-          if (j >= seg_lo && j < seg_hi) {
-            const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j);
-            acc2[j].x += live ? gather_plane<NHWC>(a, meas, ref, HW, ray, kt[0] / depth, kt[1] / depth, kt[2] / depth, sc) : 0.0f;
-          }
+          if (j >= seg_lo && j < seg_hi)   // workgroup-uniform
+            tap_plane<QPR, REC>(tile_bytes, row_bytes, addr[j], frac[j], rv, &acc2[j]);
       }
-      // state 2: the whole footprint of the run lies outside the image -> zeros
-      seg_lo = seg_hi;
+      __syncthreads();
+      SWEEP_TRACE(const unsigned long long tr_s2 = __builtin_amdgcn_s_memtime(); tr_taps += tr_s2 - tr_s1; ++tr_passes;)
+      if (!more) break;
+      if (next_run) adopt_run();
+      SWEEP_TRACE(tr_switch += __builtin_amdgcn_s_memtime() - tr_s2;)
+      e = e_next;
+      c0 = c_next;
     }
   }
 
   // A tap outside its staged box can only come from round-off beyond the 0.05 px slack of the corner test.  It has never
   // been observed, but the result must not depend on it: the whole workgroup is redone through the gather path (second
   // pass, or inline when there is none).
-  SWEEP_TRACE(tr_loop_end = __builtin_amdgcn_s_memtime();)
+  SWEEP_TRACE(const unsigned long long tr_loop_end = __builtin_amdgcn_s_memtime();)
   const int any_violated = __syncthreads_or(violated);
-  SWEEP_TRACE(tr_sync = __builtin_amdgcn_s_memtime();)
   if (any_violated) {
 #pragma unroll
     for (int j = 0; j < DP; ++j) acc2[j] = float2v{0.0f, 0.0f};
@@ -704,11 +762,11 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
 #ifdef DVMVS_SWEEP_TRACE
   if (tid == 0 && work.group < kTraceGroups) {
     unsigned long long* t = g_sweep_trace + static_cast<size_t>(work.group) * kTraceWords;
-    t[0] = tr_start; t[1] = tr_setup; t[2] = __builtin_amdgcn_s_memtime(); t[3] = tr_box; t[4] = tr_stage; t[5] = tr_taps;
+    t[0] = tr_start; t[1] = tr_setup; t[2] = __builtin_amdgcn_s_memtime(); t[3] = tr_plan - tr_setup; t[4] = tr_stage; t[5] = tr_taps;
     t[6] = tr_passes; t[7] = tr_records; t[8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
     t[9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                                       // XCC_ID
     t[10] = tr_real0; t[11] = __builtin_amdgcn_s_memrealtime(); t[12] = static_cast<unsigned long long>(n_spilled) | (static_cast<unsigned long long>(blockIdx.x) << 32);
-    t[13] = tr_box_a; t[14] = tr_box_b; t[15] = ((tr_loop_end - tr_start) << 32) | (tr_sync - tr_loop_end);
+    t[13] = tr_switch; t[14] = static_cast<unsigned long long>(n_runs); t[15] = tr_loop_end - tr_start;
   }
 #endif
   if (!GATHER && n_spilled > 0) {
@@ -805,7 +863,7 @@ int raise_dynamic_lds_limit(Kernel kernel, size_t bytes, bool* configured) {
 }
 
 template <class Cfg, bool NHWC>
-int launch_sweep_tiled_layout(const CostVolumeArgs& a, hipStream_t stream) {
+int launch_sweep_tiled_layout(const CostVolumeArgs& a, hipStream_t stream, int spill_grid = kSpillGrid) {
   const long long tiles = static_cast<long long>((a.W + Cfg::TW - 1) / Cfg::TW) * ((a.H + Cfg::TH - 1) / Cfg::TH);
   const long long total = tiles * ((a.D + Cfg::DP - 1) / Cfg::DP) * a.B;
   if (total > (1LL << 30)) return DVMVS_EUNSUPPORTED;
@@ -825,13 +883,13 @@ int launch_sweep_tiled_layout(const CostVolumeArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(Cfg::NT), Cfg::kLdsBytes, stream, a);
   const int rc2 = launch_status();
   if (rc2 != 0) return rc2;
-  hipLaunchKernelGGL((sweep_spill_kernel<Cfg, NHWC>), dim3(kSpillGrid), dim3(Cfg::NT), 0, stream, a);
+  hipLaunchKernelGGL((sweep_spill_kernel<Cfg, NHWC>), dim3(spill_grid), dim3(Cfg::NT), 0, stream, a);
   return launch_status();
 }
 
 template <class Cfg>
-int launch_sweep_tiled(const CostVolumeArgs& a, hipStream_t stream) {
-  return a.image2_nhwc ? launch_sweep_tiled_layout<Cfg, true>(a, stream) : launch_sweep_tiled_layout<Cfg, false>(a, stream);
+int launch_sweep_tiled(const CostVolumeArgs& a, hipStream_t stream, int spill_grid = kSpillGrid) {
+  return a.image2_nhwc ? launch_sweep_tiled_layout<Cfg, true>(a, stream, spill_grid) : launch_sweep_tiled_layout<Cfg, false>(a, stream, spill_grid);
 }
 
 // the shipped configuration; the spill workspace is sized for it
@@ -844,39 +902,26 @@ size_t spill_words_for(int B, int M, int H, int W, int D) {
   return kSpillHeaderWords + groups + groups * spill_slot_words(M, Cfg::DP);
 }
 
-// sized for the finest tiling among the configurations that may use it (each launch indexes it with its own tiling)
-size_t sweep_spill_words(int B, int M, int H, int W, int D) {
-  const size_t a = spill_words_for<SweepDefault>(B, M, H, W, D), b = spill_words_for<SweepConfig<16, 4, 8, 8, 320, 2>>(B, M, H, W, D);
-  return a > b ? a : b;
-}
+size_t sweep_spill_words(int B, int M, int H, int W, int D) { return spill_words_for<SweepDefault>(B, M, H, W, D); }
 
 int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream) { return launch_sweep_tiled<SweepDefault>(a, stream); }
 
 #ifdef DVMVS_SWEEP_TUNING   // tools-only builds (`make tuning`, `make trace`); the product library carries the shipped configuration only
-// tuning configurations for tools/cv_microbench.py (TW, TH, DP, CCH, CAP, MINSEG, WAVES, XCD); the spill workspace is sized
-// for the 32x8 and 16x4 tilings, other tile shapes run single-pass (inline gather)
-int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream) {
-  CostVolumeArgs b = a;
-  b.spill = nullptr;
+// tuning configurations for tools/cv_microbench.py: <TW, TH, DP, CCH, CAP, MINSEG, WAVES, XCD, PRE, PLAN0, FASTFULL>.  All use the 32x8x8
+// tiling the spill workspace is sized for.
+int launch_sweep_tuning(int which_and_grid, const CostVolumeArgs& a, hipStream_t stream) {
+  const int which = which_and_grid & 15, g = kSpillGrid << ((which_and_grid >> 4) & 3);   // + 16 / 32 / 48: second-pass grid x 2 / 4 / 8
   switch (which) {
-    case 0: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true>>(a, stream);    // 48 KB: 3 workgroups / CU
-    case 1: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, true>>(a, stream);    // ... with register prefetch
-    case 2: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 4, 3, true>>(a, stream);    // runs of >= 4 planes, else spill
-    case 3: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 1, 3, true>>(a, stream);
-    case 4: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1280, 2, 2, true>>(a, stream);    // 60 KB: 2 / CU
-    case 5: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 768, 2, 4, true>>(a, stream);     // 36 KB: 4 / CU, <= 128 VGPRs
-    case 6: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 640, 2, 3, true>>(a, stream);     // 30 KB
-    case 7: return launch_sweep_tiled<SweepConfig<32, 8, 8, 16, 640, 2, 3, true>>(a, stream);    // 80-byte records, 50 KB
-    case 8: return launch_sweep_tiled<SweepConfig<32, 8, 8, 16, 1024, 2, 2, true>>(a, stream);   // 80 KB: 2 / CU
-    case 9: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true>>(a, stream);    // 2 waves / SIMD of registers
-    case 10: return launch_sweep_tiled<SweepConfig<16, 16, 8, 8, 1024, 2, 3, true>>(b, stream);
-    case 11: return launch_sweep_tiled<SweepConfig<32, 8, 4, 8, 768, 2, 4, true>>(b, stream);    // 4 planes / workgroup
-    case 12: return launch_sweep_tiled<SweepConfig<32, 8, 16, 8, 1536, 2, 2, true>>(b, stream);  // 16 planes, 72 KB
-    // one wave per workgroup: no barriers, every wave stages its own 16x4-pixel footprint and free-runs
-    case 15: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, false, 2>>(a, stream);   // 2 staging pieces in flight (NCHW): no gain
-    case 16: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, false, 0, 64>>(a, stream);   // staggered starts (~2 us apart): slower
-    case 13: return launch_sweep_tiled<SweepConfig<16, 4, 8, 8, 320, 2, 3, true>>(a, stream);    // 15 KB: 10 / CU
-    case 14: return launch_sweep_tiled<SweepConfig<16, 4, 8, 8, 384, 2, 2, true>>(a, stream);    // 18 KB: 8 / CU
+    case 0: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 2, true, true>>(a, stream, g);    // the shipped configuration
+    case 1: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 0, true, true>>(a, stream, g);    // no prefetch
+    case 2: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 1, true, true>>(a, stream, g);    // one piece prefetched
+    case 3: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 3, true, true>>(a, stream, g);    // three
+    case 4: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 2, false, true>>(a, stream, g);   // every wave plans
+    case 5: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 2, true, false>>(a, stream, g);   // per-plane branches only
+    case 6: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 1, 3, true, 2, true, true>>(a, stream, g);    // single-plane runs allowed
+    case 7: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true, 4, true, true>>(a, stream, g);    // 2 waves / SIMD of registers, whole pass prefetched
+    case 8: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 768, 2, 4, true, 1, true, true>>(a, stream, g);     // 36 KB: 4 / CU, <= 128 VGPRs
+    case 9: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1280, 2, 2, true, 3, true, true>>(a, stream, g);    // 60 KB: 2 / CU
     default: return DVMVS_EINVAL;
   }
 }

@@ -367,6 +367,47 @@ def long_sequence_goldens(ref):
     save("fusionnet_long", **arrays)
 
 
+def pose_algebra_goldens(ref):
+    """host_pose_algebra.npz: the small fp32 matrices of THIS host -- the one every other fixture here was captured on -- for
+    the pose pairs the fixture-comparing tests use (syn.golden_algebra_pairs), by the reference's own expressions
+    (dvmvs/utils.py:51-56, :121; dvmvs/convlstm.py:30).  torch.inverse is LAPACK and LAPACK's last bits depend on the CPU (see
+    tests/synthetic.py), so these rows are what ties the depth fixtures to inputs a test can feed on another host.
+    Checked here: the same expressions inside the reference (cost_volume_fusion on the same process) give a volume that the
+    oracle reproduces to 1e-7 from THESE matrices."""
+    sweeps, rels = syn.golden_algebra_pairs()
+    sweep_in, sweep_out, rel_in, rel_out = [], [], [], []
+    for r, m, tag in sweeps:
+        pose1, pose2, K = syn.pose(r), syn.pose(m), syn.golden_algebra_K(tag)
+        extrinsic2 = torch.inverse(pose2).bmm(pose1)
+        R = extrinsic2[:, 0:3, 0:3]
+        t = extrinsic2[:, 0:3, 3].unsqueeze(-1)
+        Kt = K.bmm(t)
+        K_R_Kinv = K.bmm(R).bmm(torch.inverse(K))
+        sweep_in.append(torch.cat([pose1.reshape(-1), pose2.reshape(-1), K.reshape(-1)]).numpy())
+        sweep_out.append(torch.cat([K_R_Kinv.reshape(-1), Kt.reshape(-1)]).numpy())
+    for a, c in rels:
+        pa, pc = syn.pose(a), syn.pose(c)
+        rel_in.append(torch.cat([pa.reshape(-1), pc.reshape(-1)]).numpy())
+        rel_out.append(torch.bmm(torch.inverse(pa), pc).reshape(-1).numpy())
+    save("host_pose_algebra", sweep_in=np.stack(sweep_in), sweep_out=np.stack(sweep_out), rel_in=np.stack(rel_in), rel_out=np.stack(rel_out))
+    # the reference itself, fed these poses, lands on the volume the oracle computes FROM THE RECORDED MATRICES
+    table = syn.FixtureHostAlgebra()
+    halfK = syn.scaled_K(syn.full_K(), 2.0)
+    feats = [syn.analytic_features(s) for s in range(3)]
+    grid = ref.utils.get_warp_grid_for_cost_volume_calculation(160, 128, CPU)
+    cv = ref.utils.cost_volume_fusion(feats[0], [feats[1], feats[2]], syn.pose(202), [syn.pose(196), syn.pose(188)], halfK, grid, 0.25, 20.0, 64, CPU, True)
+    saved = ref.oracle.plane_sweep_setup
+    ref.oracle.plane_sweep_setup = table.plane_sweep_setup
+    try:
+        ocv = ref.oracle.cost_volume_fusion(feats[0], [feats[1], feats[2]], syn.pose(202), [syn.pose(196), syn.pose(188)], halfK, 0.25, 20.0, 64, True)
+    finally:
+        ref.oracle.plane_sweep_setup = saved
+    REPORT["host_pose_algebra_replay"] = {"pairs": len(sweeps), "relative_poses": len(rels),
+                                          "reference_vs_oracle_from_recorded_matrices_max_abs": maxdiff(cv, ocv)}
+    print("host pose algebra:", REPORT["host_pose_algebra_replay"])
+    assert maxdiff(cv, ocv) < 5e-7
+
+
 def keyframe_goldens(ref):
     """Replays the reference KeyframeBuffer over the sample poses; must reproduce the shipped index files."""
     poses = syn.sample_poses()
@@ -491,11 +532,15 @@ def main():
     if "--only-long-sequence" in sys.argv:
         long_sequence_goldens(ref)
         return
+    if "--only-pose-algebra" in sys.argv:
+        pose_algebra_goldens(ref)
+        return
     cost_volume_goldens(ref)
     de16 = reprojection_goldens(ref)
     lstm_goldens(ref, de16)
     end_to_end_goldens(ref)
     long_sequence_goldens(ref)
+    pose_algebra_goldens(ref)
     keyframe_goldens(ref)
     error_metric_goldens(ref)
     loss_goldens(ref)

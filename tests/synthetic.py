@@ -234,6 +234,74 @@ def keyframe_index_lines(n_meas=2):
     return out
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# host pose algebra of the fixture host
+# ----------------------------------------------------------------------------------------------------------------------
+# The reference evaluates its few small matrices with fp32 LAPACK (torch.inverse -> MKL getrf/getrs).  MKL picks its kernels by
+# CPU, so the last bits of an fp32 4x4 inverse differ between hosts (observed: the Intel build container the fixtures were
+# captured on vs the AMD host of the GPU box; the resulting relative translations differ by ~1e-7 m, i.e. as much as either is
+# off the real-number result).  A fixture captured from the reference on one host therefore pins the DEPTH only together with
+# the matrices that host computed.  tests/golden/host_pose_algebra.npz holds them (make_goldens.pose_algebra_goldens: the
+# reference's expressions, evaluated in the same process as the reference run), keyed by the exact input bits, for every pose
+# pair the fixture-comparing tests use; the `fixture_host_algebra` pytest fixture replays them in place of the local LAPACK.
+def golden_algebra_pairs():
+    """(sweep pairs [(ref, meas, K tag)], relative-pose pairs [(a, c)]) whose matrices the fixture host recorded."""
+    sweeps, rels = set(), set()
+    for n_meas in (1, 2, 3):
+        lines = keyframe_index_lines(n_meas)
+        for r, ms in lines:
+            sweeps.update((r, m, "half") for m in ms)
+        for (r0, _), (r1, _) in zip(lines, lines[1:]):
+            rels.update([(r1, r0), (r0, r1)])
+    for r in range(0, 40):
+        for m in range(max(0, r - 12), r + 3):
+            sweeps.add((r, m, "half"))
+            rels.update([(r, m), (m, r)])
+    for r, ms in ((141, (135, 130, 120)), (202, (196, 188, 180)), (170, (168, 167, 160)), (166, (165, 164)), (278, (277, 276))):
+        sweeps.update((r, m, "half") for m in ms)
+        rels.update((r, m) for m in ms)
+        rels.update((m, r) for m in ms)
+    for r, ms in ((12, (9, 3)), (23, (22, 21, 20)), (141, (135,))):
+        sweeps.update((r, m, "small") for m in ms)
+    return sorted(sweeps), sorted(rels)
+
+
+def golden_algebra_K(tag):
+    half = scaled_K(full_K(), 2.0)
+    return half if tag == "half" else scaled_K(half, 4.0)
+
+
+class FixtureHostAlgebra:
+    """Replays the fixture host's fp32 pose algebra (host_pose_algebra.npz) for inputs whose bits it has seen; anything else
+    raises KeyError (add the pair to golden_algebra_pairs and regenerate)."""
+
+    def __init__(self, path=None):
+        import numpy as np
+        z = np.load(path or os.path.join(GOLDEN_DIR, "host_pose_algebra.npz"))
+        self.sweep = {z["sweep_in"][i].tobytes(): z["sweep_out"][i] for i in range(len(z["sweep_in"]))}
+        self.rel = {z["rel_in"][i].tobytes(): z["rel_out"][i] for i in range(len(z["rel_in"]))}
+
+    @staticmethod
+    def _row(*tensors):
+        import numpy as np
+        return np.concatenate([t.detach().cpu().contiguous().numpy().astype(np.float32).reshape(-1) for t in tensors]).tobytes()
+
+    def relative_pose_host(self, a, c):
+        out = [self.rel[self._row(a[b], c[b])] for b in range(a.shape[0])]
+        return torch.from_numpy(__import__("numpy").stack(out)).reshape(-1, 4, 4).clone()
+
+    def sweep_matrices_host(self, pose1, pose2s, K):
+        import numpy as np
+        B, M = pose1.shape[0], len(pose2s)
+        rows = np.stack([np.stack([self.sweep[self._row(pose1[b], pose2s[m][b], K[b])] for m in range(M)]) for b in range(B)])   # [B,M,12]
+        rows = torch.from_numpy(rows)
+        return rows[:, :, :9].contiguous().clone(), rows[:, :, 9:].contiguous().clone()
+
+    def plane_sweep_setup(self, pose1, pose2, K):    # oracle/dvmvs_oracle.py's signature: (KRKinv [B,3,3], Kt [B,3,1])
+        Hm, kt = self.sweep_matrices_host(pose1, [pose2], K)
+        return Hm[:, 0].reshape(-1, 3, 3), kt[:, 0].reshape(-1, 3, 1)
+
+
 def sample_image_names():
     """Sorted image file names of the sample scene (row i of poses.txt belongs to the i-th name)."""
     with open(os.path.join(GOLDEN_DIR, "hololens_000_image_names.txt")) as f:

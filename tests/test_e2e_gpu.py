@@ -75,7 +75,7 @@ def reference_pipeline(mods):
 
 
 @pytest.mark.parametrize("mode", ["eager_unfolded", "graphs_folded_cached"])
-def test_fusionnet_three_frames_match_the_reference(hip_device, golden_dir, mode):
+def test_fusionnet_three_frames_match_the_reference(hip_device, golden_dir, mode, fixture_host_algebra):
     """Free-running engine over the 3 golden frames (twice in the graph mode, so that both frame kinds are replayed graphs)."""
     from dvmvs.hip import ops
     z = np.load(os.path.join(golden_dir, "fusionnet_e2e.npz"))
@@ -152,7 +152,7 @@ def run_teacher_forced(engine, reference, dev, frames, expected_sub4):
 
 
 @pytest.mark.parametrize("mode", ["eager_unfolded", "graphs_folded_cached"])
-def test_fusionnet_frames_from_the_reference_state(hip_device, golden_dir, mode):
+def test_fusionnet_frames_from_the_reference_state(hip_device, golden_dir, mode, fixture_host_algebra):
     """Teacher forcing over the 3 golden frames and the 14-keyframe reference run (tracking loss, wide-baseline lines 200-204,
     249-251): given the reference's inputs and state, EVERY frame's depth is within ENGINE_VS_REFERENCE of the reference's, and
     the engine's z-buffer decision on the reference's previous depth has 0 flipped pixels."""
@@ -173,7 +173,7 @@ def test_fusionnet_frames_from_the_reference_state(hip_device, golden_dir, mode)
             assert flipped == 0, (name, n, flipped)
 
 
-def test_fusionnet_long_reference_run(hip_device, golden_dir):
+def test_fusionnet_long_reference_run(hip_device, golden_dir, fixture_host_algebra):
     """Free-running engine as benchmarked (BN folded, feature cache, hipGraph replay) over the REFERENCE's 14-keyframe run
     (tests/golden/fusionnet_long.npz).  Per frame: depth rel-L1 vs the reference and the number of low-resolution estimate pixels
     that differ from the reference's; tight bound while the run is on the reference's inputs, sanity bound after the first
@@ -215,7 +215,7 @@ def test_fusionnet_long_reference_run(hip_device, golden_dir):
     assert sum(r["on_reference_inputs"] for r in rows) >= 4
 
 
-def test_pairnet_frame_matches_the_reference(hip_device, golden_dir):
+def test_pairnet_frame_matches_the_reference(hip_device, golden_dir, fixture_host_algebra):
     z = np.load(os.path.join(golden_dir, "pairnet_e2e.npz"))
     dev = hip_device
     mods, engine = build(dev, fusion=False, fold_bn=True, cache_features=False, use_graphs=False)

@@ -89,7 +89,7 @@ def run_cv(ops, dev, f1, f2s, p1, p2s, K, lo, hi, D, dot, variant):
 # cost volume
 # ----------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_cost_volume_small_goldens(ops, dev, golden_dir, variant):
+def test_cost_volume_small_goldens(ops, dev, golden_dir, variant, fixture_host_algebra):
     z = load(golden_dir, "cost_volume_small")
     K = torch.from_numpy(z["K"])
     feats = [syn.analytic_features(s, 8, 32, 40) for s in range(4)]
@@ -108,7 +108,7 @@ def test_cost_volume_small_goldens(ops, dev, golden_dir, variant):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_cost_volume_full_size_known_answers(ops, dev, golden_dir, variant):
+def test_cost_volume_full_size_known_answers(ops, dev, golden_dir, variant, fixture_host_algebra):
     """320x256 -> 160x128 features, 32 channels, 64 planes (BASELINE.json config): KAT-CV, behind-camera pair, noise."""
     z = load(golden_dir, "cost_volume_full_pins")
     halfK = syn.scaled_K(syn.full_K(), 2.0)
@@ -131,7 +131,7 @@ def test_cost_volume_full_size_known_answers(ops, dev, golden_dir, variant):
     check_pins(ncv, z, "noise", atol=5e-5)
 
 
-def test_cost_volume_sad_known_answer(ops, dev, golden_dir):
+def test_cost_volume_sad_known_answer(ops, dev, golden_dir, fixture_host_algebra):
     """The baselines' mode: RGB (C=3), SAD, 0.5-50 m (KAT-SAD)."""
     z = load(golden_dir, "cost_volume_full_pins")
     halfK = syn.scaled_K(syn.full_K(), 2.0)
@@ -180,8 +180,11 @@ def test_cost_volume_properties_full_size(ops, dev, variant):
     cv_c = run_cv(ops, dev, f[0], [f[3]], syn.pose(10), [syn.pose(6)], halfK, **args)
     fused = run_cv(ops, dev, f[0], [f[2], f[3]], syn.pose(10), [syn.pose(9), syn.pose(6)], halfK, **args)
     assert maxerr(fused, (cv_a + cv_c) / 2) < 1e-6
-    # identical poses: every plane samples at u*(W-1)/W, v*(H-1)/H, independent of depth
-    same = run_cv(ops, dev, f[0], [f[2]], syn.pose(10), [syn.pose(10)], halfK, **args)
+    # identical poses: every plane samples at u*(W-1)/W, v*(H-1)/H, independent of depth.  (With the "exact" pose algebra:
+    # inverse(P) @ P is the identity only up to fp32 round-off in the reference's own arithmetic, which leaves a K t of ~1e-6 that
+    # the near planes turn into a 5e-5 difference between plane 0 and plane 63 -- faithfully reproduced in the default mode.)
+    same = hipcall.cost_volume(ops, f[0].to(dev), [f[2].to(dev)], syn.pose(10).to(dev), [syn.pose(10).to(dev)], halfK.to(dev),
+                               0.25, 20.0, 64, True, variant, mode="exact")
     assert maxerr(same[:, 0], same[:, 63]) < 2e-5
     ys, xs = torch.meshgrid(torch.arange(128.0), torch.arange(160.0), indexing="ij")
     warped = orc.bilinear_zeros_gather(f[2], (xs * 159 / 160).reshape(1, -1), (ys * 127 / 128).reshape(1, -1)).reshape(1, 32, 128, 160)
@@ -287,7 +290,9 @@ def test_cost_volume_gradients(ops, dev, golden_dir):
     sf = [syn.analytic_features(s, 8, 32, 40) for s in range(3)]
     f1 = sf[0].to(dev).requires_grad_(True)
     f2 = [sf[1].to(dev).requires_grad_(True), sf[2].to(dev).requires_grad_(True)]
-    out = hipcall.cost_volume(ops, f1, f2, syn.pose(12).to(dev), [syn.pose(9).to(dev), syn.pose(3).to(dev)], K.to(dev), 0.25, 20.0, 16, True, 0)
+    # the golden was captured on the fixture host: feed the kernel that host's matrices (tests/synthetic.py, "host pose algebra")
+    Hm, kt = syn.FixtureHostAlgebra().sweep_matrices_host(syn.pose(12), [syn.pose(9), syn.pose(3)], K)
+    out = ops.cost_volume(f1, f2, Hm.to(dev), kt.to(dev), 0.25, 20.0, 16, True, 0)
     out.backward(torch.from_numpy(z["grad_out"]).to(dev))
     # the same gradients in float64 (oracle autograd) arbitrate between the reference's fp32 round-off and ours
     d1 = sf[0].double().requires_grad_(True)
@@ -351,7 +356,7 @@ def splat_agrees(got, exp, max_moved=20, rtol=2e-6):
     return moved + flipped
 
 
-def test_depth_reprojection(ops, utils, dev, golden_dir):
+def test_depth_reprojection(ops, utils, dev, golden_dir, fixture_host_algebra):
     z = load(golden_dir, "reproject")
     fullK = syn.full_K()
     halfK = syn.scaled_K(fullK, 2.0)

@@ -10,7 +10,12 @@ no MIOpen summation order, no BN folding, no graph replay.
 
 Since ABI 3 the kernels are handed the reference's own small matrices (dvmvs.pose_algebra, "reference" mode: the fp32 host
 expressions of utils.py:51-56, :121 and convlstm.py:30), so they sample at the reference's positions bit for bit and what is
-left is summation order inside the kernels (~1e-7 of the cost volume).  Assertions:
+left is summation order inside the kernels (~1e-5 of the cost volume).  One caveat, measured in round 3: those expressions
+contain torch.inverse = fp32 LAPACK, whose last bits depend on the host CPU (MKL dispatches by CPU; Intel build container vs
+the GPU box's AMD host).  Comparisons against FIXTURES (captured from the reference on the build container) therefore replay
+that host's matrices (tests/golden/host_pose_algebra.npz through the `fixture_host_algebra` fixture); comparisons against the
+oracle running on the same host as the test need nothing.  With the local LAPACK instead, the hybrid sits 1.6e-5 .. 7.6e-5 from
+the fixtures until the first z-buffer pixel flips -- the distance between two hosts running the REFERENCE.  Assertions:
 
 1. hybrid vs the REFERENCE golden depth (3 frames of fusionnet_e2e.npz, then the 14-keyframe reference run of
    fusionnet_long.npz with a tracking loss and the spilling wide-baseline lines): <= 1e-4 on EVERY frame (the north-star
@@ -76,7 +81,7 @@ def flipped_pixels(a, b):
     return int(np.sum(np.abs(a - b) > 1e-3 * np.maximum(np.maximum(a, b), 1e-3)))
 
 
-def test_hybrid_pipeline_matches_the_reference_goldens(hip_device, golden_dir):
+def test_hybrid_pipeline_matches_the_reference_goldens(hip_device, golden_dir, fixture_host_algebra):
     """3 golden frames: hot path on the GPU, convolutions as in the reference run -> depth vs the reference's depth."""
     from hybrid import HipHotPath
     z = np.load(os.path.join(golden_dir, "fusionnet_e2e.npz"))
@@ -104,7 +109,7 @@ def test_hybrid_pipeline_matches_the_reference_goldens(hip_device, golden_dir):
         assert row["flipped_estimate_pixels_vs_reference"] == 0, row
 
 
-def test_hybrid_pipeline_matches_the_long_reference_run(hip_device, golden_dir):
+def test_hybrid_pipeline_matches_the_long_reference_run(hip_device, golden_dir, fixture_host_algebra):
     """fusionnet_long.npz: the REFERENCE's own loop over 14 keyframes (make_goldens.long_sequence_goldens) incl. a tracking loss
     and index lines 200-204 / 249-251, against the hybrid pipeline: depth <= 1e-4 and 0 flipped estimate pixels, every frame."""
     from hybrid import HipHotPath

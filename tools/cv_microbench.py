@@ -2,13 +2,16 @@
 geometry (lines of the sample scene's nmeas+2 index) and cross-checks every variant against the generic kernel.
 Run on the GPU box:
 
-    python tools/cv_microbench.py [--lines 0,40,117,202] [--variants 3,2,32,33] [--layouts nchw,nhwc] [--batch 1]
+    python tools/cv_microbench.py [--lines 0,40,117,202] [--variants 0,32,33] [--layouts nchw,nhwc] [--batch 1] [--lib tuning]
 
-Each (geometry, layout, variant) is captured into a hipGraph of REPS back-to-back launches and timed with HIP events
-(no host gaps).  Variant numbers: include/dvmvs_hip.h (0-3) and the tuning tables in csrc/ (16.. legacy, 32.. sweep).
-Prints one table (us per launch) and writes it as JSON when --out is given.
+Each (geometry, layout, variant) is captured into a hipGraph of REPS back-to-back ops and timed with HIP events (no host gaps).
+Variant numbers: include/dvmvs_hip.h (0-2); 32 + k = tuning configuration k of csrc/sweep_tiled.hip (+ 16 / 32 / 48: second-pass
+grid of 512 / 1024 / 2048 workgroups), which exist only in the tools-only library built by `make -C deep-video-mvs_amd/csrc tuning`
+(--lib tuning) -- the product library answers them with "invalid argument".
+Prints one table (us per op) and writes it as JSON when --out is given.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -20,39 +23,45 @@ for p in (os.path.join(ROOT, "deep-video-mvs_amd"), os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import synthetic as syn  # noqa: E402
+from dvmvs import pose_algebra  # noqa: E402
 from dvmvs.hip import _capi  # noqa: E402
 
 
 def index_lines(nmeas=2):
-    names = {n: i for i, n in enumerate(syn.sample_image_names())}
-    path = os.path.join(ROOT, "tests", "golden", "indices", f"keyframe+hololens-dataset+000+nmeas+{nmeas}")
-    out = []
-    for line in open(path):
-        parts = line.split()
-        if len(parts) == nmeas + 1 and all(p in names for p in parts):
-            out.append([names[p] for p in parts])
-    return out
+    return [[r] + list(ms) for r, ms in syn.keyframe_index_lines(nmeas)]
+
+
+def load_library(which):
+    """The product library, or one of the tools-only builds (same C ABI) next to it."""
+    if which == "product":
+        return _capi.lib()
+    lib = ctypes.CDLL(os.path.join(ROOT, "deep-video-mvs_amd", "lib", f"libdvmvs_hip_{which}.so"))
+    for name, (restype, argtypes) in _capi.SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+    return lib
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--variants", default="3,2")
+    ap.add_argument("--variants", default="0")
     ap.add_argument("--layouts", default="nchw")
     ap.add_argument("--lines", default="0,40,80,117,170,202,250", help="index lines; -1 = the synthetic sideways trajectory")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--lib", default="product", choices=["product", "tuning", "trace"])
     ap.add_argument("--small-workspace", action="store_true", help="no spill workspace (single-pass sweep, inline gather)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    lib = _capi.lib()
+    lib = load_library(args.lib)
     B, C, H, W, D, M = args.batch, 32, 128, 160, 64, args.m
     variants = [int(v) for v in args.variants.split(",")]
     layouts = args.layouts.split(",")
     feats = [torch.cat([syn.smooth_noise((1, C, H, W), seed=300 + 10 * b + i) for b in range(B)]).to(dev) for i in range(M + 1)]
     feats_cl = [t.contiguous(memory_format=torch.channels_last) for t in feats[1:]]
-    K = syn.scaled_K(syn.full_K(), 2.0).repeat(B, 1, 1).to(dev)
+    K = syn.scaled_K(syn.full_K(), 2.0).repeat(B, 1, 1)
     allp = torch.from_numpy(syn.sample_poses()).float()
     lines = index_lines(2)
     ws_bytes = 0 if args.small_workspace else lib.dvmvs_cost_volume_workspace_bytes(B, M, H, W, D)
@@ -60,7 +69,7 @@ def main():
     out = torch.empty(B, D, H, W, device=dev)
     ref_out = torch.empty_like(out)
     alg_bytes = (1 + M) * B * C * H * W * 4 + B * D * H * W * 4
-    print(f"shape B={B} C={C} {H}x{W} D={D} M={M}; algorithmic bytes {alg_bytes}")
+    print(f"shape B={B} C={C} {H}x{W} D={D} M={M}; algorithmic bytes {alg_bytes}; library: {args.lib}")
     results = {}
     for li in [int(v) for v in args.lines.split(",")]:
         if li < 0:
@@ -68,17 +77,18 @@ def main():
             ids, pose_src = [8, 7, 6], traj
         else:
             ids, pose_src = lines[li], allp
-        pose1 = pose_src[ids[0]:ids[0] + 1].repeat(B, 1, 1).to(dev)
-        pose2s = [pose_src[i:i + 1].repeat(B, 1, 1).to(dev) for i in (ids[1:] * M)[:M]]
-        pose_ptrs = _capi.pointer_array([t.data_ptr() for t in pose2s])
+        pose1 = pose_src[ids[0]:ids[0] + 1].repeat(B, 1, 1)
+        pose2s = [pose_src[i:i + 1].repeat(B, 1, 1) for i in (ids[1:] * M)[:M]]
+        Hm, kt = pose_algebra.sweep_matrices(pose1, pose2s, K, dev, "reference")
 
         def launch(variant, dst, layout):
             meas = feats_cl if layout == "nhwc" else feats[1:]
             img_ptrs = _capi.pointer_array([t.data_ptr() for t in meas])
-            rc = lib.dvmvs_cost_volume_fwd(feats[0].data_ptr(), img_ptrs, pose1.data_ptr(), pose_ptrs, K.data_ptr(), dst.data_ptr(),
+            rc = lib.dvmvs_cost_volume_fwd(feats[0].data_ptr(), img_ptrs, Hm.data_ptr(), kt.data_ptr(), dst.data_ptr(),
                                            B, M, C, H, W, D, 0.25, 20.0, 1, variant, 1 if layout == "nhwc" else 0,
                                            ws.data_ptr() if ws_bytes else None, ws_bytes, torch.cuda.current_stream().cuda_stream)
-            _capi.check(rc, f"variant {variant}")
+            if rc != 0:
+                raise RuntimeError(f"variant {variant}: code {rc}: {lib.dvmvs_error_string(rc).decode()}")
 
         launch(1, ref_out, "nchw")      # generic kernel on NCHW maps = the cross-check
         torch.cuda.synchronize()
