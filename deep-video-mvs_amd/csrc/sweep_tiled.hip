@@ -386,12 +386,12 @@ __device__ unsigned long long g_sweep_trace[kTraceGroups * kTraceWords];
 // current one and held in registers until the LDS tile is free again -- the global-load round trip of a pass (0.65 us of the
 // workgroup's dependency chain per pass in round 2's timeline, eight passes per workgroup) then overlaps the LDS-bound tap phase.
 // Pieces beyond PRE (boxes larger than PRE * NT records) are loaded after the taps as before.
-template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, bool XCD_ = true, int PRE_ = 2, bool PLAN0_ = true,
+template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, int ORDER_ = 2, int PRE_ = 2, bool PLAN0_ = true,
           bool FASTFULL_ = true>
 struct SweepConfig {
   static constexpr int TW = TW_, TH = TH_, DP = DP_, CCH = CCH_, CAP = CAP_, MINSEG = MINSEG_;
   static constexpr int WAVES = WAVES_;   // waves per SIMD the register allocation is held to
-  static constexpr bool XCD = XCD_;      // XCD-aware workgroup numbering
+  static constexpr int ORDER = ORDER_;    // workgroup numbering, see decode_work
   static constexpr int PRE = PRE_;       // prefetched staging pieces per thread (NCHW; x2 for channels-last quads), 0 = none
   static constexpr bool PLAN0 = PLAN0_;  // the run plan is made by wave 0 only (the other waves wait at the barrier)
   static constexpr bool FASTFULL = FASTFULL_;   // straight-line tap block for runs that cover the whole chunk
@@ -402,22 +402,38 @@ struct SweepConfig {
   static_assert(NT % 64 == 0 && MINSEG >= 1 && MINSEG <= DP && DP <= 32, "workgroup shape");
 };
 
-// Decodes the linear workgroup number.  XCD-aware: XCD = blockIdx % 8 gets a contiguous range of (batch, tile, chunk) work
-// items, tile-major, so the chunks of a tile and its row neighbours share one L2.  Near chunks first within a tile (their
-// footprints are the large ones).  `group` is the work item's number in (batch, tile, chunk) order.
+// Decodes the linear workgroup number into a (batch, tile, chunk) work item; `group` is the item's number in (batch, tile, chunk)
+// order (it indexes the spill slots).
+//   ORDER 0: linear.
+//   ORDER >= 1, XCD-aware: XCD = blockIdx % 8 gets a contiguous range of items (tile-major), so the 8 plane chunks of a tile and its
+//     row neighbours are fetched into ONE L2.  Within the range any permutation keeps that property; what it decides is which work
+//     items share a CU: the dispatcher deals an XCD's workgroups round its 32 CUs (number k lands with k + 32 and k + 64, all
+//     resident from the first microsecond), and a workgroup's cost is set by its chunk -- far chunks tap all four channel passes of
+//     both frames (the LDS-bound part), near chunks often see their footprint leave the image and finish in a third of the time.
+//   ORDER 1: tile-major within the XCD (round 2): with 8 chunks per tile, k, k + 32 and k + 64 are the SAME chunk of three tiles, so
+//     a quarter of the CUs get three far chunks each and decide the launch time while others idle (timeline: 33 us span, 22 us mean).
+//   ORDER 2: chunk-major within the XCD, far chunks first: every CU gets a far, a middle and (half of them) a near chunk.
+//   ORDER 3: tile-major with the chunk rotated by 3 per dispatch round (k, k + 32, k + 64 get chunks c, c + 3, c + 6).
 struct SweepWork {
   int b, tile, chunk, group;
   bool valid;
 };
 
-template <bool XCD>
+template <int ORDER>
 __device__ inline SweepWork decode_work(int block, int tiles, int chunks, int B) {
   SweepWork w;
   const int per_b = tiles * chunks, total = per_b * B;
   int v = block;
-  if (XCD) {
+  if (ORDER >= 1) {
     const int per_xcd = (total + 7) / 8;
-    v = (block & 7) * per_xcd + (block >> 3);
+    int l = block >> 3;   // position within the XCD's range
+    if (ORDER == 2 && per_xcd % chunks == 0) {
+      const int rows = per_xcd / chunks;                      // tiles in this XCD's range
+      l = (l % rows) * chunks + (chunks - 1 - l / rows);      // chunk index l / rows counts from the far end
+    } else if (ORDER == 3 && per_xcd % chunks == 0) {
+      l = (l / chunks) * chunks + (l % chunks + 3 * (l / 32)) % chunks;
+    }
+    v = (block & 7) * per_xcd + l;
   }
   w.valid = v < total;
   w.group = v;
@@ -444,7 +460,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
 
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
   const int chunks = (a.D + DP - 1) / DP;
-  const SweepWork work = decode_work<Cfg::XCD>(blockIdx.x, tiles_x * tiles_y, chunks, a.B);
+  const SweepWork work = decode_work<Cfg::ORDER>(blockIdx.x, tiles_x * tiles_y, chunks, a.B);
   if (!work.valid) return;
   const int b = work.b;
   const int tile_y = work.tile / tiles_x, tile_x = work.tile - tile_y * tiles_x;
@@ -867,7 +883,7 @@ int launch_sweep_tiled_layout(const CostVolumeArgs& a, hipStream_t stream, int s
   const long long tiles = static_cast<long long>((a.W + Cfg::TW - 1) / Cfg::TW) * ((a.H + Cfg::TH - 1) / Cfg::TH);
   const long long total = tiles * ((a.D + Cfg::DP - 1) / Cfg::DP) * a.B;
   if (total > (1LL << 30)) return DVMVS_EUNSUPPORTED;
-  const unsigned int grid = static_cast<unsigned int>(Cfg::XCD ? (total + 7) / 8 * 8 : total);
+  const unsigned int grid = static_cast<unsigned int>(Cfg::ORDER >= 1 ? (total + 7) / 8 * 8 : total);
   if (a.spill == nullptr) {
     static bool configured[kMaxDevices] = {};
     auto kernel = sweep_tiled_kernel<Cfg, NHWC, true>;
@@ -893,7 +909,7 @@ int launch_sweep_tiled(const CostVolumeArgs& a, hipStream_t stream, int spill_gr
 }
 
 // the shipped configuration; the spill workspace is sized for it
-using SweepDefault = SweepConfig<32, 8, 8, 8, 1024, 2>;
+using SweepDefault = SweepConfig<32, 8, 8, 8, 1024, 2>;   // <TW, TH, DP, CCH, CAP, MINSEG>: 3 workgroups / CU, chunk-major numbering, 2 pieces prefetched
 
 template <class Cfg>
 size_t spill_words_for(int B, int M, int H, int W, int D) {
@@ -907,21 +923,20 @@ size_t sweep_spill_words(int B, int M, int H, int W, int D) { return spill_words
 int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream) { return launch_sweep_tiled<SweepDefault>(a, stream); }
 
 #ifdef DVMVS_SWEEP_TUNING   // tools-only builds (`make tuning`, `make trace`); the product library carries the shipped configuration only
-// tuning configurations for tools/cv_microbench.py: <TW, TH, DP, CCH, CAP, MINSEG, WAVES, XCD, PRE, PLAN0, FASTFULL>.  All use the 32x8x8
+// tuning configurations for tools/cv_microbench.py: <TW, TH, DP, CCH, CAP, MINSEG, WAVES, ORDER, PRE, PLAN0, FASTFULL>.  All use the 32x8x8
 // tiling the spill workspace is sized for.
 int launch_sweep_tuning(int which_and_grid, const CostVolumeArgs& a, hipStream_t stream) {
-  const int which = which_and_grid & 15, g = kSpillGrid << ((which_and_grid >> 4) & 3);   // + 16 / 32 / 48: second-pass grid x 2 / 4 / 8
+  const int which = which_and_grid & 15, g = kSpillGrid << ((which_and_grid >> 4) & 3);   // + 16: second-pass grid x 2
   switch (which) {
-    case 0: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 2, true, true>>(a, stream, g);    // the shipped configuration
-    case 1: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 0, true, true>>(a, stream, g);    // no prefetch
-    case 2: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 1, true, true>>(a, stream, g);    // one piece prefetched
-    case 3: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 3, true, true>>(a, stream, g);    // three
-    case 4: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 2, false, true>>(a, stream, g);   // every wave plans
-    case 5: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, true, 2, true, false>>(a, stream, g);   // per-plane branches only
-    case 6: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 1, 3, true, 2, true, true>>(a, stream, g);    // single-plane runs allowed
-    case 7: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, true, 4, true, true>>(a, stream, g);    // 2 waves / SIMD of registers, whole pass prefetched
-    case 8: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 768, 2, 4, true, 1, true, true>>(a, stream, g);     // 36 KB: 4 / CU, <= 128 VGPRs
-    case 9: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1280, 2, 2, true, 3, true, true>>(a, stream, g);    // 60 KB: 2 / CU
+    case 0: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 2, 2, true, true>>(a, stream, g);    // the shipped configuration
+    case 1: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 1, 2, true, true>>(a, stream, g);    // round 2's tile-major numbering
+    case 2: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 3, 2, true, true>>(a, stream, g);    // rotated chunks
+    case 3: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 2, 3, true, true>>(a, stream, g);    // three pieces prefetched
+    case 4: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 2, 0, true, true>>(a, stream, g);    // no prefetch
+    case 5: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 2, 2, true, false>>(a, stream, g);   // per-plane branches only
+    case 6: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, 2, 4, true, true>>(a, stream, g);    // 2 waves / SIMD of registers, whole pass prefetched
+    case 7: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1280, 2, 2, 2, 3, true, true>>(a, stream, g);    // 60 KB: 2 / CU
+    case 8: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 0, 2, true, true>>(a, stream, g);    // linear numbering (no XCD awareness)
     default: return DVMVS_EINVAL;
   }
 }

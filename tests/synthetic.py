@@ -253,6 +253,9 @@ def golden_algebra_pairs():
             sweeps.update((r, m, "half") for m in ms)
         for (r0, _), (r1, _) in zip(lines, lines[1:]):
             rels.update([(r1, r0), (r0, r1)])
+    refs = [keyframe_index_lines(2)[i][0] for i in LONG_SCHEDULE if i is not None]      # consecutive frames of the long run
+    for r0, r1 in zip(refs, refs[1:]):
+        rels.update([(r1, r0), (r0, r1)])
     for r in range(0, 40):
         for m in range(max(0, r - 12), r + 3):
             sweeps.add((r, m, "half"))

@@ -56,8 +56,8 @@ def build(dev, fusion=True, **kw):   # kw: DepthEngine options (fold_bn, cache_f
 #   by the previous DEPTH (utils.py:136-154) -- takes one pixel from a different source point than the reference did, which a
 #   1e-4 perturbation of the previous depth does on some frames; from there on the two runs see different inputs and only a
 #   sanity bound applies.  Which frame that is depends on MIOpen's algorithm choice; it is reported, not asserted.
-REL_L1_TARGET = 1e-4
-ENGINE_VS_REFERENCE = 2.5e-4      # two float32 evaluations of the same ~50-layer network, each ~1e-4 from exact
+REL_L1_TARGET = 1e-4              # the north-star bound: asserted frame by frame from the reference's state (measured 3.7e-5 .. 7.0e-5)
+ENGINE_VS_REFERENCE = 1.5e-4      # free-running, while on the reference's inputs: the per-frame difference compounds through h, c (measured <= 8.4e-5)
 AFTER_A_FLIPPED_PIXEL = 5e-2      # sanity bound once the discrete depth estimate differs
 
 
@@ -120,8 +120,10 @@ def test_fusionnet_three_frames_match_the_reference(hip_device, golden_dir, mode
 def run_teacher_forced(engine, reference, dev, frames, expected_sub4):
     """Every frame from the REFERENCE's state: (h, c, previous depth, previous pose) of the all-CPU reference pipeline are
     installed in the engine before the step.  ``frames``: (reference pose index, measurement indices) or None = tracking loss.
-    Returns [(step, engine-vs-reference-pipeline rel-L1 (full resolution), engine-vs-golden rel-L1 (sub-sampled) or None,
-    flipped estimate pixels)]."""
+    Returns [(step, engine-vs-reference-pipeline rel-L1 (full resolution), engine-vs-golden rel-L1 (sub-sampled),
+    estimate pixels on which the engine's z-buffer decision differs from the pipeline's, estimate pixels on which the PIPELINE
+    differs from the golden run (the CPU pipeline is itself a float32 evaluation ~1e-5 from the reference run; once one of its
+    own estimate pixels flips it stops being a stand-in for the golden until the next restart))]."""
     from dvmvs.hip import ops
     fullK = syn.full_K()
     fullK_dev, halfK_dev = fullK.to(dev), syn.scaled_K(fullK, 2.0).to(dev)
@@ -132,7 +134,7 @@ def run_teacher_forced(engine, reference, dev, frames, expected_sub4):
             reference.reset()
             continue
         r, ms = item
-        flipped = 0
+        flipped, pipeline_flipped = 0, 0
         if reference.previous_depth is not None:
             h, c = reference.lstm_state
             engine.load_state(h.to(dev), c.to(dev), reference.previous_depth.to(dev), reference.previous_pose)
@@ -145,9 +147,10 @@ def run_teacher_forced(engine, reference, dev, frames, expected_sub4):
         depth = engine.step(syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK,
                             frame_id=r, measurement_ids=list(ms))
         d = depth.cpu().numpy().astype(np.float64)
-        golden = expected_sub4(n)
-        rows.append((n, rel_l1(d, d_ref.numpy().astype(np.float64)),
-                     None if golden is None else rel_l1(d[0, ::4, ::4], golden.astype(np.float64)), flipped))
+        golden, golden_estimate = expected_sub4(n)
+        if rec["depth_estimation"] is not None:
+            pipeline_flipped = flipped_pixels(rec["depth_estimation"].numpy(), golden_estimate)
+        rows.append((n, rel_l1(d, d_ref.numpy().astype(np.float64)), rel_l1(d[0, ::4, ::4], golden.astype(np.float64)), flipped, pipeline_flipped))
     return rows
 
 
@@ -161,16 +164,25 @@ def test_fusionnet_frames_from_the_reference_state(hip_device, golden_dir, mode,
     z3 = np.load(os.path.join(golden_dir, "fusionnet_e2e.npz"))
     zl = np.load(os.path.join(golden_dir, "fusionnet_long.npz"))
     lines = syn.keyframe_index_lines(2)
-    runs = [("3 golden frames", list(syn.E2E_FRAMES), lambda n: z3[f"f{n}_depth_sub4"]),
-            ("long reference run", [None if i is None else lines[i] for i in syn.LONG_SCHEDULE], lambda n: zl[f"s{n}_depth_sub4"])]
+    runs = [("3 golden frames", list(syn.E2E_FRAMES), lambda n: (z3[f"f{n}_depth_sub4"], z3[f"f{n}_depth_estimation_full"])),
+            ("long reference run", [None if i is None else lines[i] for i in syn.LONG_SCHEDULE],
+             lambda n: (zl[f"s{n}_depth_sub4"], zl[f"s{n}_depth_estimation"]))]
     for name, frames, expected in runs:
         mods, engine = build(dev, fusion=True, fold_bn=fast, cache_features=fast, use_graphs=fast)
         rows = run_teacher_forced(engine, reference_pipeline(mods), dev, frames, expected)
-        for n, vs_pipeline, vs_golden, flipped in rows:
-            print("%s, %s step %2d: engine depth rel-L1 vs the reference pipeline %.3e, vs the reference golden %.3e, flipped estimate pixels %d"
-                  % (mode, name, n, vs_pipeline, vs_golden, flipped))
-            assert vs_pipeline <= ENGINE_VS_REFERENCE and vs_golden <= ENGINE_VS_REFERENCE, (name, n, vs_pipeline, vs_golden)
+        on_golden, checked_vs_golden = True, 0
+        for n, vs_pipeline, vs_golden, flipped, pipeline_flipped in rows:
+            if frames[n - 1] is None or n == 0:
+                on_golden = True      # restart: the pipeline is on the golden run's inputs again
+            on_golden = on_golden and pipeline_flipped == 0
+            print("%s, %s step %2d: engine depth rel-L1 vs the reference pipeline %.3e, vs the reference golden %.3e%s, flipped estimate pixels %d"
+                  % (mode, name, n, vs_pipeline, vs_golden, "" if on_golden else " [the CPU pipeline itself has left the golden run]", flipped))
+            assert vs_pipeline <= REL_L1_TARGET, (name, n, vs_pipeline)
             assert flipped == 0, (name, n, flipped)
+            if on_golden:
+                assert vs_golden <= REL_L1_TARGET, (name, n, vs_golden)
+                checked_vs_golden += 1
+        assert checked_vs_golden >= len(rows) - 4, (name, checked_vs_golden)
 
 
 def test_fusionnet_long_reference_run(hip_device, golden_dir, fixture_host_algebra):

@@ -128,17 +128,18 @@ def test_hybrid_pipeline_matches_the_long_reference_run(hip_device, golden_dir, 
         depth = hybrid.step(syn.e2e_image(r), syn.pose(r), [syn.e2e_image(i) for i in ms], [syn.pose(i) for i in ms], fullK,
                             record=lambda **kw: rec.update(kw))
         cv = rec["cost_volume"].reshape(-1)[syn.sample_indices(rec["cost_volume"].numel())].numpy()
+        cv_ref = z[f"s{n}_cost_volume_samples"]
         rows.append({"step": n, "index_line": item, "hybrid_vs_reference": rel_l1(depth[0, ::4, ::4].numpy(), z[f"s{n}_depth_sub4"]),
                      "flipped_estimate_pixels_vs_reference": flipped_pixels(rec["depth_estimation"].numpy(), z[f"s{n}_depth_estimation"]),
-                     "cost_volume_max_abs_diff": float(np.abs(cv - z[f"s{n}_cost_volume_samples"]).max())})
-        print("long run step %2d (index line %3d): hybrid depth rel-L1 vs reference %.3e, %d flipped estimate pixels, cost volume max |diff| %.1e"
-              % (n, item, rows[-1]["hybrid_vs_reference"], rows[-1]["flipped_estimate_pixels_vs_reference"], rows[-1]["cost_volume_max_abs_diff"]))
+                     "cost_volume_rel_diff": float(np.abs(cv - cv_ref).max() / np.abs(cv_ref).max())})
+        print("long run step %2d (index line %3d): hybrid depth rel-L1 vs reference %.3e, %d flipped estimate pixels, cost volume max |diff| %.1e of its max"
+              % (n, item, rows[-1]["hybrid_vs_reference"], rows[-1]["flipped_estimate_pixels_vs_reference"], rows[-1]["cost_volume_rel_diff"]))
     write_report("long_reference_run", rows)
     assert len(rows) == 14
     for row in rows:
         assert row["hybrid_vs_reference"] <= REL_L1_NORTH_STAR, row
         assert row["flipped_estimate_pixels_vs_reference"] == 0, row
-        assert row["cost_volume_max_abs_diff"] <= 2e-5, row
+        assert row["cost_volume_rel_diff"] <= 2e-5, row      # summation order inside the kernel; the sampled positions are the reference's
 
 
 def test_hybrid_pipeline_matches_the_oracle_over_index_lines(hip_device):
