@@ -30,6 +30,10 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (same guide)
+LDS_PEAK_TBPS = 256 * 256 * 2.4e9 / 1e12   # 256 CUs x 256 B/clk (ds_read_b128, MI355X_MICROARCH.md LDS table) x 2.4 GHz = 157 TB/s
+# LDS bytes the sweep's formulation reads per op: 4 taps x C channels x 4 B per (pixel, plane, frame); and the measured floor of
+# its inner pattern (tools/ubench_tap.hip: 8 ds_read_b128 + 20 v_pk_fma_f32 per plane and 8-channel pass, 12 waves / CU)
+SWEEP_LDS_PATTERN_FLOOR_US = 11.9
 ROOFLINE_GEOMETRIES = 25       # keyframe geometries the sweep kernel is timed on, spread over the WHOLE index file
 
 
@@ -232,6 +236,65 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
     return sum(per_geometry) / len(per_geometry), algorithmic_bytes, per_geometry
 
 
+def count_graph_kernels(graph):
+    """Kernel nodes of a captured torch.cuda.CUDAGraph, read from its debug dump (None when the runtime cannot dump)."""
+    import re
+    import tempfile
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "graph.dot")
+            graph.debug_dump(path)
+            text = open(path).read()
+        return len(re.findall(r"label=\"[^\"]*(KERNEL|kernel)", text)) or None
+    except Exception:
+        return None
+
+
+def measure_small_kernels(engine, reps=20):
+    """The other hot-path kernels of a fusionnet frame -- ConvLSTM gates, hidden-state warp, depth re-projection (splat +
+    decimate) -- timed like the sweep: a hipGraph of ``reps`` back-to-back calls, HIP events on the replay stream.  They move a
+    few hundred KB each and sit at the launch-latency floor of a dependent graph node; the fractions say so."""
+    from dvmvs.hip import ops as _ops
+    s = engine._static
+    dev = s["h"].device
+    S, H, W = engine.sequences, engine.height, engine.width
+    cc = torch.randn(S, 2048, H // 32, W // 32, device=dev)
+    c_state, h_state = torch.randn(S, 512, H // 32, W // 32, device=dev), torch.zeros(S, 512, H // 32, W // 32, device=dev)
+    estimate = torch.rand(S, 1, H // 32, W // 32, device=dev) * 3 + 0.5
+    warped = torch.empty_like(h_state)
+    T = torch.eye(4, device=dev).repeat(S, 1, 1)
+    T[:, 0, 3] = 0.05
+    prev_depth = torch.rand(S, 1, H, W, device=dev) * 3 + 0.5
+    zbuffer, low = torch.zeros(S, H // 2, W // 2, device=dev), torch.zeros(S, 1, H // 32, W // 32, device=dev)
+    full_K, half_K, lstm_K = s["full_K"].clone(), s["half_K"].clone(), s["lstm_K"].clone()
+    calls = {
+        "lstm_gates": (lambda: _ops.lstm_gates_into(cc, c_state, h_state), 2048 * 80 * 4 + 512 * 80 * 4 + 2 * 512 * 80 * 4, 1),
+        "hidden_warp": (lambda: _ops.hidden_warp_into(h_state, estimate, T, lstm_K, True, warped), 2 * 512 * 80 * 4 + 80 * 4, 1),
+        "depth_reproject": (lambda: _ops.depth_reproject_lowres_into(T, prev_depth, full_K, half_K, zbuffer, low, 16),
+                            H * W * 4 + (H // 2) * (W // 2) * 4, 2),
+    }
+    out = {}
+    for name, (fn, alg_bytes, launches) in calls.items():
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1e3 / (3 * reps)
+        out[name] = {"us_per_call": round(us, 2), "launches": launches, "algorithmic_bytes": S * alg_bytes,
+                     "achieved_GBps": round(S * alg_bytes / us / 1e3, 1), "frac_of_hbm_peak": S * alg_bytes / us / 1e3 / HBM_PEAK_GBPS}
+    return out
+
+
 def usable_cores():
     """Host cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (os.cpu_count() alone
     reports the whole socket inside a quota-limited container, and oversubscribing it makes oneDNN/OpenMP crawl)."""
@@ -289,8 +352,44 @@ def cpu_baseline(args, modules, n_meas):
         pass
     return {"value": frames / t_total, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{frames} keyframes of the same synthetic fusionnet sequence (320x256, 64 planes, M={n_meas}) on {cpu_model}; "
-                      f"oracle/fusionnet_cpu.py with torch CPU kernels, {cores} threads",
+                      f"oracle/fusionnet_cpu.py with torch CPU kernels, {cores} threads = {cores} of the host's {os.cpu_count()} cores "
+                      f"(the cgroup CPU quota / scheduler affinity of this container)",
             "stage_ms": {k2: round(1e3 * v / frames, 2) for k2, v in pipe.stage_seconds.items()}}
+
+
+def timed_region(step_fn, warmup, steps, world, device, before=None, after=None):
+    """The contract's timing harness, shared by the inference and training modes (and driven on CPU, with the gloo backend and
+    a stub step, by tests/test_bench_harness.py): ``warmup`` untimed steps, then EXACTLY ``steps`` steps bracketed by a barrier +
+    device synchronisation on both sides; returns the MAXIMUM over ranks of the elapsed seconds.  ``step_fn(i)`` gets the running
+    step number; ``before`` / ``after`` run just outside the timed region (profiling markers)."""
+    import torch.distributed as dist
+    sync = (lambda: torch.cuda.synchronize(device)) if torch.device(device).type == "cuda" else (lambda: None)
+    i = 0
+    for _ in range(warmup):
+        step_fn(i)
+        i += 1
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    if before is not None:
+        before()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn(i)
+        i += 1
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if after is not None:
+        after()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    return elapsed
 
 
 def train_mode(args, world, rank, device):
@@ -316,24 +415,15 @@ def train_mode(args, world, rank, device):
     # poses stay on the host (read by the host-side pose algebra only, dvmvs.pose_algebra)
     poses = [torch.stack([all_poses[(40 * b + 3 * i + 7 * rank) % len(all_poses)] for b in range(B)]) for i in range(T)]
     K = torch.cat([syn.full_K(width=W, height=H)] * B).to(device)
-    for _ in range(max(args.warmup, 1)):
-        train_step(model, opt, reducer, images, depths, poses, K)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = train_step(model, opt, reducer, images, depths, poses, K)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    last = {}
+
+    def step(_):
+        last["loss"] = train_step(model, opt, reducer, images, depths, poses, K)
+
+    marker = torch.ones(4096, device=device)
+    mark = (lambda: (marker.cumsum(0), torch.cuda.synchronize())) if args.mark_region else None
+    elapsed = timed_region(step, max(args.warmup, 1), args.steps, world, device, before=mark, after=mark)
+    loss = last["loss"]
     if rank == 0:
         print(json.dumps({
             "metric": "fusionnet training sub-sequences/sec (8 frames, 256x256, 64 planes)", "value": world * B * args.steps / elapsed,
@@ -378,6 +468,7 @@ def main():
     engine = DepthEngine(*modules, device=device, fold_bn=not args.no_fold_bn, cache_features=not args.no_feature_cache,
                          use_graphs=not args.no_graphs, channels_last=args.channels_last,
                          lstm_channels_last=not args.no_lstm_channels_last)
+    engine.graph_debug = True
     M = args.measurement_frames
     n_images = 32
     total = args.warmup + args.steps
@@ -397,34 +488,9 @@ def main():
         if not args.no_feature_cache:
             for k in range(M):
                 engine._half_features(k, images[k % n_images])
-        k = M
-        for _ in range(args.warmup):
-            run_frame(k)
-            k += 1
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
         marker = torch.ones(4096, device=device)
-        if args.mark_region:
-            marker.cumsum(0)
-            torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run_frame(k)
-            k += 1
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if args.mark_region:
-            marker.cumsum(0)
-            torch.cuda.synchronize()
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        mark = (lambda: (marker.cumsum(0), torch.cuda.synchronize())) if args.mark_region else None
+        elapsed = timed_region(lambda i: run_frame(M + i), args.warmup, args.steps, world, device, before=mark, after=mark)
     depth_mean = float(engine._static["depth"].mean())
     assert np.isfinite(depth_mean), "non-finite depth"
 
@@ -452,6 +518,13 @@ def main():
         # useful arithmetic of the op: per (pixel, plane, frame) 4 taps x C channels of FMA + 4 weight FMAs, 2 flop each
         useful_flop = 128 * 160 * 64 * M * (4 * 32 + 4) * 2
         valu_tflops = useful_flop / kernel_s / 1e12
+        lds_bytes = 128 * 160 * 64 * M * 4 * 32 * 4
+        other_kernels = None if args.no_roofline_leg else measure_small_kernels(engine)
+        launches_per_frame = None
+        try:     # kernel nodes of the captured frame graph (what one replay launches)
+            launches_per_frame = {f"n_meas={k[0]},has_previous={k[1]}": count_graph_kernels(g) for k, g in engine._graphs.items()}
+        except Exception:
+            pass
         rel = golden_rel_l1(modules, device, args) if not args.no_rel_l1 else None
         result = {
             "metric": "depth frames/sec/GPU @ 320x256x64 planes (fusionnet); rel-L1 vs ref",
@@ -473,6 +546,14 @@ def main():
             # reads): the same duration against the fp32 vector peak, counting only the useful tap FMAs
             "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": valu_tflops / FP32_VALU_PEAK_TFLOPS, "useful_flop": useful_flop},
+            # the pipe this formulation is actually bound by: 4 taps x 32 channels x 4 B from LDS per (pixel, plane, frame).  "peak" is
+            # the ds_read_b128 rate of the chip; "pattern_floor_us" the measured floor of the kernel's own inner pattern (bank conflicts
+            # of the tap addresses and the packed FMAs between the reads included)
+            "roofline_lds": {"bound": "lds", "achieved": lds_bytes / kernel_s / 1e12, "peak": LDS_PEAK_TBPS, "unit": "TB/s",
+                             "frac": lds_bytes / kernel_s / 1e12 / LDS_PEAK_TBPS, "lds_bytes": lds_bytes,
+                             "pattern_floor_us": SWEEP_LDS_PATTERN_FLOOR_US, "frac_of_pattern_floor": SWEEP_LDS_PATTERN_FLOOR_US / (kernel_s * 1e6)},
+            "roofline_other": other_kernels,
+            "launches_per_frame": launches_per_frame,
             "rel_l1": None if rel is None else {
                 "what": "depth rel-L1 mean(|d - d_ref| / d_ref) of this engine configuration vs the REFERENCE forward on the 3 golden frames "
                         "(tests/golden/fusionnet_e2e.npz); target 1e-4; the kernels alone (CPU convolutions held fixed) are pinned by "

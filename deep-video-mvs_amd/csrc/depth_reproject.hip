@@ -62,7 +62,38 @@ __global__ void nearest_decimate_kernel(const float* __restrict__ in, float* __r
   out[i] = in[(static_cast<size_t>(b) * H + yo * f) * W + xo * f];
 }
 
+// The frame path needs only the decimated estimate: one kernel picks rows / columns 0, f, 2f, ... of the z-buffer AND clears it,
+// so that the buffer is all-zero again when the next frame splats into it -- no zero-fill launch per frame.
+__global__ void decimate_clear_kernel(float* __restrict__ zbuffer, float* __restrict__ out, int B, int H, int W, int f) {
+  const int Ho = H / f, Wo = W / f;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * H * W) return;
+  const int x = i % W, y = (i / W) % H, b = i / (W * H);
+  const float v = zbuffer[i];
+  if (y % f == 0 && x % f == 0 && y / f < Ho && x / f < Wo) out[(static_cast<size_t>(b) * Ho + y / f) * Wo + x / f] = v;
+  zbuffer[i] = 0.0f;
+}
+
 }  // namespace dvmvs
+
+extern "C" int dvmvs_depth_reproject_lowres_fwd(const float* transformation, const float* previous_depth, const float* full_K,
+                                                const float* half_K, float* zbuffer, float* out_lowres, int lowres_factor,
+                                                int B, int full_height, int full_width, dvmvs_stream_t stream) {
+  using namespace dvmvs;
+  if (!transformation || !previous_depth || !full_K || !half_K || !zbuffer || !out_lowres) return DVMVS_EINVAL;
+  if (B <= 0 || full_height < 2 || full_width < 2 || B > 65535 || lowres_factor <= 0) return DVMVS_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int hh = full_height / 2, hw = full_width / 2;
+  if (hh / lowres_factor <= 0 || hw / lowres_factor <= 0) return DVMVS_EINVAL;
+  const int HWf = full_height * full_width;
+  hipLaunchKernelGGL(depth_splat_kernel, dim3((HWf + 255) / 256, B), dim3(256), 0, s, transformation, previous_depth, full_K, half_K,
+                     reinterpret_cast<unsigned int*>(zbuffer), B, full_height, full_width);
+  int rc = launch_status();
+  if (rc != 0) return rc;
+  const int n = B * hh * hw;
+  hipLaunchKernelGGL(decimate_clear_kernel, dim3((n + 255) / 256), dim3(256), 0, s, zbuffer, out_lowres, B, hh, hw, lowres_factor);
+  return launch_status();
+}
 
 extern "C" int dvmvs_depth_reproject_fwd(const float* transformation, const float* previous_depth, const float* full_K,
                                          const float* half_K, float* out, float* out_lowres, int lowres_factor,

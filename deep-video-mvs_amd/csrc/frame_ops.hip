@@ -10,50 +10,63 @@
 
 namespace dvmvs {
 
+// ACT 0 none, 1 ReLU, 2 sigmoid, 3 sigmoid followed by the decoder's depth mapping 1 / (p0 * s + p1)
+// (/root/reference/dvmvs/fusionnet/model.py:231-232,297-303: inverse_depth_multiplier, inverse_depth_base).
 template <int ACT>
-__device__ inline float apply_act(float v) {
+__device__ inline float apply_act(float v, float p0 = 0.0f, float p1 = 0.0f) {
   if (ACT == 1) return fmaxf(v, 0.0f);
   if (ACT == 2) return 1.0f / (1.0f + expf(-v));
+  if (ACT == 3) {
+#pragma clang fp contract(off)
+    const float s = 1.0f / (1.0f + expf(-v));
+    return 1.0f / (p0 * s + p1);     // multiply, add, reciprocal: the op order of the ATen expression it replaces
+  }
   return v;
 }
 
-// One workgroup row per (b, c) plane chunk; float4 when the plane size allows it.
+// One workgroup row per (b, c) plane chunk; float4 when the plane size allows it.  Reads the convolution output `x` (dense
+// [B,C,H,W]) and writes `dst`, which may be x itself (in place) or a channel slice of a larger buffer -- batch item b of the
+// destination starts at dst + b * dst_batch_stride, its C planes are dense -- so that a torch.cat of convolution outputs never
+// has to be materialised by a copy kernel.
 // RES: 0 none; 1 residual of the same shape is added after the activation; 2 the residual has half the resolution and is
 // nearest-up-sampled on the fly (the FPN top-down path: lateral + interpolate(top, "nearest")).
 template <int ACT, bool VEC4, int RES>
-__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ x, const float* __restrict__ bias,
-                                                       const float* __restrict__ residual, int C, int HW, int W) {
+__global__ __launch_bounds__(256) void bias_act_kernel(const float* x, float* dst, long long dst_batch_stride, const float* __restrict__ bias,
+                                                       const float* __restrict__ residual, int C, int HW, int W, float p0, float p1) {
   const int plane = blockIdx.y;  // b * C + c
-  const float bv = bias ? bias[plane % C] : 0.0f;
-  float* p = x + static_cast<size_t>(plane) * HW;
+  const int b = plane / C, c = plane - b * C;
+  const float bv = bias ? bias[c] : 0.0f;
+  const float* p = x + static_cast<size_t>(plane) * HW;
+  float* d = dst + static_cast<size_t>(b) * dst_batch_stride + static_cast<size_t>(c) * HW;
   if (VEC4 && RES != 2) {
     typedef float float4v __attribute__((ext_vector_type(4)));
-    float4v* p4 = reinterpret_cast<float4v*>(p);
+    const float4v* p4 = reinterpret_cast<const float4v*>(p);
+    float4v* d4 = reinterpret_cast<float4v*>(d);
     const float4v* r4 = reinterpret_cast<const float4v*>(residual + (RES == 1 ? static_cast<size_t>(plane) * HW : 0));
     const int n4 = HW / 4;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
       float4v v = p4[i];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(v[e] + bv);
+      for (int e = 0; e < 4; ++e) v[e] = apply_act<ACT>(v[e] + bv, p0, p1);
       if (RES == 1) {
         const float4v r = r4[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += r[e];
       }
-      p4[i] = v;
+      d4[i] = v;
     }
   } else {
     const int Wh = W / 2;
     const float* r = RES == 1 ? residual + static_cast<size_t>(plane) * HW
                               : (RES == 2 ? residual + static_cast<size_t>(plane) * (HW / 4) : nullptr);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
-      float v = apply_act<ACT>(p[i] + bv);
+      float v = apply_act<ACT>(p[i] + bv, p0, p1);
       if (RES == 1) v += r[i];
       if (RES == 2) {
         const int y = i / W, xx = i - y * W;
         v += r[(y >> 1) * Wh + (xx >> 1)];
       }
-      p[i] = v;
+      d[i] = v;
     }
   }
 }
@@ -61,7 +74,9 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ x, co
 // 2x bilinear up-sampling, align_corners=True, in ATen's op order:
 //   src = dst * (in - 1) / (out - 1);  i0 = int(src);  l1 = src - i0;  l0 = 1 - l1
 //   out = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11)
-__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int H, int W) {
+// Batch item b of the destination starts at out + b * out_batch_stride (a channel slice of a concatenation buffer), its C planes are dense.
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, long long out_batch_stride,
+                                                         int planes, int C, int H, int W) {
   // No FMA contraction: the fractional weight must come from the ROUNDED product sh * oy, the same value whose integer part
   // selects the tap (ATen does exactly that); fma(sh, oy, -y0) would mix a rounded index with an unrounded fraction.
 #pragma clang fp contract(off)
@@ -80,7 +95,9 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
     const float h1 = fy - static_cast<float>(y0), h0 = 1.0f - h1;
     const float w1 = fx - static_cast<float>(x0), w0 = 1.0f - w1;
     const float* p = in + pl * H * W;
-    out[i] = h0 * (w0 * p[y0 * W + x0] + w1 * p[y0 * W + x1]) + h1 * (w0 * p[y1 * W + x0] + w1 * p[y1 * W + x1]);
+    const long long b = pl / C, c = pl - b * C;
+    out[b * out_batch_stride + (c * OH + oy) * OW + ox] =
+        h0 * (w0 * p[y0 * W + x0] + w1 * p[y0 * W + x1]) + h1 * (w0 * p[y1 * W + x0] + w1 * p[y1 * W + x1]);
   }
 }
 
@@ -88,15 +105,19 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
 // fused.  MIOpen runs these MnasNet layers through its naive reference kernel (naive_conv_ab_nonpacked_fwd_nchw) plus a
 // separate bias/activation launch; a direct kernel is one launch and reads each input element from L1 k*k times.
 // One thread per output element; the k*k weights of the channel are wave-uniform (scalar loads).
-template <int K, int ACT>
+// PRE: the input is the raw output of the preceding 1x1 expansion convolution and its epilogue -- bias add + ReLU -- is applied
+// on the fly to every in-bounds tap (the zero padding stays zero, as it would be on the activated map): one launch per inverted
+// residual block less than convolution -> epilogue -> depthwise.
+template <int K, int ACT, bool PRE>
 __global__ __launch_bounds__(256) void depthwise_conv_kernel(const float* __restrict__ in, const float* __restrict__ weight,
-                                                             const float* __restrict__ bias, float* __restrict__ out, int C, int H, int W,
-                                                             int OH, int OW, int stride) {
+                                                             const float* __restrict__ bias, const float* __restrict__ pre_bias,
+                                                             float* __restrict__ out, int C, int H, int W, int OH, int OW, int stride) {
   const int c = blockIdx.y, b = blockIdx.z;
   const float* wk = weight + static_cast<size_t>(c) * K * K;
   const float* src = in + (static_cast<size_t>(b) * C + c) * H * W;
   float* dst = out + (static_cast<size_t>(b) * C + c) * OH * OW;
   const float bv = bias ? bias[c] : 0.0f;
+  const float pv = (PRE && pre_bias) ? pre_bias[c] : 0.0f;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < OH * OW; i += gridDim.x * blockDim.x) {
     const int oy = i / OW, ox = i - oy * OW;
     const int y0 = oy * stride - K / 2, x0 = ox * stride - K / 2;
@@ -108,7 +129,8 @@ __global__ __launch_bounds__(256) void depthwise_conv_kernel(const float* __rest
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
         const int x = x0 + kx;
-        const float v = (yin && x >= 0 && x < W) ? src[y * W + x] : 0.0f;
+        float v = 0.0f;
+        if (yin && x >= 0 && x < W) v = PRE ? fmaxf(src[y * W + x] + pv, 0.0f) : src[y * W + x];
         acc = fmaf(v, wk[ky * K + kx], acc);
       }
     }
@@ -117,21 +139,24 @@ __global__ __launch_bounds__(256) void depthwise_conv_kernel(const float* __rest
 }
 
 template <int K, int ACT>
-int launch_depthwise(const float* in, const float* w, const float* b, float* out, int B, int C, int H, int W, int OH, int OW, int stride,
-                     hipStream_t s) {
+int launch_depthwise(const float* in, const float* w, const float* b, const float* pre_bias, bool pre, float* out, int B, int C, int H, int W,
+                     int OH, int OW, int stride, hipStream_t s) {
   dim3 grid(max(1, min((OH * OW + 255) / 256, 64)), C, B), block(256);
-  hipLaunchKernelGGL((depthwise_conv_kernel<K, ACT>), grid, block, 0, s, in, w, b, out, C, H, W, OH, OW, stride);
+  if (pre) hipLaunchKernelGGL((depthwise_conv_kernel<K, ACT, true>), grid, block, 0, s, in, w, b, pre_bias, out, C, H, W, OH, OW, stride);
+  else hipLaunchKernelGGL((depthwise_conv_kernel<K, ACT, false>), grid, block, 0, s, in, w, b, pre_bias, out, C, H, W, OH, OW, stride);
   return launch_status();
 }
 
 template <int ACT>
-int launch_bias_act(float* x, const float* bias, const float* residual, int residual_mode, int B, int C, int H, int W, hipStream_t s) {
+int launch_bias_act(const float* x, float* dst, long long dst_batch_stride, const float* bias, const float* residual, int residual_mode,
+                    int B, int C, int H, int W, float p0, float p1, hipStream_t s) {
   const int HW = H * W;
-  const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(residual) % 16 == 0);
+  const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(residual) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(dst) % 16 == 0) && (dst_batch_stride % 4 == 0);
   const bool vec4 = (HW % 4 == 0) && aligned && residual_mode != 2;
   const int work = vec4 ? HW / 4 : HW;
   dim3 grid(max(1, min((work + 255) / 256, 64)), B * C), block(256);
-#define DVMVS_BA(V, R) hipLaunchKernelGGL((bias_act_kernel<ACT, V, R>), grid, block, 0, s, x, bias, residual, C, HW, W)
+#define DVMVS_BA(V, R) hipLaunchKernelGGL((bias_act_kernel<ACT, V, R>), grid, block, 0, s, x, dst, dst_batch_stride, bias, residual, C, HW, W, p0, p1)
   if (residual_mode == 0) { if (vec4) DVMVS_BA(true, 0); else DVMVS_BA(false, 0); }
   else if (residual_mode == 1) { if (vec4) DVMVS_BA(true, 1); else DVMVS_BA(false, 1); }
   else DVMVS_BA(false, 2);
@@ -141,35 +166,48 @@ int launch_bias_act(float* x, const float* bias, const float* residual, int resi
 
 }  // namespace dvmvs
 
-extern "C" int dvmvs_bias_act_inplace(float* x, const float* bias, const float* residual, int residual_mode, int B, int C, int H,
-                                      int W, int activation, dvmvs_stream_t stream) {
+extern "C" int dvmvs_bias_act_fwd(const float* x, float* dst, long long dst_batch_stride, const float* bias, const float* residual,
+                                  int residual_mode, int B, int C, int H, int W, int activation, float p0, float p1,
+                                  dvmvs_stream_t stream) {
   using namespace dvmvs;
-  if (!x || B <= 0 || C <= 0 || H <= 0 || W <= 0) return DVMVS_EINVAL;
+  if (!x || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0) return DVMVS_EINVAL;
   if (residual_mode < 0 || residual_mode > 2 || (residual_mode != 0 && !residual)) return DVMVS_EINVAL;
+  if (dst_batch_stride < static_cast<long long>(C) * H * W) return DVMVS_EINVAL;
   if (residual_mode == 2 && ((H & 1) || (W & 1))) return DVMVS_EUNSUPPORTED;
   if (static_cast<long long>(B) * C > 65535LL) return DVMVS_EUNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (activation) {
-    case 0: return launch_bias_act<0>(x, bias, residual, residual_mode, B, C, H, W, s);
-    case 1: return launch_bias_act<1>(x, bias, residual, residual_mode, B, C, H, W, s);
-    case 2: return launch_bias_act<2>(x, bias, residual, residual_mode, B, C, H, W, s);
+    case 0: return launch_bias_act<0>(x, dst, dst_batch_stride, bias, residual, residual_mode, B, C, H, W, p0, p1, s);
+    case 1: return launch_bias_act<1>(x, dst, dst_batch_stride, bias, residual, residual_mode, B, C, H, W, p0, p1, s);
+    case 2: return launch_bias_act<2>(x, dst, dst_batch_stride, bias, residual, residual_mode, B, C, H, W, p0, p1, s);
+    case 3: return launch_bias_act<3>(x, dst, dst_batch_stride, bias, residual, residual_mode, B, C, H, W, p0, p1, s);
     default: return DVMVS_EINVAL;
   }
 }
 
-extern "C" int dvmvs_upsample2x_fwd(const float* in, float* out, int B, int C, int H, int W, dvmvs_stream_t stream) {
+extern "C" int dvmvs_bias_act_inplace(float* x, const float* bias, const float* residual, int residual_mode, int B, int C, int H,
+                                      int W, int activation, dvmvs_stream_t stream) {
+  if (activation == 3) return DVMVS_EINVAL;   // the depth mapping has parameters: dvmvs_bias_act_fwd
+  return dvmvs_bias_act_fwd(x, x, static_cast<long long>(C) * H * W, bias, residual, residual_mode, B, C, H, W, activation, 0.0f, 0.0f, stream);
+}
+
+extern "C" int dvmvs_upsample2x_fwd(const float* in, float* out, long long out_batch_stride, int B, int C, int H, int W,
+                                    dvmvs_stream_t stream) {
   using namespace dvmvs;
   if (!in || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return DVMVS_EINVAL;
+  if (out_batch_stride == 0) out_batch_stride = static_cast<long long>(C) * H * W * 4;
+  if (out_batch_stride < static_cast<long long>(C) * H * W * 4) return DVMVS_EINVAL;
   const long long total = static_cast<long long>(B) * C * H * W * 4;
   long long blocks = (total + 255) / 256;
   if (blocks > 256LL * 16) blocks = 256LL * 16;
   hipLaunchKernelGGL(upsample2x_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
-                     B * C, H, W);
+                     out_batch_stride, B * C, C, H, W);
   return launch_status();
 }
 
-extern "C" int dvmvs_depthwise_conv_fwd(const float* in, const float* weight, const float* bias, float* out, int B, int C, int H, int W,
-                                        int kernel_size, int stride, int activation, dvmvs_stream_t stream) {
+extern "C" int dvmvs_depthwise_conv_fwd(const float* in, const float* weight, const float* bias, const float* pre_bias, int pre_relu,
+                                        float* out, int B, int C, int H, int W, int kernel_size, int stride, int activation,
+                                        dvmvs_stream_t stream) {
   using namespace dvmvs;
   if (!in || !weight || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return DVMVS_EINVAL;
   if ((kernel_size != 3 && kernel_size != 5) || (stride != 1 && stride != 2) || activation < 0 || activation > 2) return DVMVS_EUNSUPPORTED;
@@ -177,7 +215,7 @@ extern "C" int dvmvs_depthwise_conv_fwd(const float* in, const float* weight, co
   const int pad = kernel_size / 2;
   const int OH = (H + 2 * pad - kernel_size) / stride + 1, OW = (W + 2 * pad - kernel_size) / stride + 1;
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define DVMVS_DW(K, A) return launch_depthwise<K, A>(in, weight, bias, out, B, C, H, W, OH, OW, stride, s)
+#define DVMVS_DW(K, A) return launch_depthwise<K, A>(in, weight, bias, pre_bias, pre_relu != 0, out, B, C, H, W, OH, OW, stride, s)
   if (kernel_size == 3) {
     if (activation == 0) DVMVS_DW(3, 0);
     if (activation == 1) DVMVS_DW(3, 1);

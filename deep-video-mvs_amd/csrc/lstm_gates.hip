@@ -43,8 +43,10 @@ __device__ inline void row_stats(const float (&v)[EPL], const bool (&ok)[EPL], f
 }
 
 template <int LPR, int EPL>
-__global__ __launch_bounds__(256) void lstm_gates_fwd_kernel(const float* __restrict__ cc, const float* __restrict__ c_cur,
-                                                             float* __restrict__ h_next, float* __restrict__ c_next,
+// c_next may alias c_cur (the frame engine updates its state buffers in place): a row is read completely into registers before
+// anything of it is written, and rows are owned by disjoint lane groups -- hence no __restrict__ on the two state pointers.
+__global__ __launch_bounds__(256) void lstm_gates_fwd_kernel(const float* __restrict__ cc, const float* c_cur,
+                                                             float* __restrict__ h_next, float* c_next,
                                                              int B, int hidden, int HW) {
   constexpr int kRowsPerBlock = 256 / LPR;
   const int row = blockIdx.x * kRowsPerBlock + threadIdx.x / LPR;  // (b, channel)

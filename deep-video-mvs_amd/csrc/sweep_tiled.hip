@@ -386,8 +386,12 @@ __device__ unsigned long long g_sweep_trace[kTraceGroups * kTraceWords];
 // current one and held in registers until the LDS tile is free again -- the global-load round trip of a pass (0.65 us of the
 // workgroup's dependency chain per pass in round 2's timeline, eight passes per workgroup) then overlaps the LDS-bound tap phase.
 // Pieces beyond PRE (boxes larger than PRE * NT records) are loaded after the taps as before.
+// PSPLIT: thread groups per tile.  With PSPLIT = 2 a workgroup is 512 threads: both halves own the tile's 256 pixels, the first
+// the lower half of the chunk's planes, the second the upper half, and they share ONE staged box.  The tap phase -- the longest
+// part of a workgroup's dependency chain (eight passes of ~2 us each at 256 threads) -- is then spread over twice as many waves,
+// and a thread carries half the per-plane state (<= 128 registers: 4 waves / SIMD, two 8-wave workgroups per CU).
 template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, int ORDER_ = 2, int PRE_ = 2, bool PLAN0_ = true,
-          bool FASTFULL_ = true>
+          bool FASTFULL_ = true, int PSPLIT_ = 1>
 struct SweepConfig {
   static constexpr int TW = TW_, TH = TH_, DP = DP_, CCH = CCH_, CAP = CAP_, MINSEG = MINSEG_;
   static constexpr int WAVES = WAVES_;   // waves per SIMD the register allocation is held to
@@ -395,11 +399,14 @@ struct SweepConfig {
   static constexpr int PRE = PRE_;       // prefetched staging pieces per thread (NCHW; x2 for channels-last quads), 0 = none
   static constexpr bool PLAN0 = PLAN0_;  // the run plan is made by wave 0 only (the other waves wait at the barrier)
   static constexpr bool FASTFULL = FASTFULL_;   // straight-line tap block for runs that cover the whole chunk
-  static constexpr int NT = TW * TH;
+  static constexpr int PSPLIT = PSPLIT_;
+  static constexpr int NPIX = TW * TH;                                 // pixels of a tile = threads of one plane group
+  static constexpr int NT = NPIX * PSPLIT;
+  static constexpr int DPT = DP / PSPLIT;                              // planes per thread
   static constexpr int REC = CCH + 4;                                  // floats per LDS record
   static constexpr size_t kLdsBytes = sizeof(float) * static_cast<size_t>(REC) * CAP;
   static_assert(CCH % 4 == 0 && ((REC / 4) % 2) == 1, "record stride must be an odd number of 16-byte slots");
-  static_assert(NT % 64 == 0 && MINSEG >= 1 && MINSEG <= DP && DP <= 32, "workgroup shape");
+  static_assert(NPIX % 64 == 0 && MINSEG >= 1 && MINSEG <= DP && DP <= 32 && DP % PSPLIT == 0 && NT <= 1024, "workgroup shape");
 };
 
 // Decodes the linear workgroup number into a (batch, tile, chunk) work item; `group` is the item's number in (batch, tile, chunk)
@@ -449,6 +456,7 @@ __device__ inline SweepWork decode_work(int block, int tiles, int chunks, int B)
 template <class Cfg, bool NHWC, bool GATHER>
 __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_kernel(CostVolumeArgs a) {
   constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP, CCH = Cfg::CCH, CAP = Cfg::CAP, NT = Cfg::NT, REC = Cfg::REC;
+  constexpr int NPIX = Cfg::NPIX, DPT = Cfg::DPT;
   constexpr int QPR = CCH / 4;   // 16-byte quads per record
   constexpr int kMaxRuns = max_runs<DP, Cfg::MINSEG>();
   extern __shared__ __attribute__((aligned(16))) float s_tile[];   // [CAP][REC]
@@ -505,8 +513,10 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   const int HW = a.H * a.W;
   // lane -> pixel: each 16-lane ds_read_b128 service group owns 16 consecutive pixels of one tile row (see sweep_lane_pixel)
   const int lane_pixel = sweep_lane_pixel(tid & 31);
-  const int x = tile_x * TW + (TW == 32 ? lane_pixel : TW == 16 ? (lane_pixel & 15) : tid % TW);
-  const int y = tile_y * TH + (TW == 32 ? tid / 32 : TW == 16 ? (tid >> 5) * 2 + (lane_pixel >> 4) : tid / TW);
+  const int ptid = Cfg::PSPLIT == 1 ? tid : tid % NPIX;         // this thread's pixel within the tile
+  const int j0 = Cfg::PSPLIT == 1 ? 0 : (tid / NPIX) * DPT;     // its first plane within the chunk (wave-uniform)
+  const int x = tile_x * TW + (TW == 32 ? lane_pixel : TW == 16 ? (lane_pixel & 15) : ptid % TW);
+  const int y = tile_y * TH + (TW == 32 ? ptid / 32 : TW == 16 ? (ptid >> 5) * 2 + (lane_pixel >> 4) : ptid / TW);
   const bool live = x < a.W && y < a.H;
   const float xf = static_cast<float>(x), yf = static_cast<float>(y);
   const int pix = live ? y * a.W + x : 0;
@@ -528,9 +538,9 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   // sum_m sum_c ref[c] * warped_m[c]: one accumulator over all measurement frames (sum over frames, then / C, then / M; for the
   // usual power-of-two C this is bit-identical to the reference's per-frame / C followed by the sum, otherwise it is one
   // rounding closer to exact).  Even- and odd-channel partial sums ride in the two halves of packed FMAs.
-  float2v acc2[DP];
+  float2v acc2[DPT];
 #pragma unroll
-  for (int j = 0; j < DP; ++j) acc2[j] = float2v{0.0f, 0.0f};
+  for (int j = 0; j < DPT; ++j) acc2[j] = float2v{0.0f, 0.0f};
 
   // ---- runs that cannot be staged: queue them for the second pass, or gather them here when there is none ----
   int first_staged = n_runs;
@@ -548,9 +558,9 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
       const float* kt = s_kt + m * 3;
       gcfloat_p meas = as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW;
 #pragma unroll
-      for (int j = 0; j < DP; ++j)
-        if (j >= seg_lo && j < seg_lo + seg_len) {
-          const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j);
+      for (int j = 0; j < DPT; ++j)
+        if (j0 + j >= seg_lo && j0 + j < seg_lo + seg_len) {
+          const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j0 + j);
           acc2[j].x += live ? gather_plane<NHWC>(a, meas, ref, HW, ray, kt[0] / depth, kt[1] / depth, kt[2] / depth, sc) : 0.0f;
         }
     }
@@ -564,8 +574,8 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   if (first_staged < n_runs) {
     // state of the run being tapped
     int m = 0, seg_lo = 0, seg_hi = 0, row_bytes = 0, n_pieces = 0;
-    int addr[DP];
-    float2v frac[DP];
+    int addr[DPT];
+    float2v frac[DPT];
     // state of the run being staged (the same run, or the next one while the last pass of the current run is tapped)
     __amdgpu_buffer_rsrc_t meas_rsrc;
     unsigned int goff[kPieces];
@@ -609,13 +619,13 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
       const int P = st_box.pitch;
       row_bytes = P * REC * 4;
       const SweepRay ray = sweep_ray(s_H + m * 9, xf, yf);
-      const float4v* ktd_m = s_ktd + m * DP;
+      const float4v* ktd_m = s_ktd + m * DP + j0;
 #pragma unroll
-      for (int j = 0; j < DP; ++j) {   // all planes in one basic block (those outside the run get addresses that are never used)
+      for (int j = 0; j < DPT; ++j) {  // all of this thread's planes in one basic block (those outside the run get addresses that are never used)
         const float4v kd = ktd_m[j];   // zeros beyond the last plane of a ragged chunk
         float ix, iy;
         sweep_sample(ray, kd.x, kd.y, kd.z, sc, &ix, &iy);
-        const bool in_run = j >= seg_lo && j < seg_hi;   // workgroup-uniform
+        const bool in_run = j0 + j >= seg_lo && j0 + j < seg_hi;   // wave-uniform
         const float fx = floorf(ix), fy = floorf(iy);
         int rx = static_cast<int>(fx) - st_box.x_lo, ry = static_cast<int>(fy) - st_box.y_lo;
         if (live && in_run) violated |= (static_cast<unsigned int>(rx) > static_cast<unsigned int>(st_box.RW - 2)) |
@@ -715,11 +725,11 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
       // ---- taps of (run e, pass c0) ----
       if (Cfg::FASTFULL && seg_lo == 0 && seg_hi == DP) {   // the common case as one straight-line block
 #pragma unroll
-        for (int j = 0; j < DP; ++j) tap_plane<QPR, REC>(tile_bytes, row_bytes, addr[j], frac[j], rv, &acc2[j]);
+        for (int j = 0; j < DPT; ++j) tap_plane<QPR, REC>(tile_bytes, row_bytes, addr[j], frac[j], rv, &acc2[j]);
       } else {
 #pragma unroll
-        for (int j = 0; j < DP; ++j)
-          if (j >= seg_lo && j < seg_hi)   // workgroup-uniform
+        for (int j = 0; j < DPT; ++j)
+          if (j0 + j >= seg_lo && j0 + j < seg_hi)   // wave-uniform
             tap_plane<QPR, REC>(tile_bytes, row_bytes, addr[j], frac[j], rv, &acc2[j]);
       }
       __syncthreads();
@@ -739,7 +749,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   const int any_violated = __syncthreads_or(violated);
   if (any_violated) {
 #pragma unroll
-    for (int j = 0; j < DP; ++j) acc2[j] = float2v{0.0f, 0.0f};
+    for (int j = 0; j < DPT; ++j) acc2[j] = float2v{0.0f, 0.0f};
     n_spilled = 0;
     for (int m = 0; m < a.M; ++m) {
       if (!GATHER) {
@@ -750,9 +760,9 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
         const float* kt = s_kt + m * 3;
         gcfloat_p meas = as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW;
 #pragma unroll
-        for (int j = 0; j < DP; ++j)
-          if (j < planes && live) {
-            const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j);
+        for (int j = 0; j < DPT; ++j)
+          if (j0 + j < planes && live) {
+            const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j0 + j);
             acc2[j].x += gather_plane<NHWC>(a, meas, ref, HW, ray, kt[0] / depth, kt[1] / depth, kt[2] / depth, sc);
           }
       }
@@ -760,19 +770,19 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   }
 
   if (live) {
-    gfloat_p out = as_global(a.out) + (static_cast<size_t>(b) * a.D + d_block) * HW + pix;
+    gfloat_p out = as_global(a.out) + (static_cast<size_t>(b) * a.D + d_block + j0) * HW + pix;
     const float Cf = static_cast<float>(a.C), Mf = static_cast<float>(a.M);
     if (((a.C & (a.C - 1)) | (a.M & (a.M - 1))) == 0) {
       // both counts are powers of two (the usual 32 channels, 1 or 2 frames): x * 2^-k is x / 2^k, correctly rounded either
       // way, without the 2 x 10 instructions of an IEEE division per output
       const float rC = 1.0f / Cf, rM = 1.0f / Mf;
 #pragma unroll
-      for (int j = 0; j < DP; ++j)
-        if (j < planes) out[static_cast<size_t>(j) * HW] = ((acc2[j].x + acc2[j].y) * rC) * rM;
+      for (int j = 0; j < DPT; ++j)
+        if (j0 + j < planes) out[static_cast<size_t>(j) * HW] = ((acc2[j].x + acc2[j].y) * rC) * rM;
     } else {
 #pragma unroll
-      for (int j = 0; j < DP; ++j)
-        if (j < planes) out[static_cast<size_t>(j) * HW] = ((acc2[j].x + acc2[j].y) / Cf) / Mf;
+      for (int j = 0; j < DPT; ++j)
+        if (j0 + j < planes) out[static_cast<size_t>(j) * HW] = ((acc2[j].x + acc2[j].y) / Cf) / Mf;
     }
   }
 #ifdef DVMVS_SWEEP_TRACE
@@ -800,7 +810,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
 // writer that applies its contributions in a fixed order, so the volume does not depend on scheduling, while the critical
 // path of a unit is at most M single-plane gathers.
 template <class Cfg, bool NHWC>
-__global__ __launch_bounds__(Cfg::NT) void sweep_spill_kernel(CostVolumeArgs a) {
+__global__ __launch_bounds__(Cfg::NPIX) void sweep_spill_kernel(CostVolumeArgs a) {
   constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP;
   const guint_p spill = as_global(a.spill);
   const unsigned int units = spill[0] * DP;
@@ -899,7 +909,7 @@ int launch_sweep_tiled_layout(const CostVolumeArgs& a, hipStream_t stream, int s
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(Cfg::NT), Cfg::kLdsBytes, stream, a);
   const int rc2 = launch_status();
   if (rc2 != 0) return rc2;
-  hipLaunchKernelGGL((sweep_spill_kernel<Cfg, NHWC>), dim3(spill_grid), dim3(Cfg::NT), 0, stream, a);
+  hipLaunchKernelGGL((sweep_spill_kernel<Cfg, NHWC>), dim3(spill_grid), dim3(Cfg::NPIX), 0, stream, a);
   return launch_status();
 }
 
@@ -937,6 +947,11 @@ int launch_sweep_tuning(int which_and_grid, const CostVolumeArgs& a, hipStream_t
     case 6: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, 2, 4, true, true>>(a, stream, g);    // 2 waves / SIMD of registers, whole pass prefetched
     case 7: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1280, 2, 2, 2, 3, true, true>>(a, stream, g);    // 60 KB: 2 / CU
     case 8: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 0, 2, true, true>>(a, stream, g);    // linear numbering (no XCD awareness)
+    case 9: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 4, 2, 2, true, true, 2>>(a, stream, g);   // 512 threads: planes split over two thread groups, 2 / CU
+    case 10: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1536, 2, 4, 2, 2, true, true, 2>>(a, stream, g);  // ... with 72 KB boxes
+    case 11: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1536, 2, 4, 2, 3, true, true, 2>>(a, stream, g);  // ... whole pass prefetched
+    case 12: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 6, 2, 1, true, true, 2>>(a, stream, g);  // ... 3 / CU (<= 80 registers)
+    case 13: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1280, 2, 4, 2, 2, true, true, 2>>(a, stream, g);  // ... 60 KB boxes
     default: return DVMVS_EINVAL;
   }
 }

@@ -14,6 +14,11 @@ MI355X-specific execution choices (none of them changes results beyond fp32 roun
 * **BatchNorm folding** -- conv + eval-mode BN are folded into one biased convolution before inference;
 * **epilogue fusion** -- bias add + ReLU / sigmoid after every MIOpen convolution run as one in-place HIP kernel, and
   the 2x bilinear up-sampling of the decoder is a HIP kernel (ATen's takes ~80 us on the 512 x 8 x 10 bottleneck map);
+* **no concatenation or state copies** (one sequence per engine, the headline configuration) -- every producer writes straight
+  into the buffer its consumer reads: FPN outputs, the cost volume and encoder outputs into channel slices of the encoder's
+  concatenation buffers, skip connections and up-sampled maps into the decoder's, the warped hidden state into the ConvLSTM's
+  input, the gates into the state buffers in place, the last convolution's epilogue (sigmoid -> depth) into the depth buffer that
+  is also next frame's "previous depth"; the FPN's unused 1/32 output is not computed.  ~45 launches per frame less;
 * **hipGraph replay** -- after a warm-up frame (MIOpen solver search) the whole frame is captured once per
   (number of measurement frames, has-previous-state) and replayed; the HIP ops are capture-safe (no host sync,
   no allocation inside the C ABI), images and the frame's small matrices live in static device buffers;
@@ -73,8 +78,12 @@ def fold_batchnorm(module):
 # epilogue fusion: conv (MIOpen, no bias) + one in-place HIP kernel for bias and activation
 # ----------------------------------------------------------------------------------------------------------------------
 class FusedConv2d(nn.Module):
-    """Convolution whose bias add and activation run as ONE in-place HIP kernel (dvmvs_bias_act_inplace) instead of
-    two ATen launches after the MIOpen convolution.  Same arithmetic (add, then max / sigmoid), so results are identical."""
+    """Convolution whose bias add and activation run as ONE HIP kernel (dvmvs_bias_act_fwd) instead of two ATen launches
+    after the MIOpen convolution.  Same arithmetic (add, then max / sigmoid), so results are identical.  Three launch savers:
+    * ``out=``: the epilogue writes into a caller-supplied channel slice of a concatenation buffer (no torch.cat copy later);
+    * ``defer_epilogue``: a ReLU convolution directly followed by a depthwise one hands over its RAW output, and the depthwise
+      kernel applies bias + ReLU to its input taps on the fly (``pre_bias``): one launch per MnasNet block less;
+    * depthwise layers are a single HIP launch (convolution + bias + activation)."""
 
     def __init__(self, conv, activation):
         super().__init__()
@@ -83,26 +92,30 @@ class FusedConv2d(nn.Module):
         self.stride, self.padding, self.dilation, self.groups = conv.stride, conv.padding, conv.dilation, conv.groups
         self.activation = _ops.ACTIVATIONS[activation]
         self.register_buffer("_no_bias", torch.empty(0, device=conv.weight.device), persistent=False)
+        self.defer_epilogue = False      # set by fuse_epilogues: the next (depthwise) layer applies this layer's bias + ReLU
+        self.pre_bias = None             # set by fuse_epilogues on that depthwise layer: the deferred bias
 
         k = conv.kernel_size
         self.depthwise = (conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1 and k[0] == k[1] and k[0] in (3, 5)
                           and tuple(conv.padding) == (k[0] // 2, k[0] // 2) and tuple(conv.dilation) == (1, 1)
                           and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2))
 
-    def forward(self, x, residual=None, residual_mode=0):
-        """``residual`` (mode 1: same shape, mode 2: half resolution, nearest-up-sampled) is added in the same epilogue."""
-        if self.depthwise and residual is None:   # MnasNet depthwise layers: one HIP launch instead of MIOpen's naive kernel + epilogue
-            return _ops.depthwise_conv(x, self.weight, self.bias if self.bias is not None else self._no_bias, self.stride[0],
-                                       self.activation)
+    def forward(self, x, residual=None, residual_mode=0, out=None, activation=None, p0=0.0, p1=0.0):
+        """``residual`` (mode 1: same shape, mode 2: half resolution, nearest-up-sampled) is added in the same epilogue; ``out``
+        is the destination (default: the convolution's own output buffer); ``activation`` overrides the layer's."""
+        act = self.activation if activation is None else activation
+        if self.depthwise and residual is None and out is None:
+            pre = self.pre_bias
+            return _ops.depthwise_conv(x, self.weight, self.bias if self.bias is not None else self._no_bias, self.stride[0], act,
+                                       pre if pre is not None else self._no_bias, pre is not None)
+        if self.pre_bias is not None:
+            raise RuntimeError("a depthwise layer with a deferred input epilogue must take the depthwise kernel")
         y = nn.functional.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
         if not y.is_contiguous():
             y = y.contiguous()
-        bias = self.bias if self.bias is not None else self._no_bias
-        if residual is None:
-            _ops.bias_act_(y, bias, self.activation, self._no_bias, 0)
-        else:
-            _ops.bias_act_(y, bias, self.activation, residual, residual_mode)
-        return y
+        if self.defer_epilogue:
+            return y
+        return _ops.bias_act_into(y, y if out is None else out, self.bias, act, residual, residual_mode if residual is not None else 0, p0, p1)
 
 
 def fuse_epilogues(module):
@@ -133,6 +146,16 @@ def fuse_epilogues(module):
                 m = parent._modules[name]
                 if isinstance(m, nn.Conv2d) and m.bias is not None:
                     parent._modules[name] = FusedConv2d(m, "none")
+    # a ReLU convolution directly followed by a depthwise layer: its epilogue moves into the depthwise kernel's input read
+    for parent in module.modules():
+        if not isinstance(parent, nn.Sequential):
+            continue
+        fused = [m for m in parent._modules.values() if not isinstance(m, nn.Identity)]
+        for first, second in zip(fused, fused[1:]):
+            if isinstance(first, FusedConv2d) and isinstance(second, FusedConv2d) and second.depthwise and not first.depthwise and \
+                    first.activation == _ops.ACTIVATIONS["relu"] and first.bias is not None and first.groups == 1:
+                first.defer_epilogue = True
+                second.pre_bias = first.bias
     # shortcut sums folded into the producing convolution's epilogue
     from dvmvs.backbone import FeaturePyramidNetwork, InvertedResidual
     for m in module.modules():
@@ -187,6 +210,8 @@ class DepthEngine:
         self.sequences = int(sequences)
         if self.sequences < 1:
             raise ValueError("sequences must be >= 1")
+        # destination-passing frame body (see the module docstring): needs the fused epilogues and contiguous channel slices
+        self.direct = bool(fuse and fold_bn and not channels_last and self.sequences == 1)
         self.pose_algebra = _pose_algebra._mode(pose_algebra)
         self._prev_pose_host = torch.eye(4).repeat(self.sequences, 1, 1)
         self._no_previous = torch.ones(self.sequences, dtype=torch.bool)   # sequences whose next frame has no previous frame
@@ -281,14 +306,27 @@ class DepthEngine:
                 total += n
             params = z(total)
             view = lambda name, *shape: params[self._param_offsets[name][0]:self._param_offsets[name][0] + self._param_offsets[name][1]].view(*shape)
-            self._static = dict(image=z(S, 3, H, W), params=params,
+            direct = {}
+            if self.direct:
+                hc = 32
+                direct = dict(enc_cat=[z(1, 32 + 64, H // 2, W // 2), z(1, 32 + 2 * hc, H // 4, W // 4), z(1, 32 + 4 * hc, H // 8, W // 8),
+                                       z(1, 32 + 8 * hc, H // 16, W // 16)],
+                              dec_cat=[z(1, 16 * hc, H // 16, W // 16), z(1, 8 * hc + 1, H // 8, W // 8), z(1, 4 * hc + 1, H // 4, W // 4),
+                                       z(1, 2 * hc + 1, H // 2, W // 2)],
+                              full_in=z(1, hc + 1 + 3, H, W), lstm_cat=z(1, 32 * hc, H // 32, W // 32), zbuffer=z(1, H // 2, W // 2),
+                              estimate=z(1, 1, H // 32, W // 32), depth_store=z(1, H, W))
+            self._direct_buffers = direct
+            image = direct["full_in"][:, 33:36] if self.direct else z(S, 3, H, W)      # the decoder's last concatenation ends with the image
+            depth = direct["depth_store"] if self.direct else z(S, H, W)
+            ref_half = direct["enc_cat"][0][:, :32] if self.direct else z(S, 32, H // 2, W // 2)
+            self._static = dict(image=image, params=params,
                                 reproject_T=view("reproject_T", S, 4, 4), lstm_T=view("lstm_T", S, 4, 4),
                                 full_K=view("full_K", S, 3, 3), half_K=view("half_K", S, 3, 3), lstm_K=view("lstm_K", S, 3, 3),
                                 pose=view("pose", S, 4, 4), prev_pose=view("prev_pose", S, 4, 4),
                                 meas_pose=[view("meas_pose", _MAX_MEAS, S, 4, 4)[i] for i in range(_MAX_MEAS)],
-                                prev_depth=z(S, 1, H, W), h=z(S, 512, H // 32, W // 32),
-                                c=z(S, 512, H // 32, W // 32), meas_feat=[],
-                                ref_half=z(S, 32, H // 2, W // 2), depth=z(S, H, W))
+                                # direct: the depth buffer IS next frame's previous depth (written once, by the last epilogue)
+                                prev_depth=depth.view(S, 1, H, W) if self.direct else z(S, 1, H, W), h=z(S, 512, H // 32, W // 32),
+                                c=z(S, 512, H // 32, W // 32), meas_feat=[], ref_half=ref_half, depth=depth)
             self._ring = [(torch.zeros(total, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(_STAGING_SLOTS)]
         while len(self._static["meas_feat"]) < n_meas:
             self._static["meas_feat"].append(z(S, 32, H // 2, W // 2))
@@ -328,8 +366,15 @@ class DepthEngine:
             put("Hm", Hm)
             put("kt", kt)
             if self.is_fusionnet:
-                put("reproject_T", _pose_algebra.relative_pose_host(pose, previous))   # utils.py:121
-                put("lstm_T", _pose_algebra.relative_pose_host(previous, pose))        # convlstm.py:30
+                eye = torch.eye(4).expand(S, 4, 4)
+                if bool(self._no_previous.all()):      # nothing to relate to: the identity, exactly (see above)
+                    reproject_T = lstm_T = eye
+                else:
+                    fresh = self._no_previous.view(S, 1, 1)
+                    reproject_T = torch.where(fresh, eye, _pose_algebra.relative_pose_host(pose, previous))   # utils.py:121
+                    lstm_T = torch.where(fresh, eye, _pose_algebra.relative_pose_host(previous, pose))        # convlstm.py:30
+                put("reproject_T", reproject_T)
+                put("lstm_T", lstm_T)
         put("full_K", full_K)
         put("half_K", half_K)
         put("lstm_K", lstm_K)
@@ -341,8 +386,80 @@ class DepthEngine:
         self._prev_pose_host = pose.clone()
         self._no_previous[:] = False
 
+    # ---- destination-passing frame body (one sequence) ------------------------------------------------------------------
+    def _fpn_direct(self, taps, outs):
+        """FeaturePyramidNetwork.forward (dvmvs/backbone.py; torchvision's top-down pathway) with the four used outputs written
+        into ``outs`` and the unused 1/32 output (fusionnet/model.py:159-164 drops it) not computed."""
+        fpn = self.fs.fpn
+        top = fpn.inner_blocks[-1](taps[-1])
+        for level in range(len(taps) - 2, -1, -1):
+            top = fpn.inner_blocks[level](taps[level], residual=top, residual_mode=2)
+            fpn.layer_blocks[level](top, out=outs[level])
+
+    def _decoder_block_direct(self, block, x, cat, depth):
+        """DecoderBlock.forward (dvmvs/networks.py) on the concatenation buffer ``cat`` = [up-convolution | skip | up(depth)]; the skip
+        slice has already been written by the encoder's aggregator."""
+        up_channels = block.up_convolution.conv[0].weight.shape[0]
+        block.up_convolution.conv[0](_ops.upsample2x(x), out=cat[:, :up_channels])
+        if depth is not None:
+            _ops.upsample2x_into(depth, cat[:, -1:])
+        return block.convolution2[0](block.convolution1[0](cat))
+
+    def _frame_body_direct(self, n_meas, has_previous):
+        s, d = self._static, self._direct_buffers
+        enc_cat, dec_cat = d["enc_cat"], d["dec_cat"]
+        # features: MnasNet taps -> FPN, each used output into the front of its encoder concatenation buffer
+        self._fpn_direct(self.fe(s["image"]), [c[:, :32] for c in enc_cat])
+        Hm, kt = self._sweep_views(n_meas)
+        if self.pose_algebra == "exact":
+            Hm, kt = _ops.sweep_matrices(s["pose"], s["meas_pose"][:n_meas], s["half_K"])
+        _ops.cost_volume_into(s["ref_half"], s["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, enc_cat[0][:, 32:],
+                              _utils.COST_VOLUME_VARIANT)
+        # encoder: aggregator output = skip connection, written where the decoder will read it
+        enc, dec = self.enc, self.dec
+        x = None
+        for level in range(4):
+            skip_channels = getattr(enc, f"aggregator{level}")[0].weight.shape[0]
+            cat = dec_cat[3 - level]
+            up_channels = cat.shape[1] - skip_channels - (1 if level < 3 else 0)
+            skip = getattr(enc, f"aggregator{level}")[0](enc_cat[level], out=cat[:, up_channels:up_channels + skip_channels])
+            block = getattr(enc, f"encoder_block{level}")
+            x = block.standard_convolution.conv1[0](block.down_convolution.down_conv[0](skip))
+            if level < 3:
+                block.standard_convolution.conv2[0](x, out=enc_cat[level + 1][:, 32:])
+            elif self.is_fusionnet:
+                x = block.standard_convolution.conv2[0](x, out=d["lstm_cat"][:, :512])
+            else:
+                x = block.standard_convolution.conv2[0](x)
+        bottom = x
+        if self.is_fusionnet:
+            cell = self.lstm.lstm_cell
+            if has_previous:
+                exact = self.pose_algebra == "exact"
+                reproject_T = _ops.relative_pose(s["pose"], s["prev_pose"]) if exact else s["reproject_T"]
+                lstm_T = _ops.relative_pose(s["prev_pose"], s["pose"]) if exact else s["lstm_T"]
+                _ops.depth_reproject_lowres_into(reproject_T, s["prev_depth"], s["full_K"], s["half_K"], d["zbuffer"], d["estimate"], 16)
+                _ops.hidden_warp_into(s["h"], d["estimate"], lstm_T, s["lstm_K"], True, d["lstm_cat"][:, 512:])
+            else:
+                d["lstm_cat"][:, 512:].copy_(s["h"])      # first frame of a sequence: the (zero) state as it is, no warp (convlstm.py:29)
+            _ops.lstm_gates_into(cell.conv(d["lstm_cat"]), s["c"], s["h"])
+            bottom = s["h"]
+        d1 = self._decoder_block_direct(dec.decoder_block1, bottom, dec_cat[0], None)
+        d2 = self._decoder_block_direct(dec.decoder_block2, d1, dec_cat[1], dec.depth_layer_one_sixteen[0](d1))
+        d3 = self._decoder_block_direct(dec.decoder_block3, d2, dec_cat[2], dec.depth_layer_one_eight[0](d2))
+        d4 = self._decoder_block_direct(dec.decoder_block4, d3, dec_cat[3], dec.depth_layer_quarter[0](d3))
+        full_in = d["full_in"]
+        _ops.upsample2x_into(d4, full_in[:, :32])
+        _ops.upsample2x_into(dec.depth_layer_half[0](d4), full_in[:, 32:33])
+        refined = dec.refine[1][0](dec.refine[0][0](full_in))
+        # last convolution: bias + sigmoid + depth mapping (model.py:231-232) in one epilogue, into the depth / previous-depth buffer
+        dec.depth_layer_full[0](refined, out=s["prev_depth"], activation=_ops.ACTIVATION_SIGMOID_TO_DEPTH,
+                                p0=dec.inverse_depth_multiplier, p1=dec.inverse_depth_base)
+
     def _frame_body(self, n_meas, has_previous):
         """The per-frame computation on the static buffers (this is what gets captured into a hipGraph)."""
+        if self.direct:
+            return self._frame_body_direct(n_meas, has_previous)
         s = self._static
         feats = self._features(s["image"])
         ref_half = feats[0].contiguous()
@@ -434,6 +551,8 @@ class DepthEngine:
         state buffer changes); the caller replays the graph to actually run the frame."""
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
+        if getattr(self, "graph_debug", False):     # bench.py counts the kernel nodes of the frame graph from its dot dump
+            graph.enable_debug_mode()
         with torch.cuda.graph(graph):
             self._frame_body(*key)
         return graph

@@ -421,7 +421,7 @@ def upsample2x(x: Tensor) -> Tensor:
     B, C, H, W = x.shape
     out = torch.empty((B, C, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _capi.lib().dvmvs_upsample2x_fwd(_ptr(x), _ptr(out), B, C, H, W, _stream(x))
+        rc = _capi.lib().dvmvs_upsample2x_fwd(_ptr(x), _ptr(out), 0, B, C, H, W, _stream(x))
     _capi.check(rc, "dvmvs_upsample2x_fwd")
     return out
 
@@ -438,8 +438,10 @@ def _(x):
 
 
 @torch.library.custom_op("dvmvs::depthwise_conv", mutates_args=(), device_types="cuda")
-def depthwise_conv(x: Tensor, weight: Tensor, bias: Tensor, stride: int, activation: int) -> Tensor:
-    """Depthwise k x k convolution (weight [C,1,k,k], padding k//2) + bias (numel 0 = none) + activation, one HIP launch."""
+def depthwise_conv(x: Tensor, weight: Tensor, bias: Tensor, stride: int, activation: int, pre_bias: Tensor, pre_relu: bool) -> Tensor:
+    """Depthwise k x k convolution (weight [C,1,k,k], padding k//2) + bias (numel 0 = none) + activation, one HIP launch.  With
+    ``pre_relu`` the input is the raw output of the preceding 1x1 convolution and relu(x + pre_bias[c]) (numel 0 = no bias) is applied
+    to it on the fly."""
     _dev_f32("depthwise_conv", x, weight)
     x, weight = x.contiguous(), weight.contiguous()
     B, C, H, W = x.shape
@@ -450,14 +452,17 @@ def depthwise_conv(x: Tensor, weight: Tensor, bias: Tensor, stride: int, activat
     OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     out = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _capi.lib().dvmvs_depthwise_conv_fwd(_ptr(x), _ptr(weight), _ptr(bias.contiguous()) if bias.numel() else None, _ptr(out),
+        if pre_bias.numel() not in (0, C):
+            raise ValueError(f"dvmvs::depthwise_conv: pre_bias has {pre_bias.numel()} entries for {C} channels")
+        rc = _capi.lib().dvmvs_depthwise_conv_fwd(_ptr(x), _ptr(weight), _ptr(bias.contiguous()) if bias.numel() else None,
+                                                  _ptr(pre_bias.contiguous()) if pre_bias.numel() else None, int(bool(pre_relu)), _ptr(out),
                                                   B, C, H, W, k, int(stride), int(activation), _stream(x))
     _capi.check(rc, "dvmvs_depthwise_conv_fwd")
     return out
 
 
 @depthwise_conv.register_fake
-def _(x, weight, bias, stride, activation):
+def _(x, weight, bias, stride, activation, pre_bias, pre_relu):
     B, C, H, W = x.shape
     k = weight.shape[-1]
     pad = k // 2
@@ -465,5 +470,118 @@ def _(x, weight, bias, stride, activation):
 
 
 @depthwise_conv.register_kernel("cpu")
-def _(x, weight, bias, stride, activation):
+def _(x, weight, bias, stride, activation, pre_bias, pre_relu):
     _no_cpu("depthwise_conv")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# destination-passing forms for the frame engine (inference, no autograd, hipGraph-capturable): the producer writes straight
+# into a channel slice of a concatenation buffer or into a state buffer, so that torch.cat / copy_ launches disappear from
+# the frame.  Plain functions over the C ABI, not torch.library ops: nothing here allocates or needs shape inference.
+# ----------------------------------------------------------------------------------------------------------------------
+ACTIVATION_SIGMOID_TO_DEPTH = 3
+
+
+def _slice_batch_stride(name, dst, B, C, H, W):
+    """``dst`` must be [B,C,H,W] with dense planes and channels (a channel slice of a contiguous NCHW buffer); returns its batch
+    stride in elements."""
+    if dst.device.type != "cuda" or dst.dtype != torch.float32:
+        raise TypeError(f"dvmvs::{name}: destination must be a float32 HIP tensor")
+    if tuple(dst.shape) != (B, C, H, W) or dst.stride(3) != 1 or dst.stride(2) != W or dst.stride(1) != H * W:
+        raise ValueError(f"dvmvs::{name}: destination {tuple(dst.shape)} / strides {dst.stride()} is not a channel slice of a "
+                         f"contiguous NCHW buffer for [{B},{C},{H},{W}]")
+    return dst.stride(0) if B > 1 else C * H * W
+
+
+def bias_act_into(x: Tensor, dst: Tensor, bias, activation: int, residual=None, residual_mode: int = RESIDUAL_NONE, p0: float = 0.0,
+                  p1: float = 0.0) -> Tensor:
+    """dst = act(x + bias[c]) (+ residual); ``x`` a dense convolution output, ``dst`` x itself or a channel slice (see above)."""
+    _dev_f32("bias_act_into", x)
+    if not x.is_contiguous() or x.dim() != 4:
+        raise ValueError("dvmvs::bias_act_into: expected a contiguous NCHW source")
+    B, C, H, W = x.shape
+    stride = _slice_batch_stride("bias_act_into", dst, B, C, H, W)
+    if bias is not None and bias.numel() not in (0, C):
+        raise ValueError(f"dvmvs::bias_act_into: bias has {bias.numel()} entries for {C} channels")
+    res_ptr = None
+    if residual_mode != RESIDUAL_NONE:
+        want = (B, C, H, W) if residual_mode == RESIDUAL_SAME else (B, C, H // 2, W // 2)
+        if tuple(residual.shape) != want or not residual.is_contiguous():
+            raise ValueError(f"dvmvs::bias_act_into: residual {tuple(residual.shape)} does not match {want} (contiguous)")
+        res_ptr = _ptr(residual)
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().dvmvs_bias_act_fwd(_ptr(x), _ptr(dst), stride, _ptr(bias) if bias is not None and bias.numel() else None, res_ptr,
+                                            int(residual_mode), B, C, H, W, int(activation), float(p0), float(p1), _stream(x))
+    _capi.check(rc, "dvmvs_bias_act_fwd")
+    return dst
+
+
+def upsample2x_into(x: Tensor, dst: Tensor) -> Tensor:
+    _dev_f32("upsample2x_into", x)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    stride = _slice_batch_stride("upsample2x_into", dst, B, C, 2 * H, 2 * W)
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().dvmvs_upsample2x_fwd(_ptr(x), _ptr(dst), stride, B, C, H, W, _stream(x))
+    _capi.check(rc, "dvmvs_upsample2x_fwd")
+    return dst
+
+
+def lstm_gates_into(combined_conv: Tensor, c_state: Tensor, h_state: Tensor) -> None:
+    """State update in place: c_state <- c', h_state <- h' (the kernel reads a row of c completely before it writes it)."""
+    _dev_f32("lstm_gates_into", combined_conv, c_state, h_state)
+    B, hidden, H, W = c_state.shape
+    if tuple(combined_conv.shape) != (B, 4 * hidden, H, W) or tuple(h_state.shape) != tuple(c_state.shape):
+        raise ValueError("dvmvs::lstm_gates_into: shapes do not match")
+    if not (combined_conv.is_contiguous() and c_state.is_contiguous() and h_state.is_contiguous()):
+        raise ValueError("dvmvs::lstm_gates_into: expected contiguous tensors")
+    with torch.cuda.device(c_state.device):
+        rc = _capi.lib().dvmvs_lstm_gates_fwd(_ptr(combined_conv), _ptr(c_state), _ptr(h_state), _ptr(c_state), B, hidden, H, W, _stream(c_state))
+    _capi.check(rc, "dvmvs_lstm_gates_fwd")
+
+
+def hidden_warp_into(image_src: Tensor, depth_dst: Tensor, src_trans_dst: Tensor, camera_matrix: Tensor, zero_invalid: bool, dst: Tensor) -> Tensor:
+    _dev_f32("hidden_warp_into", image_src, depth_dst, src_trans_dst, camera_matrix, dst)
+    B, C, H, W = image_src.shape
+    if not (image_src.is_contiguous() and dst.is_contiguous() and tuple(dst.shape) == (B, C, H, W)):
+        raise ValueError("dvmvs::hidden_warp_into: source and destination must be contiguous [B,C,H,W]")
+    with torch.cuda.device(image_src.device):
+        rc = _capi.lib().dvmvs_hidden_warp_fwd(_ptr(image_src), _ptr(depth_dst.contiguous()), _ptr(src_trans_dst.contiguous()),
+                                               _ptr(camera_matrix.contiguous()), _ptr(dst), B, C, H, W, int(bool(zero_invalid)), _stream(image_src))
+    _capi.check(rc, "dvmvs_hidden_warp_fwd")
+    return dst
+
+
+def depth_reproject_lowres_into(transformation: Tensor, previous_depth: Tensor, full_K: Tensor, half_K: Tensor, zbuffer: Tensor, out_lowres: Tensor,
+                                factor: int) -> Tensor:
+    """Splat + decimate with a caller-owned z-buffer [B,Hf/2,Wf/2] that is all-zero before and after the call (two launches)."""
+    _dev_f32("depth_reproject_lowres_into", transformation, previous_depth, full_K, half_K, zbuffer, out_lowres)
+    B, one, Hf, Wf = previous_depth.shape
+    if one != 1 or zbuffer.numel() != B * (Hf // 2) * (Wf // 2) or not zbuffer.is_contiguous() or not out_lowres.is_contiguous() or \
+            out_lowres.numel() != B * ((Hf // 2) // factor) * ((Wf // 2) // factor):
+        raise ValueError("dvmvs::depth_reproject_lowres_into: buffer shapes do not match the previous depth")
+    with torch.cuda.device(previous_depth.device):
+        rc = _capi.lib().dvmvs_depth_reproject_lowres_fwd(_ptr(transformation.contiguous()), _ptr(previous_depth.contiguous()), _ptr(full_K.contiguous()),
+                                                          _ptr(half_K.contiguous()), _ptr(zbuffer), _ptr(out_lowres), int(factor), B, Hf, Wf,
+                                                          _stream(previous_depth))
+    _capi.check(rc, "dvmvs_depth_reproject_lowres_fwd")
+    return out_lowres
+
+
+def cost_volume_into(image1: Tensor, image2s, Hm: Tensor, kt: Tensor, min_depth: float, max_depth: float, dst: Tensor, variant: int = 0) -> Tensor:
+    """Dot-product cost volume written into ``dst`` [B,D,H,W] (contiguous: for B == 1 a channel slice of a larger buffer is)."""
+    _dev_f32("cost_volume_into", image1, Hm, kt, dst, *image2s)
+    B, C, H, W = image1.shape
+    M, D = len(image2s), dst.shape[1]
+    _check_sweep_matrices("cost_volume_into", Hm, kt, B, M)
+    if not (image1.is_contiguous() and dst.is_contiguous() and tuple(dst.shape) == (B, D, H, W) and all(t.is_contiguous() for t in image2s)):
+        raise ValueError("dvmvs::cost_volume_into: expected contiguous NCHW tensors")
+    workspace, ws_bytes = sweep_workspace(image1.device, B, M, H, W, D) if COST_VOLUME_TWO_PASS else (None, 0)
+    with torch.cuda.device(image1.device):
+        rc = _capi.lib().dvmvs_cost_volume_fwd(_ptr(image1), _capi.pointer_array([_ptr(t) for t in image2s]), _ptr(Hm.contiguous()), _ptr(kt.contiguous()),
+                                               _ptr(dst), B, M, C, H, W, D, float(min_depth), float(max_depth), 1, int(variant), _capi.LAYOUT_NCHW,
+                                               _ptr(workspace) if workspace is not None else None, ws_bytes, _stream(image1))
+    if rc != 0 and workspace is not None:
+        drop_sweep_workspace(image1.device, B, M, H, W, D)
+    _capi.check(rc, "dvmvs_cost_volume_fwd")
+    return dst

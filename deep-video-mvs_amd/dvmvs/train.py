@@ -97,7 +97,12 @@ def train(train_loader, val_loader, model, optimizer, summary_writer, epoch, bes
     training = _run_epoch(train_loader, model, forward_pass_function, True, on_batch=step)
 
     if Config.train_validate:
-        validation = validate(val_loader=val_loader, model=model, forward_pass_function=forward_pass_function)
+        # data-parallel run (one process per GPU, gradient_reducer): every rank validates its own shard, the meters are summed
+        # over the ranks, so all ranks see the SAME validation losses, take the same "best so far" decision, and only rank 0
+        # writes the checkpoint files into the shared run directory
+        validation = validate(val_loader=val_loader, model=model, forward_pass_function=forward_pass_function,
+                              reduce_over_ranks=gradient_reducer is not None)
+        writer_rank = not (gradient_reducer is not None and _distributed() and torch.distributed.get_rank() != 0)
         end_step = (epoch + 1) * steps_per_epoch
         if summary_writer is not None:
             for name, meter, value in zip(METER_NAMES, training, validation):
@@ -107,16 +112,30 @@ def train(train_loader, val_loader, model, optimizer, summary_writer, epoch, bes
             for k, value in enumerate(validation):
                 best_loss[k] = min(value, best_loss[k])
             l1, huber, l1_inv, l1_rel = validation
-            named = [{"name": "module_" + str(k), "epoch": epoch + 1, "state_dict": module.state_dict()} for k, module in enumerate(model)]
-            save_checkpoint(run_directory, named, step=end_step, loss=[l1, l1_inv, l1_rel, huber])
-            save_optimizer(run_directory, optimizer=optimizer, step=end_step, loss=[l1, l1_inv, l1_rel, huber])
+            if writer_rank:
+                named = [{"name": "module_" + str(k), "epoch": epoch + 1, "state_dict": module.state_dict()} for k, module in enumerate(model)]
+                save_checkpoint(run_directory, named, step=end_step, loss=[l1, l1_inv, l1_rel, huber])
+                save_optimizer(run_directory, optimizer=optimizer, step=end_step, loss=[l1, l1_inv, l1_rel, huber])
         switch_mode(model=model, mode="train")   # validation left the modules in eval mode
     return [meter.avg for meter in training]
 
 
-def validate(val_loader, model, forward_pass_function):
-    """Running means (L1, Huber, L1-inv, L1-rel) of the full-resolution prediction over ``val_loader``, modules in eval mode."""
+def _distributed():
+    return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+
+
+def validate(val_loader, model, forward_pass_function, reduce_over_ranks=False):
+    """Running means (L1, Huber, L1-inv, L1-rel) of the full-resolution prediction over ``val_loader``, modules in eval mode.
+    With ``reduce_over_ranks`` (data-parallel training) sums and counts are all-reduced first: the means are those of the whole
+    validation set on every rank."""
     switch_mode(model=model, mode="eval")
     with torch.no_grad():
         meters = _run_epoch(val_loader, model, forward_pass_function, False)
+    if reduce_over_ranks and _distributed():
+        device = next(model[0].parameters()).device
+        if torch.distributed.get_backend() == "nccl" and device.type != "cuda":
+            device = torch.device("cuda", torch.cuda.current_device())
+        totals = torch.tensor([[float(m.sum), float(m.count)] for m in meters], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(totals, op=torch.distributed.ReduceOp.SUM)
+        return tuple(float(s / c) if c > 0 else 0.0 for s, c in totals.tolist())
     return tuple(meter.avg for meter in meters)

@@ -147,7 +147,7 @@ int dvmvs_relative_pose(const float* a, const float* c, float* out, int B, dvmvs
  *   i,f,o = sigmoid; g = celu(LN_hw(cc_g)); c' = LN_hw(f*c + i*g); h' = o*celu(c').  LN: biased variance,
  *   eps 1e-5, no affine; celu alpha = 1.
  * Replaces /root/reference/dvmvs/convlstm.py:45-59.
- *   combined_conv [B,4*hidden,H,W]   c_cur [B,hidden,H,W]   h_next, c_next [B,hidden,H,W] out
+ *   combined_conv [B,4*hidden,H,W]   c_cur [B,hidden,H,W]   h_next, c_next [B,hidden,H,W] out; c_next may be c_cur (in-place state update)
  */
 int dvmvs_lstm_gates_fwd(const float* combined_conv, const float* c_cur, float* h_next, float* c_next,
                          int B, int hidden, int H, int W, dvmvs_stream_t stream);
@@ -173,26 +173,43 @@ int dvmvs_lstm_gates_bwd(const float* grad_h, const float* grad_c, const float* 
 int dvmvs_depth_reproject_fwd(const float* transformation, const float* previous_depth, const float* full_K,
                               const float* half_K, float* out, float* out_lowres, int lowres_factor,
                               int B, int full_height, int full_width, dvmvs_stream_t stream);
+/*
+ * The frame path's form of the above: only the decimated estimate [B,1,(Hf/2)/f,(Wf/2)/f] is produced.  `zbuffer`
+ * [B,Hf/2,Wf/2] is caller-owned scratch that MUST be all-zero when the call starts; the call leaves it all-zero again (the
+ * decimation kernel clears it), so the owner zero-fills it once: two launches per frame instead of three.
+ */
+int dvmvs_depth_reproject_lowres_fwd(const float* transformation, const float* previous_depth, const float* full_K,
+                                     const float* half_K, float* zbuffer, float* out_lowres, int lowres_factor,
+                                     int B, int full_height, int full_width, dvmvs_stream_t stream);
 
 /*
- * Frame-path epilogues (not part of the reference's function list; they replace ATen elementwise launches that sit
- * between MIOpen convolutions on the per-frame path, /root/reference/dvmvs/layers.py:39-65 and fusionnet/model.py:57,112,290).
- *   dvmvs_bias_act_inplace: x[b,c,:,:] = act(x[b,c,:,:] + bias[c]) [+ residual]; bias may be NULL; activation 0 none, 1 ReLU,
- *                           2 sigmoid; residual_mode 0 none, 1 residual [B,C,H,W] (MnasNet shortcut), 2 residual [B,C,H/2,W/2]
- *                           nearest-up-sampled on the fly (FPN top-down sum, torchvision FeaturePyramidNetwork.forward).
+ * Frame-path epilogues (not part of the reference's function list; they replace ATen elementwise / copy launches that sit
+ * between MIOpen convolutions on the per-frame path, /root/reference/dvmvs/layers.py:39-65 and fusionnet/model.py:57,112,231-232,290-303).
+ * At batch 1 a frame is ~250 launches of a few microseconds each, so what these buy is launches, not FLOPs.
+ *   dvmvs_bias_act_fwd:     dst[b,c,:,:] = act(x[b,c,:,:] + bias[c]) [+ residual]; x is a dense [B,C,H,W] convolution output, dst may
+ *                           be x (in place) or a CHANNEL SLICE of a larger buffer: batch item b starts at dst + b * dst_batch_stride
+ *                           (in floats), its C planes are dense -- a torch.cat of convolution outputs is then never copied.
+ *                           bias may be NULL; activation 0 none, 1 ReLU, 2 sigmoid, 3 sigmoid then the decoder's depth mapping
+ *                           1 / (p0 * s + p1) (fusionnet/model.py:231-232,297-303); residual_mode 0 none, 1 residual [B,C,H,W]
+ *                           (MnasNet shortcut), 2 residual [B,C,H/2,W/2] nearest-up-sampled on the fly (FPN top-down sum).
+ *   dvmvs_bias_act_inplace: the same with dst = x (activations 0..2).
  *   dvmvs_upsample2x_fwd:   torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True);
- *                           in [B,C,H,W] -> out [B,C,2H,2W].
+ *                           in [B,C,H,W] -> out [B,C,2H,2W], batch item b at out + b * out_batch_stride (0 = dense).
  */
+int dvmvs_bias_act_fwd(const float* x, float* dst, long long dst_batch_stride, const float* bias, const float* residual,
+                       int residual_mode, int B, int C, int H, int W, int activation, float p0, float p1, dvmvs_stream_t stream);
 int dvmvs_bias_act_inplace(float* x, const float* bias, const float* residual, int residual_mode, int B, int C, int H, int W,
                            int activation, dvmvs_stream_t stream);
-int dvmvs_upsample2x_fwd(const float* in, float* out, int B, int C, int H, int W, dvmvs_stream_t stream);
+int dvmvs_upsample2x_fwd(const float* in, float* out, long long out_batch_stride, int B, int C, int H, int W, dvmvs_stream_t stream);
 /*
  *   dvmvs_depthwise_conv_fwd: depthwise convolution (groups == C, weight [C,1,k,k], k in {3,5}, padding k/2, stride 1|2)
  *                           with bias (may be NULL) and activation fused; in [B,C,H,W] -> out [B,C,OH,OW].  The MnasNet
- *                           depthwise layers of the feature extractor (torchvision mnasnet _InvertedResidual).
+ *                           depthwise layers of the feature extractor (torchvision mnasnet _InvertedResidual).  With pre_relu != 0
+ *                           the input is the RAW output of the preceding 1x1 expansion convolution and relu(in + pre_bias[c])
+ *                           (pre_bias may be NULL) is applied to every in-bounds tap on the fly.
  */
-int dvmvs_depthwise_conv_fwd(const float* in, const float* weight, const float* bias, float* out, int B, int C, int H, int W,
-                             int kernel_size, int stride, int activation, dvmvs_stream_t stream);
+int dvmvs_depthwise_conv_fwd(const float* in, const float* weight, const float* bias, const float* pre_bias, int pre_relu, float* out,
+                             int B, int C, int H, int W, int kernel_size, int stride, int activation, dvmvs_stream_t stream);
 
 /*
  * TSDF fusion of one RGB-D frame into a voxel volume, in place.  Replaces the `integrate` CUDA kernel the reference's

@@ -589,15 +589,105 @@ def test_fused_modules_match_plain_modules(dev):
 
 def test_depthwise_conv_matches_torch(ops, dev):
     g = torch.Generator().manual_seed(23)
+    none = torch.empty(0, device=dev)
     for (B, C, H, W, k, stride) in ((1, 32, 128, 160, 3, 1), (1, 48, 128, 160, 3, 2), (2, 72, 33, 41, 5, 2), (1, 240, 32, 40, 5, 1),
                                     (1, 1152, 8, 10, 3, 1), (1, 3, 7, 5, 5, 1)):
         x = torch.randn(B, C, H, W, generator=g)
         w = torch.randn(C, 1, k, k, generator=g) * 0.3
         b = torch.randn(C, generator=g)
         for name, fn in (("none", lambda t: t), ("relu", torch.relu), ("sigmoid", torch.sigmoid)):
-            got = ops.depthwise_conv(x.to(dev), w.to(dev), b.to(dev), stride, ops.ACTIVATIONS[name])
+            got = ops.depthwise_conv(x.to(dev), w.to(dev), b.to(dev), stride, ops.ACTIVATIONS[name], none, False)
             exp = fn(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=k // 2, groups=C))
             assert tuple(got.shape) == tuple(exp.shape)
             assert maxerr(got, exp) < 2e-5 * max(1.0, exp.abs().max().item()), (B, C, H, W, k, stride, name)
-        got = ops.depthwise_conv(x.to(dev), w.to(dev), torch.empty(0, device=dev), stride, 0)
+        got = ops.depthwise_conv(x.to(dev), w.to(dev), none, stride, 0, none, False)
         assert maxerr(got, torch.nn.functional.conv2d(x, w, None, stride=stride, padding=k // 2, groups=C)) < 2e-5 * 10
+        # the preceding 1x1 convolution's epilogue (bias + ReLU) applied to the input taps on the fly; the zero padding stays zero
+        pb = torch.randn(C, generator=g)
+        got = ops.depthwise_conv(x.to(dev), w.to(dev), b.to(dev), stride, ops.ACTIVATIONS["relu"], pb.to(dev), True)
+        exp = torch.relu(torch.nn.functional.conv2d(torch.relu(x + pb.view(1, -1, 1, 1)), w, b, stride=stride, padding=k // 2, groups=C))
+        assert maxerr(got, exp) < 2e-5 * max(1.0, exp.abs().max().item()), (B, C, H, W, k, stride, "pre-activated")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# destination-passing forms (the frame engine's launch savers)
+# ----------------------------------------------------------------------------------------------------------------------
+def test_epilogues_write_into_channel_slices(ops, dev):
+    """dvmvs_bias_act_fwd / dvmvs_upsample2x_fwd with a channel slice of a larger buffer as destination (what replaces torch.cat),
+    batch 1 and batch 2 (batch stride of the big buffer), and the sigmoid -> depth mapping of the decoder's last layer."""
+    g = torch.Generator().manual_seed(41)
+    for B in (1, 2):
+        x = torch.randn(B, 7, 12, 20, generator=g)
+        bias = torch.randn(7, generator=g)
+        big = torch.full((B, 16, 12, 20), -5.0, device=dev)
+        ops.bias_act_into(x.to(dev), big[:, 4:11], bias.to(dev), ops.ACTIVATIONS["relu"])
+        exp = torch.relu(x + bias.view(1, -1, 1, 1))
+        assert torch.equal(big[:, 4:11].cpu(), exp) and bool((big[:, :4] == -5.0).all()) and bool((big[:, 11:] == -5.0).all())
+        r = torch.randn(B, 7, 12, 20, generator=g)
+        ops.bias_act_into(x.to(dev), big[:, 9:16], None, ops.ACTIVATIONS["none"], r.to(dev), ops.RESIDUAL_SAME)
+        assert maxerr(big[:, 9:16], x + r) == 0.0
+        up = torch.full((B, 9, 24, 40), 7.0, device=dev)
+        ops.upsample2x_into(x.to(dev), up[:, 1:8])
+        ref = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+        assert maxerr(up[:, 1:8], ref) < 1e-6 and bool((up[:, 0] == 7.0).all()) and bool((up[:, 8] == 7.0).all())
+    # last decoder layer: depth = 1 / (multiplier * sigmoid(conv + bias) + base)   (fusionnet/model.py:231-232, 297-303)
+    y = torch.randn(1, 1, 256, 320, generator=g) * 3
+    b1 = torch.randn(1, generator=g)
+    mult, base = 1 / 0.25 - 1 / 20.0, 1 / 20.0
+    store = torch.zeros(1, 256, 320, device=dev)
+    ops.bias_act_into(y.to(dev), store.view(1, 1, 256, 320), b1.to(dev), ops.ACTIVATION_SIGMOID_TO_DEPTH, p0=mult, p1=base)
+    exp = 1.0 / (mult * torch.sigmoid(y + b1.view(1, 1, 1, 1)) + base).squeeze(1)
+    assert float(((store.cpu() - exp).abs() / exp).max()) < 2e-6
+    with pytest.raises(ValueError):
+        ops.bias_act_into(y.to(dev), torch.zeros(1, 1, 256, 320, device=dev)[:, :, ::2], None, 0)   # not a channel slice
+
+
+def test_state_updates_in_place(ops, dev):
+    """lstm_gates_into (c and h updated in their own buffers) and depth_reproject_lowres_into (z-buffer left all-zero) equal the
+    allocating ops bit for bit."""
+    g = torch.Generator().manual_seed(43)
+    cc, c0 = torch.randn(2, 2048, 8, 10, generator=g).to(dev), torch.randn(2, 512, 8, 10, generator=g).to(dev)
+    h_ref, c_ref = ops.lstm_gates(cc, c0)
+    c_state, h_state = c0.clone(), torch.full_like(c0, 9.0)
+    ops.lstm_gates_into(cc, c_state, h_state)
+    assert torch.equal(c_state, c_ref) and torch.equal(h_state, h_ref)
+    fullK = syn.full_K()
+    halfK = syn.scaled_K(fullK, 2.0)
+    prev = syn.analytic_depth()
+    full, low = hipcall.depth_reproject(ops, syn.pose(10), syn.pose(9), *to(dev, prev, fullK, halfK), 16)
+    from dvmvs import pose_algebra
+    T = pose_algebra.relative_pose(syn.pose(10), syn.pose(9), dev)
+    zbuffer, estimate = torch.zeros(1, 128, 160, device=dev), torch.full((1, 1, 8, 10), -1.0, device=dev)
+    for _ in range(3):     # repeated use of the same z-buffer: it must come back all-zero every time
+        ops.depth_reproject_lowres_into(T, prev.to(dev), fullK.to(dev), halfK.to(dev), zbuffer, estimate, 16)
+        assert torch.equal(estimate, low) and float(zbuffer.abs().max()) == 0.0
+    dst = torch.zeros(1, 1024, 8, 10, device=dev)
+    hw = load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"), "hidden_warp")
+    h0 = syn.analytic_lstm_inputs()[2]
+    lK = syn.scaled_K(syn.full_K(), 32.0)
+    args = to(dev, h0, torch.from_numpy(hw["depth_masked"]), torch.from_numpy(hw["T"]), lK)
+    ops.hidden_warp_into(*args, True, dst[:, 512:])
+    assert torch.equal(dst[:, 512:], ops.hidden_warp(*args, True)) and float(dst[:, :512].abs().max()) == 0.0
+
+
+def test_destination_passing_engine_equals_the_concatenating_one(dev):
+    """The headline engine (one sequence, BN folded, epilogues fused, every producer writing into its consumer's buffer) against
+    the same engine with torch.cat / copy_ launches (direct = False): same convolutions, same kernels, same arithmetic -- the depth
+    must agree to float32 round-off of the re-ordered epilogues (measured: bit-identical or ~1e-7)."""
+    from dvmvs.engine import DepthEngine
+    from dvmvs.fusionnet.model import CostVolumeDecoder, CostVolumeEncoder, FeatureExtractor, FeatureShrinker, LSTMFusion
+    ctors = (FeatureExtractor, FeatureShrinker, CostVolumeEncoder, LSTMFusion, CostVolumeDecoder)
+    mods = syn.build_e2e_modules(ctors)
+    direct = DepthEngine(*mods, device=dev, use_graphs=False)
+    plain = DepthEngine(*mods, device=dev, use_graphs=False)
+    assert direct.direct
+    plain.direct = False
+    fullK = syn.full_K()
+    for n, (r, ms) in enumerate(list(syn.E2E_FRAMES) + [(12, (11, 9))]):
+        args = (syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK)
+        a = direct.step(*args, frame_id=r, measurement_ids=list(ms)).clone()
+        b = plain.step(*args, frame_id=r, measurement_ids=list(ms)).clone()
+        err = float(((a - b).abs() / b).mean())
+        print(f"frame {n}: destination-passing vs concatenating engine, depth rel-L1 {err:.3e}")
+        assert err <= 2e-6, (n, err)
+        assert float((direct._static["h"] - plain._static["h"]).abs().max()) <= 1e-4
