@@ -240,7 +240,9 @@ __device__ inline void tap_weights(float frac_x, float frac_y, float2v* w_n, flo
   *w_s = xw * frac_y;                           // {sw, se}
 }
 
-template <int QPR, int REC>
+// LEAN: the record's quads one after the other (four 16-byte reads in flight instead of eight: 16 registers less), for the
+// configurations that run five waves per SIMD on 96 registers.
+template <int QPR, int REC, bool LEAN = false>
 __device__ inline void tap_plane(const char* tile_bytes, int row_bytes, int addr, float2v frac, const float2v* rv, float2v* acc) {
   const char* row0 = tile_bytes + addr;
   const char* row1 = row0 + row_bytes;
@@ -255,6 +257,7 @@ __device__ inline void tap_plane(const char* tile_bytes, int row_bytes, int addr
     t_ne = fma2(rv[q * 2], ne.lo, t_ne); t_ne = fma2(rv[q * 2 + 1], ne.hi, t_ne);
     t_sw = fma2(rv[q * 2], sw.lo, t_sw); t_sw = fma2(rv[q * 2 + 1], sw.hi, t_sw);
     t_se = fma2(rv[q * 2], se.lo, t_se); t_se = fma2(rv[q * 2 + 1], se.hi, t_se);
+    if (LEAN) __builtin_amdgcn_sched_barrier(0);   // the next quad's reads are not hoisted above these FMAs
   }
   asm volatile("" : "+v"(frac));   // opaque: keeps the four products out of registers between passes (they are loop-invariant
                                     // and would be hoisted right back into the 16 VGPRs this formulation saves)
@@ -391,7 +394,7 @@ __device__ unsigned long long g_sweep_trace[kTraceGroups * kTraceWords];
 // part of a workgroup's dependency chain (eight passes of ~2 us each at 256 threads) -- is then spread over twice as many waves,
 // and a thread carries half the per-plane state (<= 128 registers: 4 waves / SIMD, two 8-wave workgroups per CU).
 template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, int ORDER_ = 2, int PRE_ = 2, bool PLAN0_ = true,
-          bool FASTFULL_ = true, int PSPLIT_ = 1>
+          bool FASTFULL_ = true, int PSPLIT_ = 1, bool LEAN_ = false>
 struct SweepConfig {
   static constexpr int TW = TW_, TH = TH_, DP = DP_, CCH = CCH_, CAP = CAP_, MINSEG = MINSEG_;
   static constexpr int WAVES = WAVES_;   // waves per SIMD the register allocation is held to
@@ -400,6 +403,7 @@ struct SweepConfig {
   static constexpr bool PLAN0 = PLAN0_;  // the run plan is made by wave 0 only (the other waves wait at the barrier)
   static constexpr bool FASTFULL = FASTFULL_;   // straight-line tap block for runs that cover the whole chunk
   static constexpr int PSPLIT = PSPLIT_;
+  static constexpr bool LEAN = LEAN_;    // register diet for 5 waves / SIMD: quads tapped one after the other, reference features loaded per pass
   static constexpr int NPIX = TW * TH;                                 // pixels of a tile = threads of one plane group
   static constexpr int NT = NPIX * PSPLIT;
   static constexpr int DPT = DP / PSPLIT;                              // planes per thread
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
     float4v pre[kPre > 0 ? kPre * kPreRegs : 1];
     float2v rv_next[CCH / 2];
     auto prefetch = [&](int c0) {   // the staged run's pass c0: reference features and the first kPre pieces, requests only
-      load_ref(c0, rv_next);
+      if (!Cfg::LEAN) load_ref(c0, rv_next);
 #pragma unroll
       for (int k = 0; k < kPre; ++k)
         if (k * NT < st_n_pieces) load_piece(k, c0, pre + k * kPreRegs);   // workgroup-uniform
@@ -685,8 +689,12 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
       SWEEP_TRACE(const unsigned long long tr_s0 = __builtin_amdgcn_s_memtime();)
       // ---- stage (run e, pass c0): pieces beyond the prefetched ones, a few in flight at a time, then the prefetched ones ----
       float2v rv[CCH / 2];
+      if (Cfg::LEAN) {
+        load_ref(c0, rv);   // (its round trip overlaps the stores and the barrier below)
+      } else {
 #pragma unroll
-      for (int c = 0; c < CCH / 2; ++c) rv[c] = rv_next[c];
+        for (int c = 0; c < CCH / 2; ++c) rv[c] = rv_next[c];
+      }
       constexpr int kBatch = NHWC ? 4 : 1;
 #pragma unroll
       for (int k0 = kPre; k0 < kPieces; k0 += kBatch) {
@@ -725,12 +733,12 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
       // ---- taps of (run e, pass c0) ----
       if (Cfg::FASTFULL && seg_lo == 0 && seg_hi == DP) {   // the common case as one straight-line block
 #pragma unroll
-        for (int j = 0; j < DPT; ++j) tap_plane<QPR, REC>(tile_bytes, row_bytes, addr[j], frac[j], rv, &acc2[j]);
+        for (int j = 0; j < DPT; ++j) tap_plane<QPR, REC, Cfg::LEAN>(tile_bytes, row_bytes, addr[j], frac[j], rv, &acc2[j]);
       } else {
 #pragma unroll
         for (int j = 0; j < DPT; ++j)
           if (j0 + j >= seg_lo && j0 + j < seg_hi)   // wave-uniform
-            tap_plane<QPR, REC>(tile_bytes, row_bytes, addr[j], frac[j], rv, &acc2[j]);
+            tap_plane<QPR, REC, Cfg::LEAN>(tile_bytes, row_bytes, addr[j], frac[j], rv, &acc2[j]);
       }
       __syncthreads();
       SWEEP_TRACE(const unsigned long long tr_s2 = __builtin_amdgcn_s_memtime(); tr_taps += tr_s2 - tr_s1; ++tr_passes;)
@@ -928,7 +936,11 @@ size_t spill_words_for(int B, int M, int H, int W, int D) {
   return kSpillHeaderWords + groups + groups * spill_slot_words(M, Cfg::DP);
 }
 
-size_t sweep_spill_words(int B, int M, int H, int W, int D) { return spill_words_for<SweepDefault>(B, M, H, W, D); }
+// sized for the finest tiling among the configurations that may use it (each launch indexes it with its own tiling)
+size_t sweep_spill_words(int B, int M, int H, int W, int D) {
+  const size_t a = spill_words_for<SweepDefault>(B, M, H, W, D), b = spill_words_for<SweepConfig<32, 4, 8, 8, 640, 2>>(B, M, H, W, D);
+  return a > b ? a : b;
+}
 
 int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream) { return launch_sweep_tiled<SweepDefault>(a, stream); }
 
@@ -952,6 +964,9 @@ int launch_sweep_tuning(int which_and_grid, const CostVolumeArgs& a, hipStream_t
     case 11: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1536, 2, 4, 2, 3, true, true, 2>>(a, stream, g);  // ... whole pass prefetched
     case 12: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 6, 2, 1, true, true, 2>>(a, stream, g);  // ... 3 / CU (<= 80 registers)
     case 13: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1280, 2, 4, 2, 2, true, true, 2>>(a, stream, g);  // ... 60 KB boxes
+    // 32x4-pixel tiles, planes split over two 128-thread groups: 1280 workgroups of 4 waves, five per CU, all resident
+    case 14: return launch_sweep_tiled<SweepConfig<32, 4, 8, 8, 640, 2, 5, 2, 1, true, true, 2, true>>(a, stream, g);
+    case 15: return launch_sweep_tiled<SweepConfig<32, 4, 8, 8, 640, 2, 5, 2, 1, true, false, 2, true>>(a, stream, g);
     default: return DVMVS_EINVAL;
   }
 }

@@ -442,7 +442,10 @@ class DepthEngine:
                 _ops.hidden_warp_into(s["h"], d["estimate"], lstm_T, s["lstm_K"], True, d["lstm_cat"][:, 512:])
             else:
                 d["lstm_cat"][:, 512:].copy_(s["h"])      # first frame of a sequence: the (zero) state as it is, no warp (convlstm.py:29)
-            _ops.lstm_gates_into(cell.conv(d["lstm_cat"]), s["c"], s["h"])
+            combined = cell.conv(d["lstm_cat"])
+            if not combined.is_contiguous():       # channels-last convolution (lstm_channels_last): back to the gates' NCHW rows
+                combined = combined.contiguous()
+            _ops.lstm_gates_into(combined, s["c"], s["h"])
             bottom = s["h"]
         d1 = self._decoder_block_direct(dec.decoder_block1, bottom, dec_cat[0], None)
         d2 = self._decoder_block_direct(dec.decoder_block2, d1, dec_cat[1], dec.depth_layer_one_sixteen[0](d1))

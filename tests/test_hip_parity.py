@@ -691,3 +691,28 @@ def test_destination_passing_engine_equals_the_concatenating_one(dev):
         print(f"frame {n}: destination-passing vs concatenating engine, depth rel-L1 {err:.3e}")
         assert err <= 2e-6, (n, err)
         assert float((direct._static["h"] - plain._static["h"]).abs().max()) <= 1e-4
+
+
+def test_cost_volume_backward_scatter_is_reproducible_to_round_off(ops, dev):
+    """SURVEY section 5 / VERDICT r2: the measurement-feature gradient is an LDS-privatised scatter (ds_add_f32 into the staged box,
+    one global atomic per box element at the flush), so the ORDER of the float additions varies from run to run.  At the training
+    feature size (128x128, 32 channels, 64 planes) repeated runs must agree to float32 round-off of those sums -- stated bound
+    1e-5 of the gradient's largest entry -- and the reference-feature gradient (a gather, no atomics) bit for bit."""
+    g = torch.Generator().manual_seed(77)
+    f1 = torch.randn(2, 32, 128, 128, generator=g).to(dev)
+    f2 = torch.randn(2, 32, 128, 128, generator=g).to(dev)
+    go = torch.randn(2, 64, 128, 128, generator=g).to(dev)
+    K = torch.cat([syn.scaled_K(syn.full_K(width=256, height=256), 2.0)] * 2)
+    p1, p2 = torch.cat([syn.pose(10), syn.pose(202)]), torch.cat([syn.pose(9), syn.pose(196)])     # an easy pair and a spilling one
+    runs = []
+    for _ in range(4):
+        a, b = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+        hipcall.cost_volume(ops, a, [b], p1, [p2], K, 0.25, 20.0, 64, True, 0).backward(go)
+        runs.append((a.grad.clone(), b.grad.clone()))
+    scale = runs[0][1].abs().max().item()
+    worst = 0.0
+    for ga, gb in runs[1:]:
+        assert torch.equal(ga, runs[0][0])                                   # gather: no atomics
+        worst = max(worst, (gb - runs[0][1]).abs().max().item())
+    print(f"measurement-feature gradient, run-to-run max |diff| {worst:.3e} of max |g| {scale:.3e} = {worst / scale:.2e}")
+    assert worst <= 1e-5 * scale
