@@ -116,7 +116,7 @@ extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* im
                                      float* workspace, size_t workspace_bytes, dvmvs_stream_t stream) {
   using namespace dvmvs;
   if (image2_layout != DVMVS_LAYOUT_NCHW && image2_layout != DVMVS_LAYOUT_NHWC) return DVMVS_EINVAL;
-  if (variant < 0 || (variant > 2 && variant < 32) || variant > 127) return DVMVS_EINVAL;
+  if (variant < 0 || (variant > 2 && variant < 32) || variant > 255) return DVMVS_EINVAL;
   if (variant == 2 && !dot_product) return DVMVS_EUNSUPPORTED;
   CostVolumeArgs a;
   const int rc = fill_sweep_args(&a, image1, image2s, Hm, kt, cost_volume, B, M, C, H, W, D, min_depth, max_depth, true);

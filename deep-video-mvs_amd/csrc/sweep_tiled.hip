@@ -394,14 +394,15 @@ __device__ unsigned long long g_sweep_trace[kTraceGroups * kTraceWords];
 // part of a workgroup's dependency chain (eight passes of ~2 us each at 256 threads) -- is then spread over twice as many waves,
 // and a thread carries half the per-plane state (<= 128 registers: 4 waves / SIMD, two 8-wave workgroups per CU).
 template <int TW_, int TH_, int DP_, int CCH_, int CAP_, int MINSEG_, int WAVES_ = 3, int ORDER_ = 2, int PRE_ = 2, bool PLAN0_ = true,
-          bool FASTFULL_ = true, int PSPLIT_ = 1, bool LEAN_ = false>
+          bool FASTFULL_ = false, int PSPLIT_ = 1, bool LEAN_ = false>
 struct SweepConfig {
   static constexpr int TW = TW_, TH = TH_, DP = DP_, CCH = CCH_, CAP = CAP_, MINSEG = MINSEG_;
   static constexpr int WAVES = WAVES_;   // waves per SIMD the register allocation is held to
   static constexpr int ORDER = ORDER_;    // workgroup numbering, see decode_work
   static constexpr int PRE = PRE_;       // prefetched staging pieces per thread (NCHW; x2 for channels-last quads), 0 = none
   static constexpr bool PLAN0 = PLAN0_;  // the run plan is made by wave 0 only (the other waves wait at the barrier)
-  static constexpr bool FASTFULL = FASTFULL_;   // straight-line tap block for runs that cover the whole chunk
+  static constexpr bool FASTFULL = FASTFULL_;   // extra straight-line tap block for runs that cover the whole chunk (measured: 14 more
+                                                // registers, 0.5 us slower on the mean: off)
   static constexpr int PSPLIT = PSPLIT_;
   static constexpr bool LEAN = LEAN_;    // register diet for 5 waves / SIMD: quads tapped one after the other, reference features loaded per pass
   static constexpr int NPIX = TW * TH;                                 // pixels of a tile = threads of one plane group
@@ -479,17 +480,21 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
   const int d_block = work.chunk * DP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int planes = min(DP, a.D - d_block);
-  SWEEP_TRACE(unsigned long long tr_stage = 0, tr_taps = 0, tr_passes = 0, tr_records = 0, tr_switch = 0;)
+  SWEEP_TRACE(unsigned long long tr_stage = 0, tr_taps = 0, tr_passes = 0, tr_records = 0, tr_switch = 0, tr_setup = 0;)
   SWEEP_TRACE(const unsigned long long tr_start = __builtin_amdgcn_s_memtime(); const unsigned long long tr_real0 = __builtin_amdgcn_s_memrealtime();)
 
-  // ---- per-workgroup tables: the caller's Hm = K R K^-1 and K t per measurement frame, K t / depth per plane (utils.py:66-68) ----
-  {
+  // ---- per-workgroup tables (the caller's Hm = K R K^-1 and K t per measurement frame, K t / depth per plane: utils.py:66-68) and
+  // the run plan.  With PLAN0 both are wave 0's job -- an in-order wave reads back its own LDS writes without a barrier -- and
+  // the other waves go straight to the one barrier below ----
+  const SweepScale sc = sweep_scale(a.W, a.H);
+  if (!Cfg::PLAN0 || tid < 64) {
+    const int first = Cfg::PLAN0 ? lane : tid, stride = Cfg::PLAN0 ? 64 : NT;
     gcfloat_p Hm_g = as_global(a.Hm) + static_cast<size_t>(b) * a.M * 9;
     gcfloat_p kt_g = as_global(a.kt) + static_cast<size_t>(b) * a.M * 3;
-    for (int i = tid; i < a.M * 9; i += NT) s_H[i] = Hm_g[i];
+    for (int i = first; i < a.M * 9; i += stride) s_H[i] = Hm_g[i];
     if (GATHER)
-      for (int i = tid; i < a.M * 3; i += NT) s_kt[i] = kt_g[i];
-    for (int i = tid; i < a.M * DP; i += NT) {
+      for (int i = first; i < a.M * 3; i += stride) s_kt[i] = kt_g[i];
+    for (int i = first; i < a.M * DP; i += stride) {
       const int m = i / DP, j = i - m * DP;
       float4v k = {0.0f, 0.0f, 0.0f, 0.0f};
       if (j < planes) {
@@ -500,13 +505,8 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
       }
       s_ktd[i] = k;
     }
-  }
-  __syncthreads();
-  SWEEP_TRACE(const unsigned long long tr_setup = __builtin_amdgcn_s_memtime();)
-
-  const SweepScale sc = sweep_scale(a.W, a.H);
-  // ---- run plan (wave 0; with PLAN0 == false every wave evaluates it and wave 0's copy is the one written) ----
-  if (!Cfg::PLAN0 || tid < 64) {   // (all waves: identical values, benign identical writes)
+    if (!Cfg::PLAN0) __syncthreads();   // (every wave plans: identical values, benign identical writes)
+    SWEEP_TRACE(tr_setup = __builtin_amdgcn_s_memtime();)
     const int n = plan_runs<TW, TH, DP, CAP, Cfg::MINSEG>(a, s_H, s_ktd, tile_x, tile_y, planes, sc, lane, s_runs);
     if (tid == 0) s_n_runs = n;
   }
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
 // frames whose queued run contains this plane with plain read-modify-writes.  A (pixel, plane) output has exactly one
 // writer that applies its contributions in a fixed order, so the volume does not depend on scheduling, while the critical
 // path of a unit is at most M single-plane gathers.
-template <class Cfg, bool NHWC>
+template <class Cfg, bool NHWC, int KCH = 8>
 __global__ __launch_bounds__(Cfg::NPIX) void sweep_spill_kernel(CostVolumeArgs a) {
   constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP;
   const guint_p spill = as_global(a.spill);
@@ -858,8 +858,8 @@ __global__ __launch_bounds__(Cfg::NPIX) void sweep_spill_kernel(CostVolumeArgs a
 #pragma unroll
       for (int k = 0; k < 9; ++k) Hm[k] = Hm_g[k];
       const SweepRay ray = sweep_ray(Hm, xf, yf);
-      const float part = gather_plane<NHWC>(a, as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW, ref, HW, ray,
-                                            kt_g[0] / depth, kt_g[1] / depth, kt_g[2] / depth, sc);
+      const float part = gather_plane<NHWC, KCH>(a, as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW, ref, HW, ray,
+                                                 kt_g[0] / depth, kt_g[1] / depth, kt_g[2] / depth, sc);
       if (!touched) value = *out;
       touched = true;
       value += (part / static_cast<float>(a.C)) / static_cast<float>(a.M);   // same scaling order as the first pass
@@ -881,6 +881,7 @@ __global__ __launch_bounds__(Cfg::NPIX) void sweep_spill_kernel(CostVolumeArgs a
 // ---- launch ------------------------------------------------------------------------------------------------------------
 constexpr int kMaxDevices = 64;
 constexpr int kSpillGrid = 256;   // second-pass workgroups (grid-stride over the queued units; an empty pass should cost little)
+constexpr int kSpillChannels = 8;  // channels x 4 taps of one sample in flight per thread in the second pass
 
 template <class Kernel>
 int raise_dynamic_lds_limit(Kernel kernel, size_t bytes, bool* configured) {
@@ -897,7 +898,7 @@ int raise_dynamic_lds_limit(Kernel kernel, size_t bytes, bool* configured) {
 }
 
 template <class Cfg, bool NHWC>
-int launch_sweep_tiled_layout(const CostVolumeArgs& a, hipStream_t stream, int spill_grid = kSpillGrid) {
+int launch_sweep_tiled_layout(const CostVolumeArgs& a, hipStream_t stream, int spill_grid = kSpillGrid, int spill_kch = kSpillChannels) {
   const long long tiles = static_cast<long long>((a.W + Cfg::TW - 1) / Cfg::TW) * ((a.H + Cfg::TH - 1) / Cfg::TH);
   const long long total = tiles * ((a.D + Cfg::DP - 1) / Cfg::DP) * a.B;
   if (total > (1LL << 30)) return DVMVS_EUNSUPPORTED;
@@ -917,13 +918,16 @@ int launch_sweep_tiled_layout(const CostVolumeArgs& a, hipStream_t stream, int s
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(Cfg::NT), Cfg::kLdsBytes, stream, a);
   const int rc2 = launch_status();
   if (rc2 != 0) return rc2;
-  hipLaunchKernelGGL((sweep_spill_kernel<Cfg, NHWC>), dim3(spill_grid), dim3(Cfg::NPIX), 0, stream, a);
+  if (spill_kch >= 32) hipLaunchKernelGGL((sweep_spill_kernel<Cfg, NHWC, 32>), dim3(spill_grid), dim3(Cfg::NPIX), 0, stream, a);
+  else if (spill_kch >= 16) hipLaunchKernelGGL((sweep_spill_kernel<Cfg, NHWC, 16>), dim3(spill_grid), dim3(Cfg::NPIX), 0, stream, a);
+  else hipLaunchKernelGGL((sweep_spill_kernel<Cfg, NHWC, 8>), dim3(spill_grid), dim3(Cfg::NPIX), 0, stream, a);
   return launch_status();
 }
 
 template <class Cfg>
-int launch_sweep_tiled(const CostVolumeArgs& a, hipStream_t stream, int spill_grid = kSpillGrid) {
-  return a.image2_nhwc ? launch_sweep_tiled_layout<Cfg, true>(a, stream, spill_grid) : launch_sweep_tiled_layout<Cfg, false>(a, stream, spill_grid);
+int launch_sweep_tiled(const CostVolumeArgs& a, hipStream_t stream, int spill_grid = kSpillGrid, int spill_kch = kSpillChannels) {
+  return a.image2_nhwc ? launch_sweep_tiled_layout<Cfg, true>(a, stream, spill_grid, spill_kch)
+                       : launch_sweep_tiled_layout<Cfg, false>(a, stream, spill_grid, spill_kch);
 }
 
 // the shipped configuration; the spill workspace is sized for it
@@ -948,14 +952,16 @@ int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream) { return l
 // tuning configurations for tools/cv_microbench.py: <TW, TH, DP, CCH, CAP, MINSEG, WAVES, ORDER, PRE, PLAN0, FASTFULL>.  All use the 32x8x8
 // tiling the spill workspace is sized for.
 int launch_sweep_tuning(int which_and_grid, const CostVolumeArgs& a, hipStream_t stream) {
-  const int which = which_and_grid & 15, g = kSpillGrid << ((which_and_grid >> 4) & 3);   // + 16: second-pass grid x 2
+  const int which = which_and_grid & 15, g0 = kSpillGrid << ((which_and_grid >> 4) & 3);   // + 16 / 32 / 48: second-pass grid x 2 / 4 / 8
+  const int kch = 8 << ((which_and_grid >> 6) & 3);                                         // + 64 / 128: 16 / 32 channels in flight there
+#define g g0, kch
   switch (which) {
-    case 0: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 2, 2, true, true>>(a, stream, g);    // the shipped configuration
+    case 0: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 2, 2, true, false>>(a, stream, g);   // the shipped configuration
     case 1: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 1, 2, true, true>>(a, stream, g);    // round 2's tile-major numbering
     case 2: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 3, 2, true, true>>(a, stream, g);    // rotated chunks
     case 3: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 2, 3, true, true>>(a, stream, g);    // three pieces prefetched
     case 4: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 2, 0, true, true>>(a, stream, g);    // no prefetch
-    case 5: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 2, 2, true, false>>(a, stream, g);   // per-plane branches only
+    case 5: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 2, 2, true, true>>(a, stream, g);    // with the straight-line full-chunk tap block
     case 6: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 2, 2, 4, true, true>>(a, stream, g);    // 2 waves / SIMD of registers, whole pass prefetched
     case 7: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1280, 2, 2, 2, 3, true, true>>(a, stream, g);    // 60 KB: 2 / CU
     case 8: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 3, 0, 2, true, true>>(a, stream, g);    // linear numbering (no XCD awareness)
@@ -965,10 +971,11 @@ int launch_sweep_tuning(int which_and_grid, const CostVolumeArgs& a, hipStream_t
     case 12: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1024, 2, 6, 2, 1, true, true, 2>>(a, stream, g);  // ... 3 / CU (<= 80 registers)
     case 13: return launch_sweep_tiled<SweepConfig<32, 8, 8, 8, 1280, 2, 4, 2, 2, true, true, 2>>(a, stream, g);  // ... 60 KB boxes
     // 32x4-pixel tiles, planes split over two 128-thread groups: 1280 workgroups of 4 waves, five per CU, all resident
-    case 14: return launch_sweep_tiled<SweepConfig<32, 4, 8, 8, 640, 2, 5, 2, 1, true, true, 2, true>>(a, stream, g);
-    case 15: return launch_sweep_tiled<SweepConfig<32, 4, 8, 8, 640, 2, 5, 2, 1, true, false, 2, true>>(a, stream, g);
+    case 14: return launch_sweep_tiled<SweepConfig<32, 4, 8, 8, 576, 2, 5, 2, 1, true, true, 2, true>>(a, stream, g);   // 27 KB + tables: five fit in 160 KB
+    case 15: return launch_sweep_tiled<SweepConfig<32, 4, 8, 8, 576, 2, 5, 2, 1, true, false, 2, true>>(a, stream, g);
     default: return DVMVS_EINVAL;
   }
+#undef g
 }
 #else
 int launch_sweep_tuning(int, const CostVolumeArgs&, hipStream_t) { return DVMVS_EINVAL; }
