@@ -507,12 +507,15 @@ def main():
         # exactly the kernel sources that are being benchmarked, otherwise null (profiles/README.md says how to re-collect)
         traffic, traffic_source = None, None
         try:
+            import glob
             import hashlib
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_cost_volume_pmc.json")))
             digest = hashlib.sha256(b"".join(open(os.path.join(ROOT, "deep-video-mvs_amd", "csrc", f), "rb").read()
                                              for f in ("sweep_tiled.hip", "cost_volume.hip", "plane_sweep.h"))).hexdigest()
-            if pmc.get("shape") == [1, M, 32, 128, 160, 64] and pmc.get("kernel_sources_sha256") == digest:
-                traffic, traffic_source = pmc["hbm_bytes_per_launch"], "profiles/r02_cost_volume_pmc.json"
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cost_volume_pmc.json")), reverse=True):
+                pmc = json.load(open(path))
+                if pmc.get("shape") == [1, M, 32, 128, 160, 64] and pmc.get("kernel_sources_sha256") == digest:
+                    traffic, traffic_source = pmc["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+                    break
         except (OSError, ValueError, KeyError):
             pass
         # useful arithmetic of the op: per (pixel, plane, frame) 4 taps x C channels of FMA + 4 weight FMAs, 2 flop each

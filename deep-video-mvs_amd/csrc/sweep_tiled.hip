@@ -880,7 +880,8 @@ __global__ __launch_bounds__(Cfg::NPIX) void sweep_spill_kernel(CostVolumeArgs a
 
 // ---- launch ------------------------------------------------------------------------------------------------------------
 constexpr int kMaxDevices = 64;
-constexpr int kSpillGrid = 256;   // second-pass workgroups (grid-stride over the queued units; an empty pass should cost little)
+constexpr int kSpillGrid = 1024;  // second-pass workgroups, grid-stride over the queued units: four per CU hide the gather's latency (one per
+                                  // CU: +10-15 us on the geometries that spill); an empty pass costs ~3 us either way
 constexpr int kSpillChannels = 8;  // channels x 4 taps of one sample in flight per thread in the second pass
 
 template <class Kernel>
@@ -952,7 +953,7 @@ int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream) { return l
 // tuning configurations for tools/cv_microbench.py: <TW, TH, DP, CCH, CAP, MINSEG, WAVES, ORDER, PRE, PLAN0, FASTFULL>.  All use the 32x8x8
 // tiling the spill workspace is sized for.
 int launch_sweep_tuning(int which_and_grid, const CostVolumeArgs& a, hipStream_t stream) {
-  const int which = which_and_grid & 15, g0 = kSpillGrid << ((which_and_grid >> 4) & 3);   // + 16 / 32 / 48: second-pass grid x 2 / 4 / 8
+  const int which = which_and_grid & 15, g0 = 256 << ((which_and_grid >> 4) & 3);   // + 16 / 32 / 48: second-pass grid of 512 / 1024 / 2048 (else 256)
   const int kch = 8 << ((which_and_grid >> 6) & 3);                                         // + 64 / 128: 16 / 32 channels in flight there
 #define g g0, kch
   switch (which) {

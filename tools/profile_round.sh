@@ -4,7 +4,7 @@
 #  2. rocprofv3 --pmc passes (SQ mix, LDS conflicts, FETCH_SIZE, WRITE_SIZE -- each counter group in its own run, never mixed
 #     with tracing) of the sweep + spill kernels on three keyframe geometries: easy (153), median (118), worst (165)
 # Copy what should be judged from <out> into profiles/ afterwards (tools/collect_profiles.py does that).
-out="${1:-gpurun_out/prof_r02}"
+out="${1:-gpurun_out/prof_r03}"
 mkdir -p "$out"
 export TMPDIR=/tmp
 root="$(pwd)"
