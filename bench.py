@@ -524,8 +524,15 @@ def main():
         lds_bytes = 128 * 160 * 64 * M * 4 * 32 * 4
         other_kernels = None if args.no_roofline_leg else measure_small_kernels(engine)
         launches_per_frame = None
-        try:     # kernel nodes of the captured frame graph (what one replay launches)
+        try:     # kernel nodes of the captured frame graph (what one replay launches); None where the runtime cannot dump a graph
             launches_per_frame = {f"n_meas={k[0]},has_previous={k[1]}": count_graph_kernels(g) for k, g in engine._graphs.items()}
+        except Exception:
+            pass
+        try:     # ... and the count a rocprofv3 kernel trace of this command's timed region recorded (profiles/, per round)
+            import glob
+            region = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_timed_region.csv")))[-1]
+            last = open(region).read().strip().splitlines()[-1].split(",")
+            launches_per_frame = dict(launches_per_frame or {}, profiled=float(last[5]) / float(last[7]), profiled_source=os.path.relpath(region, ROOT))
         except Exception:
             pass
         rel = golden_rel_l1(modules, device, args) if not args.no_rel_l1 else None
