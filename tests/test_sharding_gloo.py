@@ -109,3 +109,40 @@ def test_two_rank_sharded_scene_runner(tmp_path):
     assert resets0 == 2 and resets1 == 1                                  # the TRACKING LOST lines
     assert [round(v, 2) for v in s0[0]] == [1.03, 1.05] and [round(v, 2) for v in s1[1]] == [2.03, 2.05, 2.07]
     assert res["frames"] == 7.0 and res["fps"] > 0
+
+
+def _more_ranks_than_scenes_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    sys.path.insert(0, os.path.join(root, "deep-video-mvs_amd"))
+    from dvmvs import runner
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    built = []
+
+    def make_engine():
+        built.append(_StubEngine(rank))
+        return built[-1]
+
+    results, (frames, seconds, fps) = runner.predict_sharded(make_engine, [os.path.join(out_dir, "scene0")], [os.path.join(out_dir, "index0")],
+                                                              evaluate=False)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (sorted(results), len(built), frames))
+    if rank == 0:
+        torch.save(gathered, os.path.join(out_dir, "few_scenes.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_without_a_scene_still_joins_the_reduction(tmp_path):
+    """more ranks than scenes (8 GPUs, 5 scenes).  The idle rank builds no engine; the throughput reduction must pick
+    its device from the BACKEND, not from the engine, or that rank hands RCCL a CPU tensor and the others block in all_reduce.
+    With gloo both are CPU tensors, so what this checks is that every rank reaches the collective and sees the job's totals."""
+    from test_runner import _write_scene
+    _write_scene(os.path.join(str(tmp_path), "scene0"), 8)
+    with open(os.path.join(str(tmp_path), "index0"), "w") as f:
+        f.write("00003.png 00002.png 00001.png\n00005.png 00003.png 00002.png\n")
+    mp.spawn(_more_ranks_than_scenes_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    (scenes0, built0, frames0), (scenes1, built1, frames1) = torch.load(os.path.join(str(tmp_path), "few_scenes.pt"), weights_only=False)
+    assert scenes0 == [0] and scenes1 == [] and built0 == 1 and built1 == 0
+    assert frames0 == frames1 == 2.0
