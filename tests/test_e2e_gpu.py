@@ -227,6 +227,28 @@ def test_fusionnet_long_reference_run(hip_device, golden_dir, fixture_host_algeb
     assert sum(r["on_reference_inputs"] for r in rows) >= 4
 
 
+def test_exact_pose_algebra_engine(hip_device, golden_dir):
+    """The opt-in "exact" mode (fp64 pose algebra on the device, inside the captured frame, no host involvement): runs through graphs,
+    and lands where round 2's engine did -- within the reference's own fp32-vs-float64 distance of the reference (frames 0 and 1 of the
+    golden run), i.e. as close to float64 as the reference is, not bit-close to the reference."""
+    z = np.load(os.path.join(golden_dir, "fusionnet_e2e.npz"))
+    dev = hip_device
+    mods, engine = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True, pose_algebra="exact")
+    assert engine.pose_algebra == "exact"
+    fullK = syn.full_K()
+    for sweep in range(2):       # second sweep: replayed graphs
+        engine.reset()
+        for n, (r, ms) in enumerate(syn.E2E_FRAMES[:2]):
+            depth = engine.step(syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK,
+                                frame_id=r, measurement_ids=list(ms))
+            d = depth[0, ::4, ::4].cpu().numpy().astype(np.float64)
+            ref32, ref64 = z[f"f{n}_depth_sub4"].astype(np.float64), z[f"f{n}_depth64_sub4"]
+            print(f"exact mode sweep {sweep} frame {n}: vs reference {rel_l1(d, ref32):.3e}, vs float64 {rel_l1(d, ref64):.3e} "
+                  f"(reference vs float64 {rel_l1(ref32, ref64):.3e})")
+            assert rel_l1(d, ref64) <= 1.5 * rel_l1(ref32, ref64) + 2e-5
+            assert rel_l1(d, ref32) <= 3e-4
+
+
 def test_pairnet_frame_matches_the_reference(hip_device, golden_dir, fixture_host_algebra):
     z = np.load(os.path.join(golden_dir, "pairnet_e2e.npz"))
     dev = hip_device
