@@ -75,17 +75,48 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_ref_kernel(CostVolumeBwdA
 // atomics per (pixel, plane, channel) into global memory -- 3.7 G device-scope atomics for one training step at
 // 4 x 7 x 256^2 -- which a multi-XCD part serialises at the memory side.  The scatter is therefore PRIVATISED in LDS with
 // the forward kernel's geometry: a workgroup owns a 32x8 reference tile and DP planes; all of its targets lie inside the
-// bounding box of 8 sample positions (see publish_sample_box), so it accumulates into a zero-initialised LDS image of that
+// bounding box of 8 sample positions (see publish_sample_box), and it accumulates into a zero-initialised LDS image of that
 // box with ds_add_f32 (record stride CCH+1 floats: consecutive box positions fall on different banks) and flushes each
-// box element once, coalesced, with a single global atomic.  Global atomics drop by the tile's reuse factor (~15x) and
-// the rest stay on chip.  Segments whose box does not fit scatter straight to global memory as before.
+// box element once, coalesced, with a single global atomic.
+//
+// A box of any size is handled on chip: the LDS image holds a WINDOW of whole box rows (CAP positions); the workgroup walks
+// the windows of its box top to bottom, and in each one a sample contributes the tap rows that fall into it (rows are
+// disjoint between windows, so the two rows of a sample may be accumulated in consecutive windows).  Windows nobody samples
+// (the box of eight planes of a wide-baseline pair is a diagonal band) are skipped with one vote.  Round 2 fell back to
+// global atomics whenever four planes of a tile did not fit 768 positions: on the training step's own geometry (frames three
+// apart on the sample scene) that was 10-50 % of the workgroups of a call, and their 128 scattered device-scope atomics per
+// (pixel, plane) were the kernel's time (2.64 ms per call, profiles/r03_train_timed_region.csv).  What still goes straight
+// to global memory: tiles whose box is not well defined (a corner at or behind the measurement camera) and single samples
+// that fall outside the box fitted to the corners (round-off beyond its 0.05 px slack) -- both rare.
 constexpr int kBwdPlaneGroups = 4;   // generic fallback geometry (also used when H*W is tiny)
 constexpr int kBwdPPT = 4;
+
+// One (pixel, plane) straight to global memory: 4 taps x C channels of device-scope atomics.
+__device__ inline void scatter_sample_global(const CostVolumeArgs& f, const float* Hm, const float* ktd, float xf, float yf, float gj,
+                                             const float* ref, float* gmeas, int HW) {
+  float ix, iy;
+  sweep_position(Hm, ktd, xf, yf, f.W, f.H, &ix, &iy);
+  const BilinearTaps t = make_taps(ix, iy, f.W, f.H);
+  const bool v0 = t.in_x0 && t.in_y0, v1 = t.in_x1 && t.in_y0, v2 = t.in_x0 && t.in_y1, v3 = t.in_x1 && t.in_y1;
+  if (!(v0 || v1 || v2 || v3)) return;
+  const int o0 = t.y0 * f.W + t.x0;
+  const float w0 = t.w_nw * gj, w1 = t.w_ne * gj, w2 = t.w_sw * gj, w3 = t.w_se * gj;
+  for (int c = 0; c < f.C; ++c) {
+    const float r = ref[static_cast<size_t>(c) * HW];
+    float* plane = gmeas + static_cast<size_t>(c) * HW;
+    if (v0) atomicAdd(plane + o0, r * w0);
+    if (v1) atomicAdd(plane + o0 + 1, r * w1);
+    if (v2) atomicAdd(plane + o0 + f.W, r * w2);
+    if (v3) atomicAdd(plane + o0 + f.W + 1, r * w3);
+  }
+}
 
 template <int TW, int TH, int DP, int CCH, int CAP>
 __global__ __launch_bounds__(TW* TH) void cost_volume_bwd_meas_tiled_kernel(CostVolumeBwdArgs a) {
   constexpr int NT = TW * TH;
   constexpr int REC = CCH + 1;
+  constexpr int RPT = (CAP + NT - 1) / NT;   // box positions a thread flushes
+  static_assert((CAP * REC) % 4 == 0, "the LDS image is cleared in 16-byte stores");
   extern __shared__ __attribute__((aligned(16))) float s_acc[];  // [CAP][REC]
   __shared__ float s_H[DVMVS_MAX_MEASUREMENTS * 9];
   __shared__ float s_kt[DVMVS_MAX_MEASUREMENTS * 3];
@@ -120,108 +151,129 @@ __global__ __launch_bounds__(TW* TH) void cost_volume_bwd_meas_tiled_kernel(Cost
     gmeas += static_cast<size_t>(b) * f.C * HW;
     const float* Hm = s_H + m * 9;
     const float* ktd_m = s_ktd + m * DP * 3;
-    int seg_lo = 0;
-    while (seg_lo < planes) {
-      int seg_len = planes - seg_lo;
-      int state;
-      int base[DP];
+    // box of all the planes of the chunk, no capacity test (state 1: well defined, 2: entirely outside the image, 0: not defined)
+    publish_sample_box<TW, TH, DP, (1 << 30)>(f, Hm, ktd_m, tile_x, tile_y, 0, planes - 1, tid, s_box);
+    const int x_lo = s_box[0], y_lo = s_box[1], RW = s_box[2], RH = s_box[3];
+    const int state = (s_box[4] == 1 && RW > CAP) ? 0 : s_box[4];
+    __syncthreads();                            // s_box is rewritten for the next frame
+
+    unsigned direct = 0;                        // planes of this pixel that go straight to global memory
+    if (state == 1) {
+      int pos[DP];                              // (box row << 16) | box column of the north-west tap
       float w[DP][4];
-      for (;;) {
-        publish_sample_box<TW, TH, DP, CAP>(f, Hm, ktd_m, tile_x, tile_y, seg_lo, seg_lo + seg_len - 1, tid, s_box);
-        state = s_box[4];
-        int violation = 0;
-        if (state == 1) {
-          const int x_lo = s_box[0], y_lo = s_box[1], RW = s_box[2], RH = s_box[3];
 #pragma unroll
-          for (int j = 0; j < DP; ++j) {
-            base[j] = 0;
-            w[j][0] = w[j][1] = w[j][2] = w[j][3] = 0.0f;
-            if (j >= seg_lo && j < seg_lo + seg_len && live) {
-              float ix, iy;
-              sweep_position(Hm, ktd_m + j * 3, xf, yf, f.W, f.H, &ix, &iy);
-              const BilinearTaps t = make_taps(ix, iy, f.W, f.H);
-              const bool dead = (t.x0 < -1) || (t.x0 > f.W - 1) || (t.y0 < -1) || (t.y0 > f.H - 1);
-              const int rx = t.x0 - x_lo, ry = t.y0 - y_lo;
-              const bool inside = (rx >= 0) && (rx + 1 < RW) && (ry >= 0) && (ry + 1 < RH);
-              if (!dead && !inside) violation = 1;
-              if (!dead && inside) {
-                base[j] = ry * RW + rx;
-                // taps outside the image land in the apron of the box and are dropped by the flush
-                w[j][0] = t.w_nw * gd[j]; w[j][1] = t.w_ne * gd[j]; w[j][2] = t.w_sw * gd[j]; w[j][3] = t.w_se * gd[j];
-              }
-            }
+      for (int j = 0; j < DP; ++j) {
+        pos[j] = 0;
+        w[j][0] = w[j][1] = w[j][2] = w[j][3] = 0.0f;
+        if (gd[j] != 0.0f) {                    // implies live && j < planes
+          float ix, iy;
+          sweep_position(Hm, ktd_m + j * 3, xf, yf, f.W, f.H, &ix, &iy);
+          const BilinearTaps t = make_taps(ix, iy, f.W, f.H);
+          const bool dead = (t.x0 < -1) || (t.x0 > f.W - 1) || (t.y0 < -1) || (t.y0 > f.H - 1);
+          const int rx = t.x0 - x_lo, ry = t.y0 - y_lo;
+          const bool inside = (rx >= 0) && (rx + 1 < RW) && (ry >= 0) && (ry + 1 < RH);
+          if (!dead && inside) {
+            pos[j] = (ry << 16) | rx;
+            // taps outside the image land in the apron of the box and are dropped by the flush
+            w[j][0] = t.w_nw * gd[j]; w[j][1] = t.w_ne * gd[j]; w[j][2] = t.w_sw * gd[j]; w[j][3] = t.w_se * gd[j];
+          } else if (!dead) {
+            direct |= 1u << j;
           }
         }
-        if (__syncthreads_or(violation)) state = 0;
-        if (state != 0 || seg_len <= 4) break;
-        seg_len = max((seg_len + 1) / 2, 4);
       }
-      const int seg_hi = seg_lo + seg_len;
 
-      if (state == 1) {
-        const int x_lo = s_box[0], y_lo = s_box[1], RW = s_box[2], RH = s_box[3];
-        const int RS = RW * RH;
+      const int WH = min(RH, CAP / RW);         // rows per window (>= 1: RW <= CAP)
+      for (int wy0 = 0; wy0 < RH; wy0 += WH) {
+        const int rows = min(WH, RH - wy0);
+        // anything of this pixel in rows [wy0, wy0 + rows)?
+        bool mine = false;
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+          const int ry = (pos[j] >> 16) - wy0;
+          const bool any = (w[j][0] != 0.0f) || (w[j][1] != 0.0f) || (w[j][2] != 0.0f) || (w[j][3] != 0.0f);
+          mine |= any && (ry + 1 >= 0) && (ry < rows);
+        }
+        if (!__syncthreads_or(mine ? 1 : 0)) continue;   // also orders the previous window's flush before this one's clear
+
+        const int RS = rows * RW;
+        int goff[RPT];                          // image offset of the box positions this thread flushes (-1: none / apron)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          const int r = tid + k * NT;
+          const int ry = r / RW, rx = r - ry * RW;
+          const int gx = x_lo + rx, gy = y_lo + wy0 + ry;
+          goff[k] = (r < RS && gx >= 0 && gx < f.W && gy >= 0 && gy < f.H) ? gy * f.W + gx : -1;
+        }
         for (int c0 = 0; c0 < f.C; c0 += CCH) {
           const int nch = min(CCH, f.C - c0);
-          for (int i = tid; i < RS * REC; i += NT) s_acc[i] = 0.0f;
+          {
+            float4* z = reinterpret_cast<float4*>(s_acc);
+            const int n4 = (RS * REC + 3) >> 2;
+            for (int i = tid; i < n4; i += NT) z[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          }
           float rv[CCH];
 #pragma unroll
-          for (int c = 0; c < CCH; ++c) rv[c] = (live && c < nch) ? ref[static_cast<size_t>(c0 + c) * HW] : 0.0f;
+          for (int c = 0; c < CCH; ++c) rv[c] = (mine && c < nch) ? ref[static_cast<size_t>(c0 + c) * HW] : 0.0f;
           __syncthreads();
-          if (live) {
+          if (mine) {
 #pragma unroll
             for (int j = 0; j < DP; ++j) {
-              if (j >= seg_lo && j < seg_hi && (w[j][0] != 0.0f || w[j][1] != 0.0f || w[j][2] != 0.0f || w[j][3] != 0.0f)) {
-                float* r0 = s_acc + base[j] * REC;
-                float* r1 = r0 + RW * REC;
+              const int ry = (pos[j] >> 16) - wy0, rx = pos[j] & 0xffff;
+              const bool any = (w[j][0] != 0.0f) || (w[j][1] != 0.0f) || (w[j][2] != 0.0f) || (w[j][3] != 0.0f);
+              if (any && (ry + 1 >= 0) && (ry < rows)) {
+                float* r0 = s_acc + (ry * RW + rx) * REC;
+                if (ry >= 0) {
 #pragma unroll
-                for (int c = 0; c < CCH; ++c) {
-                  atomicAdd(r0 + c, rv[c] * w[j][0]);
-                  atomicAdd(r0 + REC + c, rv[c] * w[j][1]);
-                  atomicAdd(r1 + c, rv[c] * w[j][2]);
-                  atomicAdd(r1 + REC + c, rv[c] * w[j][3]);
+                  for (int c = 0; c < CCH; ++c) {
+                    atomicAdd(r0 + c, rv[c] * w[j][0]);
+                    atomicAdd(r0 + REC + c, rv[c] * w[j][1]);
+                  }
+                }
+                if (ry + 1 < rows) {
+                  float* r1 = r0 + RW * REC;
+#pragma unroll
+                  for (int c = 0; c < CCH; ++c) {
+                    atomicAdd(r1 + c, rv[c] * w[j][2]);
+                    atomicAdd(r1 + REC + c, rv[c] * w[j][3]);
+                  }
                 }
               }
             }
           }
           __syncthreads();
-          // flush: channel-major so that consecutive threads hit consecutive x of one channel plane
-          for (int i = tid; i < RS * nch; i += NT) {
-            const int c = i / RS, r = i - c * RS;
-            const int ry = r / RW, rx = r - ry * RW;
-            const int gx = x_lo + rx, gy = y_lo + ry;
-            const float v = s_acc[r * REC + c];
-            if (v != 0.0f && gx >= 0 && gx < f.W && gy >= 0 && gy < f.H)
-              atomicAdd(gmeas + static_cast<size_t>(c0 + c) * HW + gy * f.W + gx, v);
+          // flush: for one channel a wave's lanes hit consecutive x of one gradient plane; LDS reads are REC words apart (odd)
+#pragma unroll
+          for (int k = 0; k < RPT; ++k) {
+            if (goff[k] >= 0) {
+              const float* rec = s_acc + (tid + k * NT) * REC;
+              float* dst = gmeas + static_cast<size_t>(c0) * HW + goff[k];
+#pragma unroll
+              for (int c = 0; c < CCH; ++c) {
+                if (c < nch) {
+                  const float v = rec[c];
+                  if (v != 0.0f) atomicAdd(dst + static_cast<size_t>(c) * HW, v);
+                }
+              }
+            }
           }
           __syncthreads();
         }
-      } else if (state == 0 && live) {
-        // box does not fit: scatter straight to global memory
-        for (int j = seg_lo; j < seg_hi; ++j) {
-          float gj = 0.0f;
-#pragma unroll
-          for (int jj = 0; jj < DP; ++jj)
-            if (jj == j) gj = gd[jj];
-          if (gj == 0.0f) continue;
-          float ix, iy;
-          sweep_position(Hm, ktd_m + j * 3, xf, yf, f.W, f.H, &ix, &iy);
-          const BilinearTaps t = make_taps(ix, iy, f.W, f.H);
-          const bool v0 = t.in_x0 && t.in_y0, v1 = t.in_x1 && t.in_y0, v2 = t.in_x0 && t.in_y1, v3 = t.in_x1 && t.in_y1;
-          if (!(v0 || v1 || v2 || v3)) continue;
-          const int o0 = t.y0 * f.W + t.x0;
-          const float w0 = t.w_nw * gj, w1 = t.w_ne * gj, w2 = t.w_sw * gj, w3 = t.w_se * gj;
-          for (int c = 0; c < f.C; ++c) {
-            const float r = ref[static_cast<size_t>(c) * HW];
-            float* plane = gmeas + static_cast<size_t>(c) * HW;
-            if (v0) atomicAdd(plane + o0, r * w0);
-            if (v1) atomicAdd(plane + o0 + 1, r * w1);
-            if (v2) atomicAdd(plane + o0 + f.W, r * w2);
-            if (v3) atomicAdd(plane + o0 + f.W + 1, r * w3);
-          }
-        }
       }
-      seg_lo = seg_hi;
+    } else if (state == 0) {
+#pragma unroll
+      for (int j = 0; j < DP; ++j)
+        if (gd[j] != 0.0f) direct |= 1u << j;
+    }
+
+    // the rare samples that have no place in the box
+    while (direct) {
+      const int j = __ffs(direct) - 1;
+      direct &= direct - 1;
+      float gj = 0.0f;
+#pragma unroll
+      for (int jj = 0; jj < DP; ++jj)
+        if (jj == j) gj = gd[jj];
+      scatter_sample_global(f, Hm, ktd_m + j * 3, xf, yf, gj, ref, gmeas, HW);
     }
   }
 }
@@ -275,7 +327,37 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_meas_kernel(CostVolumeBwd
   }
 }
 
+// Launch of the LDS-privatised scatter: 32x8-pixel tiles x 8 planes per workgroup, CCH channels per pass, CAP box positions in LDS.
+template <int CCH, int CAP>
+static int launch_bwd_meas_tiled(const CostVolumeBwdArgs& a, int B, int H, int W, int D, hipStream_t s) {
+  constexpr int TW = 32, TH = 8, DP = 8;
+  constexpr size_t kLds = sizeof(float) * CAP * (CCH + 1);
+  auto kernel = cost_volume_bwd_meas_tiled_kernel<TW, TH, DP, CCH, CAP>;
+  // the dynamic-LDS limit is a per-device function attribute; setting it is idempotent, racing threads write the same value
+  static bool configured[64] = {};
+  int device = 0;
+  DVMVS_RETURN_IF_HIP(hipGetDevice(&device));
+  const bool tracked = device >= 0 && device < 64;
+  if (!tracked || !configured[device]) {
+    DVMVS_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            static_cast<int>(kLds)));
+    if (tracked) configured[device] = true;
+  }
+  dim3 block(TW * TH), grid(((W + TW - 1) / TW) * ((H + TH - 1) / TH), (D + DP - 1) / DP, B);
+  hipLaunchKernelGGL(kernel, grid, block, kLds, s, a);
+  return launch_status();
+}
+
+#ifdef DVMVS_SWEEP_TUNING
+static int g_bwd_tuning_config = 0;
+#endif
+
 }  // namespace dvmvs
+
+#ifdef DVMVS_SWEEP_TUNING
+// tools-only library (make tuning): which instantiation dvmvs_cost_volume_bwd launches (tools/cv_bwd_microbench.py)
+extern "C" void dvmvs_tuning_set_bwd_config(int config) { dvmvs::g_bwd_tuning_config = config; }
+#endif
 
 extern "C" int dvmvs_cost_volume_bwd(const float* grad_cost, const float* image1, const float* const* image2s,
                                      const float* Hm, const float* kt, float* grad_image1, float* const* grad_image2s,
@@ -304,22 +386,24 @@ extern "C" int dvmvs_cost_volume_bwd(const float* grad_cost, const float* image1
     if (rc != 0) return rc;
   }
   if (any_meas && HW >= 64 * 64) {
-    constexpr int TW = 32, TH = 8, DP = 8, CCH = 16, CAP = 768;
-    constexpr size_t kLds = sizeof(float) * CAP * (CCH + 1);   // 51 KB
-    auto kernel = cost_volume_bwd_meas_tiled_kernel<TW, TH, DP, CCH, CAP>;
-    // the dynamic-LDS limit is a per-device function attribute; setting it is idempotent, racing threads write the same value
-    static bool configured[64] = {};
-    int device = 0;
-    DVMVS_RETURN_IF_HIP(hipGetDevice(&device));
-    const bool tracked = device >= 0 && device < 64;
-    if (!tracked || !configured[device]) {
-      DVMVS_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              static_cast<int>(kLds)));
-      if (tracked) configured[device] = true;
+#ifdef DVMVS_SWEEP_TUNING
+    switch (g_bwd_tuning_config) {
+      case 1: rc = launch_bwd_meas_tiled<8, 1536>(a, B, H, W, D, s); break;    // 4 channel passes, 54 KB
+      case 2: rc = launch_bwd_meas_tiled<32, 384>(a, B, H, W, D, s); break;    // 1 channel pass, 50 KB
+      case 3: rc = launch_bwd_meas_tiled<16, 1152>(a, B, H, W, D, s); break;   // 77 KB: two workgroups per CU
+      case 4: rc = launch_bwd_meas_tiled<16, 576>(a, B, H, W, D, s); break;    // 38 KB: four workgroups per CU
+      case 9: {                                                                 // the global-atomic scatter (cross-check)
+        constexpr int kPlanesPerBlock = kBwdPlaneGroups * kBwdPPT;
+        dim3 block(kWave, kBwdPlaneGroups), grid((HW + kWave - 1) / kWave, (D + kPlanesPerBlock - 1) / kPlanesPerBlock, B);
+        hipLaunchKernelGGL(cost_volume_bwd_meas_kernel, grid, block, 0, s, a);
+        rc = launch_status();
+        break;
+      }
+      default: rc = launch_bwd_meas_tiled<16, 768>(a, B, H, W, D, s); break;
     }
-    dim3 block(TW * TH), grid(((W + TW - 1) / TW) * ((H + TH - 1) / TH), (D + DP - 1) / DP, B);
-    hipLaunchKernelGGL(kernel, grid, block, kLds, s, a);
-    rc = launch_status();
+#else
+    rc = launch_bwd_meas_tiled<16, 768>(a, B, H, W, D, s);   // 51 KB: three workgroups per CU
+#endif
   } else if (any_meas) {
     constexpr int kPlanesPerBlock = kBwdPlaneGroups * kBwdPPT;
     dim3 block(kWave, kBwdPlaneGroups), grid((HW + kWave - 1) / kWave, (D + kPlanesPerBlock - 1) / kPlanesPerBlock, B);

@@ -75,8 +75,11 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const float* x, float* ds
 //   src = dst * (in - 1) / (out - 1);  i0 = int(src);  l1 = src - i0;  l0 = 1 - l1
 //   out = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11)
 // Batch item b of the destination starts at out + b * out_batch_stride (a channel slice of a concatenation buffer), its C planes are dense.
+// PRE: the input is a raw convolution output and act(in + pre_bias[c]) is applied to each of the four taps on the fly (the decoder's
+// coarse depth heads: convolution -> bias + sigmoid -> x2 up-sampling into the next block's input, one launch instead of two).
+template <int PRE>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, long long out_batch_stride,
-                                                         int planes, int C, int H, int W) {
+                                                         const float* __restrict__ pre_bias, int planes, int C, int H, int W) {
   // No FMA contraction: the fractional weight must come from the ROUNDED product sh * oy, the same value whose integer part
   // selects the tap (ATen does exactly that); fma(sh, oy, -y0) would mix a rounded index with an unrounded fraction.
 #pragma clang fp contract(off)
@@ -96,8 +99,10 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
     const float w1 = fx - static_cast<float>(x0), w0 = 1.0f - w1;
     const float* p = in + pl * H * W;
     const long long b = pl / C, c = pl - b * C;
-    out[b * out_batch_stride + (c * OH + oy) * OW + ox] =
-        h0 * (w0 * p[y0 * W + x0] + w1 * p[y0 * W + x1]) + h1 * (w0 * p[y1 * W + x0] + w1 * p[y1 * W + x1]);
+    const float bv = (PRE != 0 && pre_bias) ? pre_bias[c] : 0.0f;
+    const float v00 = PRE ? apply_act<PRE>(p[y0 * W + x0] + bv) : p[y0 * W + x0], v01 = PRE ? apply_act<PRE>(p[y0 * W + x1] + bv) : p[y0 * W + x1];
+    const float v10 = PRE ? apply_act<PRE>(p[y1 * W + x0] + bv) : p[y1 * W + x0], v11 = PRE ? apply_act<PRE>(p[y1 * W + x1] + bv) : p[y1 * W + x1];
+    out[b * out_batch_stride + (c * OH + oy) * OW + ox] = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11);
   }
 }
 
@@ -191,17 +196,21 @@ extern "C" int dvmvs_bias_act_inplace(float* x, const float* bias, const float* 
   return dvmvs_bias_act_fwd(x, x, static_cast<long long>(C) * H * W, bias, residual, residual_mode, B, C, H, W, activation, 0.0f, 0.0f, stream);
 }
 
-extern "C" int dvmvs_upsample2x_fwd(const float* in, float* out, long long out_batch_stride, int B, int C, int H, int W,
-                                    dvmvs_stream_t stream) {
+extern "C" int dvmvs_upsample2x_fwd(const float* in, float* out, long long out_batch_stride, const float* pre_bias, int pre_activation,
+                                    int B, int C, int H, int W, dvmvs_stream_t stream) {
   using namespace dvmvs;
   if (!in || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return DVMVS_EINVAL;
+  if (pre_activation < 0 || pre_activation > 2) return DVMVS_EINVAL;
   if (out_batch_stride == 0) out_batch_stride = static_cast<long long>(C) * H * W * 4;
   if (out_batch_stride < static_cast<long long>(C) * H * W * 4) return DVMVS_EINVAL;
   const long long total = static_cast<long long>(B) * C * H * W * 4;
   long long blocks = (total + 255) / 256;
   if (blocks > 256LL * 16) blocks = 256LL * 16;
-  hipLaunchKernelGGL(upsample2x_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
-                     out_batch_stride, B * C, C, H, W);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (pre_activation == 1) hipLaunchKernelGGL(upsample2x_kernel<1>, grid, block, 0, s, in, out, out_batch_stride, pre_bias, B * C, C, H, W);
+  else if (pre_activation == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, grid, block, 0, s, in, out, out_batch_stride, pre_bias, B * C, C, H, W);
+  else hipLaunchKernelGGL(upsample2x_kernel<0>, grid, block, 0, s, in, out, out_batch_stride, pre_bias, B * C, C, H, W);
   return launch_status();
 }
 

@@ -100,9 +100,10 @@ class FusedConv2d(nn.Module):
                           and tuple(conv.padding) == (k[0] // 2, k[0] // 2) and tuple(conv.dilation) == (1, 1)
                           and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2))
 
-    def forward(self, x, residual=None, residual_mode=0, out=None, activation=None, p0=0.0, p1=0.0):
+    def forward(self, x, residual=None, residual_mode=0, out=None, activation=None, p0=0.0, p1=0.0, raw=False):
         """``residual`` (mode 1: same shape, mode 2: half resolution, nearest-up-sampled) is added in the same epilogue; ``out``
-        is the destination (default: the convolution's own output buffer); ``activation`` overrides the layer's."""
+        is the destination (default: the convolution's own output buffer); ``activation`` overrides the layer's; ``raw`` returns
+        the convolution output without the epilogue (the consumer applies it: up-sampler, depthwise kernel)."""
         act = self.activation if activation is None else activation
         if self.depthwise and residual is None and out is None:
             pre = self.pre_bias
@@ -113,7 +114,7 @@ class FusedConv2d(nn.Module):
         y = nn.functional.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
         if not y.is_contiguous():
             y = y.contiguous()
-        if self.defer_epilogue:
+        if self.defer_epilogue or raw:
             return y
         return _ops.bias_act_into(y, y if out is None else out, self.bias, act, residual, residual_mode if residual is not None else 0, p0, p1)
 
@@ -396,14 +397,19 @@ class DepthEngine:
             top = fpn.inner_blocks[level](taps[level], residual=top, residual_mode=2)
             fpn.layer_blocks[level](top, out=outs[level])
 
-    def _decoder_block_direct(self, block, x, cat, depth):
+    def _decoder_block_direct(self, block, x, cat, depth_head, depth_input):
         """DecoderBlock.forward (dvmvs/networks.py) on the concatenation buffer ``cat`` = [up-convolution | skip | up(depth)]; the skip
-        slice has already been written by the encoder's aggregator."""
+        slice has already been written by the encoder's aggregator.  ``depth_head`` (the previous level's depth layer) runs as raw
+        convolution and its bias + sigmoid are applied inside the up-sampling kernel."""
         up_channels = block.up_convolution.conv[0].weight.shape[0]
         block.up_convolution.conv[0](_ops.upsample2x(x), out=cat[:, :up_channels])
-        if depth is not None:
-            _ops.upsample2x_into(depth, cat[:, -1:])
+        if depth_head is not None:
+            self._upsampled_depth_head(depth_head, depth_input, cat[:, -1:])
         return block.convolution2[0](block.convolution1[0](cat))
+
+    @staticmethod
+    def _upsampled_depth_head(head, x, dst):
+        _ops.upsample2x_into(head[0](x, raw=True), dst, head[0].bias, _ops.ACTIVATIONS["sigmoid"])
 
     def _frame_body_direct(self, n_meas, has_previous):
         s, d = self._static, self._direct_buffers
@@ -447,13 +453,13 @@ class DepthEngine:
                 combined = combined.contiguous()
             _ops.lstm_gates_into(combined, s["c"], s["h"])
             bottom = s["h"]
-        d1 = self._decoder_block_direct(dec.decoder_block1, bottom, dec_cat[0], None)
-        d2 = self._decoder_block_direct(dec.decoder_block2, d1, dec_cat[1], dec.depth_layer_one_sixteen[0](d1))
-        d3 = self._decoder_block_direct(dec.decoder_block3, d2, dec_cat[2], dec.depth_layer_one_eight[0](d2))
-        d4 = self._decoder_block_direct(dec.decoder_block4, d3, dec_cat[3], dec.depth_layer_quarter[0](d3))
+        d1 = self._decoder_block_direct(dec.decoder_block1, bottom, dec_cat[0], None, None)
+        d2 = self._decoder_block_direct(dec.decoder_block2, d1, dec_cat[1], dec.depth_layer_one_sixteen, d1)
+        d3 = self._decoder_block_direct(dec.decoder_block3, d2, dec_cat[2], dec.depth_layer_one_eight, d2)
+        d4 = self._decoder_block_direct(dec.decoder_block4, d3, dec_cat[3], dec.depth_layer_quarter, d3)
         full_in = d["full_in"]
         _ops.upsample2x_into(d4, full_in[:, :32])
-        _ops.upsample2x_into(dec.depth_layer_half[0](d4), full_in[:, 32:33])
+        self._upsampled_depth_head(dec.depth_layer_half, d4, full_in[:, 32:33])
         refined = dec.refine[1][0](dec.refine[0][0](full_in))
         # last convolution: bias + sigmoid + depth mapping (model.py:231-232) in one epilogue, into the depth / previous-depth buffer
         dec.depth_layer_full[0](refined, out=s["prev_depth"], activation=_ops.ACTIVATION_SIGMOID_TO_DEPTH,

@@ -421,7 +421,7 @@ def upsample2x(x: Tensor) -> Tensor:
     B, C, H, W = x.shape
     out = torch.empty((B, C, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _capi.lib().dvmvs_upsample2x_fwd(_ptr(x), _ptr(out), 0, B, C, H, W, _stream(x))
+        rc = _capi.lib().dvmvs_upsample2x_fwd(_ptr(x), _ptr(out), 0, None, 0, B, C, H, W, _stream(x))
     _capi.check(rc, "dvmvs_upsample2x_fwd")
     return out
 
@@ -516,13 +516,18 @@ def bias_act_into(x: Tensor, dst: Tensor, bias, activation: int, residual=None, 
     return dst
 
 
-def upsample2x_into(x: Tensor, dst: Tensor) -> Tensor:
+def upsample2x_into(x: Tensor, dst: Tensor, pre_bias=None, pre_activation: int = 0) -> Tensor:
+    """x2 bilinear (align_corners) up-sampling of ``x`` into ``dst``; with ``pre_activation`` (ACTIVATIONS) ``x`` is a raw convolution
+    output and act(x + pre_bias[c]) is applied to the taps on the fly."""
     _dev_f32("upsample2x_into", x)
     x = x.contiguous()
     B, C, H, W = x.shape
     stride = _slice_batch_stride("upsample2x_into", dst, B, C, 2 * H, 2 * W)
+    if pre_bias is not None and pre_bias.numel() not in (0, C):
+        raise ValueError(f"dvmvs::upsample2x_into: pre_bias has {pre_bias.numel()} entries for {C} channels")
     with torch.cuda.device(x.device):
-        rc = _capi.lib().dvmvs_upsample2x_fwd(_ptr(x), _ptr(dst), stride, B, C, H, W, _stream(x))
+        rc = _capi.lib().dvmvs_upsample2x_fwd(_ptr(x), _ptr(dst), stride, _ptr(pre_bias) if pre_bias is not None and pre_bias.numel() else None,
+                                              int(pre_activation), B, C, H, W, _stream(x))
     _capi.check(rc, "dvmvs_upsample2x_fwd")
     return dst
 

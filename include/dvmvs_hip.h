@@ -194,13 +194,16 @@ int dvmvs_depth_reproject_lowres_fwd(const float* transformation, const float* p
  *                           (MnasNet shortcut), 2 residual [B,C,H/2,W/2] nearest-up-sampled on the fly (FPN top-down sum).
  *   dvmvs_bias_act_inplace: the same with dst = x (activations 0..2).
  *   dvmvs_upsample2x_fwd:   torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True);
- *                           in [B,C,H,W] -> out [B,C,2H,2W], batch item b at out + b * out_batch_stride (0 = dense).
+ *                           in [B,C,H,W] -> out [B,C,2H,2W], batch item b at out + b * out_batch_stride (0 = dense).  With
+ *                           pre_activation != 0 (1 ReLU, 2 sigmoid) the input is a raw convolution output and
+ *                           act(in + pre_bias[c]) (pre_bias may be NULL) is applied to the taps on the fly.
  */
 int dvmvs_bias_act_fwd(const float* x, float* dst, long long dst_batch_stride, const float* bias, const float* residual,
                        int residual_mode, int B, int C, int H, int W, int activation, float p0, float p1, dvmvs_stream_t stream);
 int dvmvs_bias_act_inplace(float* x, const float* bias, const float* residual, int residual_mode, int B, int C, int H, int W,
                            int activation, dvmvs_stream_t stream);
-int dvmvs_upsample2x_fwd(const float* in, float* out, long long out_batch_stride, int B, int C, int H, int W, dvmvs_stream_t stream);
+int dvmvs_upsample2x_fwd(const float* in, float* out, long long out_batch_stride, const float* pre_bias, int pre_activation,
+                         int B, int C, int H, int W, dvmvs_stream_t stream);
 /*
  *   dvmvs_depthwise_conv_fwd: depthwise convolution (groups == C, weight [C,1,k,k], k in {3,5}, padding k/2, stride 1|2)
  *                           with bias (may be NULL) and activation fused; in [B,C,H,W] -> out [B,C,OH,OW].  The MnasNet

@@ -321,9 +321,11 @@ def test_cost_volume_gradients(ops, dev, golden_dir):
 
 def test_cost_volume_gradients_lds_privatised_scatter(ops, dev):
     """Feature maps large enough (H*W >= 4096) for the LDS-privatised measurement-gradient kernel, including a pair whose
-    near planes do not fit the box (global-atomic spill) and odd sizes; checked against autograd through the oracle."""
+    near planes need several windows of the box, and odd sizes; checked against autograd through the oracle."""
     g = torch.Generator().manual_seed(9)
-    for (B, C, H, W, D, pairs) in ((2, 8, 64, 80, 16, ((12, (9, 3)), (202, (196, 188)))), (1, 20, 72, 100, 24, ((141, (135,)),))):
+    # the 128x128 cases: wide pairs whose eight-plane boxes are several LDS windows high (the kernel walks them row block by row block)
+    for (B, C, H, W, D, pairs) in ((2, 8, 64, 80, 16, ((12, (9, 3)), (202, (196, 188)))), (1, 20, 72, 100, 24, ((141, (135,)),)),
+                                   (2, 8, 128, 128, 16, ((202, (188,)), (86, (83,)))), (1, 36, 128, 160, 8, ((170, (160,)),))):
         a = torch.randn(B, C, H, W, generator=g)
         bs = [torch.randn(B, C, H, W, generator=g) for _ in range(len(pairs[0][1]))]
         p1 = torch.cat([syn.pose(pairs[b % len(pairs)][0]) for b in range(B)])
@@ -630,6 +632,12 @@ def test_epilogues_write_into_channel_slices(ops, dev):
         ops.upsample2x_into(x.to(dev), up[:, 1:8])
         ref = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
         assert maxerr(up[:, 1:8], ref) < 1e-6 and bool((up[:, 0] == 7.0).all()) and bool((up[:, 8] == 7.0).all())
+    # coarse depth heads: sigmoid(conv + bias) applied inside the up-sampler
+    raw, hb = torch.randn(1, 1, 16, 20, generator=g) * 2, torch.randn(1, generator=g)
+    cat = torch.zeros(1, 5, 32, 40, device=dev)
+    ops.upsample2x_into(raw.to(dev), cat[:, -1:], hb.to(dev), ops.ACTIVATIONS["sigmoid"])
+    exp = torch.nn.functional.interpolate(torch.sigmoid(raw + hb.view(1, 1, 1, 1)), scale_factor=2, mode="bilinear", align_corners=True)
+    assert maxerr(cat[:, -1:], exp) < 1e-6 and float(cat[:, :4].abs().max()) == 0.0
     # last decoder layer: depth = 1 / (multiplier * sigmoid(conv + bias) + base)   (fusionnet/model.py:231-232, 297-303)
     y = torch.randn(1, 1, 256, 320, generator=g) * 3
     b1 = torch.randn(1, generator=g)
