@@ -327,6 +327,158 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_meas_kernel(CostVolumeBwd
   }
 }
 
+// grad wrt the measurement features as a GATHER (no atomics, deterministic).  A thread owns one measurement pixel q and walks
+// the planes; on plane d the sample map p -> pos_d(p) is a homography, so the reference pixels whose 2x2 tap footprint
+// contains q are the integer points of pos_d^-1((q-1, q+1)^2): a convex quadrilateral whose corners are four evaluations of
+// the inverse homography.  The kernel visits the integer points of that quadrilateral's bounding box (a 3x3 block at unit
+// scale), evaluates for each of them the FORWARD position with exactly the forward kernel's arithmetic (sweep_position: same
+// floor, same weights as the reference's taps), keeps those that really have a tap on q and accumulates
+//   g[d,p] * f1[c,p] * w_tap      for its 32 channels in registers.
+// The inverse is only a search window: where it is not trustworthy (the 2x2 footprint straddles the plane's vanishing line,
+// or the plane's matrix is singular) the window is the whole reference image -- slow and exact.
+// Workgroup = 64 measurement pixels x 4 plane groups (planes ty, ty+4, ...); the four partial sums meet in LDS in a fixed
+// order, so the result is bit-reproducible; every output element is written by exactly one thread (added to the caller's
+// zero-filled buffer, as the contract of the scatter kernels has it).
+constexpr int kGatherChannels = 32;   // channels a thread carries (more: another pass over the planes)
+constexpr int kGatherGroups = 4;
+
+__global__ __launch_bounds__(kWave* kGatherGroups) void cost_volume_bwd_meas_gather_kernel(CostVolumeBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const CostVolumeArgs& f = a.fwd;
+  const int m = blockIdx.y, b = blockIdx.z;
+  float* gmeas = a.grad_image2[m];
+  if (!gmeas) return;                           // workgroup-uniform
+  float* s_H = smem;                            // [M][9]
+  float* s_kt = s_H + DVMVS_MAX_MEASUREMENTS * 9;
+  float* s_ktd = s_kt + DVMVS_MAX_MEASUREMENTS * 3;          // [M][D][3]
+  float* s_inv = s_ktd + DVMVS_MAX_MEASUREMENTS * f.D * 3;   // [D][9]  reference pixel ~ s_inv * (qx, qy, 1), frame m
+  float* s_red = s_inv + f.D * 9;                            // [groups][channels][64]
+  const int lane = threadIdx.x, ty = threadIdx.y;
+  const int tid = ty * kWave + lane;
+  sweep_setup(f, b, 0, f.D, tid, kWave * kGatherGroups, s_H, s_kt, s_ktd);
+  const float* Hm = s_H + m * 9;
+  for (int d = tid; d < f.D; d += kWave * kGatherGroups) {
+    // sample position = diag(sx, sy) * (A p) / (A p)_z with A = Hm + (kt / depth_d) e3^T, sx = (W-1)/W, sy = (H-1)/H
+    // (utils.py:66-76 and grid_sample's align_corners convention)  =>  p ~ A^-1 diag(1/sx, 1/sy, 1) q
+    const float* ktd = s_ktd + (m * f.D + d) * 3;
+    double A[9], inv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = static_cast<double>(Hm[i]) + ((i % 3 == 2) ? static_cast<double>(ktd[i / 3]) : 0.0);
+    inverse3(A, inv);                           // non-finite for a singular A: the window test below then fails
+    const double ux = static_cast<double>(f.W) / static_cast<double>(f.W - 1), uy = static_cast<double>(f.H) / static_cast<double>(f.H - 1);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      s_inv[d * 9 + r * 3 + 0] = static_cast<float>(inv[r * 3 + 0] * ux);
+      s_inv[d * 9 + r * 3 + 1] = static_cast<float>(inv[r * 3 + 1] * uy);
+      s_inv[d * 9 + r * 3 + 2] = static_cast<float>(inv[r * 3 + 2]);
+    }
+  }
+  __syncthreads();
+
+  const int HW = f.H * f.W;
+  const int q = blockIdx.x * kWave + lane;
+  const bool live = q < HW;
+  const int qy = live ? q / f.W : 0, qx = live ? q - qy * f.W : 0;
+  const float scale = 1.0f / (static_cast<float>(f.M) * static_cast<float>(f.C));
+  const float* g = a.grad_cost + static_cast<size_t>(b) * f.D * HW;
+  gmeas += static_cast<size_t>(b) * f.C * HW;
+
+  for (int c0 = 0; c0 < f.C; c0 += kGatherChannels) {
+    const int nch = min(kGatherChannels, f.C - c0);
+    const float* ref = f.image1 + (static_cast<size_t>(b) * f.C + c0) * HW;
+    float acc[kGatherChannels];
+#pragma unroll
+    for (int c = 0; c < kGatherChannels; ++c) acc[c] = 0.0f;
+    if (live) {
+      for (int d = ty; d < f.D; d += kGatherGroups) {
+        const float* iv = s_inv + d * 9;
+        const float* ktd = s_ktd + (m * f.D + d) * 3;
+        // inverse images of the corners of (q - 1.01, q + 1.01)^2
+        float lo_x = 3.0e38f, hi_x = -3.0e38f, lo_y = 3.0e38f, hi_y = -3.0e38f, lo_w = 3.0e38f, hi_w = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float tx = static_cast<float>(qx) + ((k & 1) ? 1.01f : -1.01f), tyv = static_cast<float>(qy) + ((k & 2) ? 1.01f : -1.01f);
+          const float pw = fmaf(iv[6], tx, fmaf(iv[7], tyv, iv[8]));
+          const float px = fmaf(iv[0], tx, fmaf(iv[1], tyv, iv[2])) / pw, py = fmaf(iv[3], tx, fmaf(iv[4], tyv, iv[5])) / pw;
+          lo_x = fminf(lo_x, px); hi_x = fmaxf(hi_x, px); lo_y = fminf(lo_y, py); hi_y = fmaxf(hi_y, py);
+          lo_w = fminf(lo_w, pw); hi_w = fmaxf(hi_w, pw);
+        }
+        // trustworthy: finite, and the homogeneous coordinate keeps its sign with a margin over the footprint (every comparison
+        // is false for NaN, which selects the whole image)
+        const bool one_sign = (lo_w > 0.0f && lo_w > 1e-3f * hi_w) || (hi_w < 0.0f && hi_w < 1e-3f * lo_w);
+        const bool bounded = (lo_x > -1e7f) && (hi_x < 1e7f) && (lo_y > -1e7f) && (hi_y < 1e7f);
+        int x0 = 0, x1 = f.W - 1, y0 = 0, y1 = f.H - 1;
+        if (one_sign && bounded) {
+          // integer points of [lo - margin, hi + margin]
+          x0 = max(0, static_cast<int>(ceilf(lo_x - 0.05f)));
+          x1 = min(f.W - 1, static_cast<int>(floorf(hi_x + 0.05f)));
+          y0 = max(0, static_cast<int>(ceilf(lo_y - 0.05f)));
+          y1 = min(f.H - 1, static_cast<int>(floorf(hi_y + 0.05f)));
+        }
+        const float* gplane = g + static_cast<size_t>(d) * HW;
+        for (int py = y0; py <= y1; ++py) {
+          for (int px = x0; px <= x1; ++px) {
+            float ix, iy;
+            sweep_position(Hm, ktd, static_cast<float>(px), static_cast<float>(py), f.W, f.H, &ix, &iy);
+            // make_taps' own test and arithmetic (dvmvs_device.h): positions this far out have no tap anywhere
+            if (!((ix > -2.0f) && (ix < static_cast<float>(f.W) + 1.0f) && (iy > -2.0f) && (iy < static_cast<float>(f.H) + 1.0f))) continue;
+            const float fx = floorf(ix), fy = floorf(iy);
+            const int dx = qx - static_cast<int>(fx), dy = qy - static_cast<int>(fy);
+            if (dx < 0 || dx > 1 || dy < 0 || dy > 1) continue;
+            const float wxv = dx ? ix - fx : (fx + 1.0f) - ix;
+            const float wyv = dy ? iy - fy : (fy + 1.0f) - iy;
+            const int p = py * f.W + px;
+            const float coef = (wxv * wyv) * (gplane[p] * scale);
+            if (coef == 0.0f) continue;
+#pragma unroll
+            for (int c = 0; c < kGatherChannels; ++c)
+              if (c < nch) acc[c] = fmaf(ref[static_cast<size_t>(c) * HW + p], coef, acc[c]);
+          }
+        }
+      }
+    }
+    // the four plane groups meet in a fixed order
+    __syncthreads();                            // previous pass's readers are done
+#pragma unroll
+    for (int c = 0; c < kGatherChannels; ++c) s_red[(ty * kGatherChannels + c) * kWave + lane] = acc[c];
+    __syncthreads();
+    if (live) {
+      constexpr int kPer = kGatherChannels / kGatherGroups;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const int c = ty * kPer + k;
+        if (c < nch) {
+          float v = 0.0f;
+#pragma unroll
+          for (int gidx = 0; gidx < kGatherGroups; ++gidx) v += s_red[(gidx * kGatherChannels + c) * kWave + lane];
+          float* dst = gmeas + static_cast<size_t>(c0 + c) * HW + q;
+          *dst += v;
+        }
+      }
+    }
+  }
+}
+
+static int launch_bwd_meas_gather(const CostVolumeBwdArgs& a, int B, int M, int H, int W, int D, hipStream_t s) {
+  const size_t smem = sizeof(float) * (DVMVS_MAX_MEASUREMENTS * 12 + static_cast<size_t>(DVMVS_MAX_MEASUREMENTS) * D * 3 + static_cast<size_t>(D) * 9 +
+                                       static_cast<size_t>(kGatherGroups) * kGatherChannels * kWave);
+  auto kernel = cost_volume_bwd_meas_gather_kernel;
+  static bool configured[64] = {};
+  int device = 0;
+  DVMVS_RETURN_IF_HIP(hipGetDevice(&device));
+  const bool tracked = device >= 0 && device < 64;
+  if (!tracked || !configured[device]) {
+    DVMVS_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            static_cast<int>(sizeof(float) * (DVMVS_MAX_MEASUREMENTS * 12 + static_cast<size_t>(DVMVS_MAX_MEASUREMENTS) * DVMVS_MAX_DEPTH_LEVELS * 3 +
+                                                                              static_cast<size_t>(DVMVS_MAX_DEPTH_LEVELS) * 9 + static_cast<size_t>(kGatherGroups) * kGatherChannels * kWave))));
+    if (tracked) configured[device] = true;
+  }
+  const int HW = H * W;
+  dim3 block(kWave, kGatherGroups), grid((HW + kWave - 1) / kWave, M, B);
+  hipLaunchKernelGGL(kernel, grid, block, smem, s, a);
+  return launch_status();
+}
+
 // Launch of the LDS-privatised scatter: 32x8-pixel tiles x 8 planes per workgroup, CCH channels per pass, CAP box positions in LDS.
 template <int CCH, int CAP>
 static int launch_bwd_meas_tiled(const CostVolumeBwdArgs& a, int B, int H, int W, int D, hipStream_t s) {
@@ -349,7 +501,7 @@ static int launch_bwd_meas_tiled(const CostVolumeBwdArgs& a, int B, int H, int W
 }
 
 #ifdef DVMVS_SWEEP_TUNING
-static int g_bwd_tuning_config = 0;
+static int g_bwd_tuning_config = -1;   // -1: what the product does
 #endif
 
 }  // namespace dvmvs
@@ -385,30 +537,22 @@ extern "C" int dvmvs_cost_volume_bwd(const float* grad_cost, const float* image1
     rc = launch_status();
     if (rc != 0) return rc;
   }
-  if (any_meas && HW >= 64 * 64) {
+  if (!any_meas) return rc;
+  int config = (W > 1 && H > 1) ? 5 : 9;        // the gather needs (W-1)/W and (H-1)/H to be invertible
 #ifdef DVMVS_SWEEP_TUNING
-    switch (g_bwd_tuning_config) {
-      case 1: rc = launch_bwd_meas_tiled<8, 1536>(a, B, H, W, D, s); break;    // 4 channel passes, 54 KB
-      case 2: rc = launch_bwd_meas_tiled<32, 384>(a, B, H, W, D, s); break;    // 1 channel pass, 50 KB
-      case 3: rc = launch_bwd_meas_tiled<16, 1152>(a, B, H, W, D, s); break;   // 77 KB: two workgroups per CU
-      case 4: rc = launch_bwd_meas_tiled<16, 576>(a, B, H, W, D, s); break;    // 38 KB: four workgroups per CU
-      case 9: {                                                                 // the global-atomic scatter (cross-check)
-        constexpr int kPlanesPerBlock = kBwdPlaneGroups * kBwdPPT;
-        dim3 block(kWave, kBwdPlaneGroups), grid((HW + kWave - 1) / kWave, (D + kPlanesPerBlock - 1) / kPlanesPerBlock, B);
-        hipLaunchKernelGGL(cost_volume_bwd_meas_kernel, grid, block, 0, s, a);
-        rc = launch_status();
-        break;
-      }
-      default: rc = launch_bwd_meas_tiled<16, 768>(a, B, H, W, D, s); break;
-    }
-#else
-    rc = launch_bwd_meas_tiled<16, 768>(a, B, H, W, D, s);   // 51 KB: three workgroups per CU
-#endif
-  } else if (any_meas) {
-    constexpr int kPlanesPerBlock = kBwdPlaneGroups * kBwdPPT;
-    dim3 block(kWave, kBwdPlaneGroups), grid((HW + kWave - 1) / kWave, (D + kPlanesPerBlock - 1) / kPlanesPerBlock, B);
-    hipLaunchKernelGGL(cost_volume_bwd_meas_kernel, grid, block, 0, s, a);
-    rc = launch_status();
+  if (g_bwd_tuning_config >= 0 && (config == 5 || g_bwd_tuning_config == 9)) config = g_bwd_tuning_config;
+  switch (config) {
+    case 0: return launch_bwd_meas_tiled<16, 768>(a, B, H, W, D, s);    // LDS-privatised scatter, 51 KB: three workgroups per CU
+    case 1: return launch_bwd_meas_tiled<8, 1536>(a, B, H, W, D, s);    // 4 channel passes, 54 KB
+    case 2: return launch_bwd_meas_tiled<32, 384>(a, B, H, W, D, s);    // 1 channel pass, 50 KB
+    case 3: return launch_bwd_meas_tiled<16, 1152>(a, B, H, W, D, s);   // 77 KB: two workgroups per CU
+    case 4: return launch_bwd_meas_tiled<16, 576>(a, B, H, W, D, s);    // 38 KB
+    default: break;
   }
-  return rc;
+#endif
+  if (config == 5) return launch_bwd_meas_gather(a, B, M, H, W, D, s);
+  constexpr int kPlanesPerBlock = kBwdPlaneGroups * kBwdPPT;     // the plain global-atomic scatter
+  dim3 block(kWave, kBwdPlaneGroups), grid((HW + kWave - 1) / kWave, (D + kPlanesPerBlock - 1) / kPlanesPerBlock, B);
+  hipLaunchKernelGGL(cost_volume_bwd_meas_kernel, grid, block, 0, s, a);
+  return launch_status();
 }

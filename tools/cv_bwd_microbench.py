@@ -2,13 +2,14 @@
 geometry: B=4, C=32, 128x128 features, 64 planes, one measurement frame, pose pairs three frames apart on the sample scene
 (the pairs bench.py --mode train feeds; BASELINE.json configs[4]).  Run on the GPU box:
 
-    python tools/cv_bwd_microbench.py [--lib tuning --configs 0,1,2,3,4,9] [--frames 1,2,3,4,5,6,7] [--out gpurun_out/x.json]
+    python tools/cv_bwd_microbench.py [--lib tuning --configs 5,0,1,2,3,4,9] [--frames 1,2,3,4,5,6,7] [--out gpurun_out/x.json]
 
 Each (frame, configuration) is captured into a hipGraph of REPS back-to-back calls and timed with HIP events; the time of the
 reference-feature gather kernel alone (no measurement gradient requested) is measured the same way and subtracted.  With
---lib tuning the configurations of csrc/cost_volume_bwd.hip are selected through dvmvs_tuning_set_bwd_config (0 = the
-product's 16 channels x 768 positions, 9 = the plain global-atomic scatter, which is also the cross-check).  The product
-library has only configuration 0 and no cross-check here: its parity tests are tests/test_hip_parity.py (float64 autograd).
+--lib tuning the configurations of csrc/cost_volume_bwd.hip are selected through dvmvs_tuning_set_bwd_config (5 = the
+product's gather kernel, 0-4 = the LDS-privatised scatter of rounds 1-3 with different channel chunks / LDS windows, 9 = the
+plain global-atomic scatter, which is also the cross-check).  The product library has only configuration 5 and no
+cross-check here: its parity tests are tests/test_hip_parity.py (float64 autograd).
 """
 import argparse
 import json
@@ -42,7 +43,7 @@ def timed(graph, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default="product", choices=["product", "tuning"])
-    ap.add_argument("--configs", default="0")
+    ap.add_argument("--configs", default="5")
     ap.add_argument("--frames", default="1,2,3,4,5,6,7")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--reps", type=int, default=5)
@@ -53,8 +54,8 @@ def main():
     if args.lib == "tuning":
         lib.dvmvs_tuning_set_bwd_config.restype, lib.dvmvs_tuning_set_bwd_config.argtypes = None, [_capi.ctypes.c_int]
     configs = [int(v) for v in args.configs.split(",")]
-    if args.lib != "tuning" and configs != [0]:
-        raise SystemExit("the product library has only configuration 0; use --lib tuning")
+    if args.lib != "tuning" and configs != [5]:
+        raise SystemExit("the product library has only configuration 5; use --lib tuning")
     B, C, H, W, D = args.batch, 32, 128, 128, 64
     g = torch.Generator().manual_seed(11)
     f1 = torch.randn(B, C, H, W, generator=g).to(dev)
