@@ -545,6 +545,8 @@ def main():
                                    f"320x256, 64 planes, M={M} measurement frames, batch 1 (BASELINE.json configs[2]; configs[3] at N>1)",
                        "sequences_per_gpu": 1, "hip_graphs": not args.no_graphs, "bn_folded": not args.no_fold_bn,
                        "feature_cache": not args.no_feature_cache, "full_resolution_only": True,
+                       "conv_epilogues_inside_miopen": (lambda rep: f"{sum(1 for r in rep if r[2])} of {len(rep)} dense convolution problems "
+                                                        "(timed against convolution + epilogue at warm-up)")(engine.conv_plan_report()),
                        "weights": "seeded (tests/synthetic.py) + published FPN checkpoint",
                        "parallelism": f"sequence-sharded x{world}, no data-path collective"},
             "roofline": {"kernel": "sweep_tiled_kernel + sweep_spill_kernel (fused warp + correlation, all planes, all measurement frames)",

@@ -339,10 +339,14 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_meas_kernel(CostVolumeBwd
 // Workgroup = 64 measurement pixels x 4 plane groups (planes ty, ty+4, ...); the four partial sums meet in LDS in a fixed
 // order, so the result is bit-reproducible; every output element is written by exactly one thread (added to the caller's
 // zero-filled buffer, as the contract of the scatter kernels has it).
-constexpr int kGatherChannels = 32;   // channels a thread carries (more: another pass over the planes)
-constexpr int kGatherGroups = 4;
-
-__global__ __launch_bounds__(kWave* kGatherGroups) void cost_volume_bwd_meas_gather_kernel(CostVolumeBwdArgs a) {
+// CH channels per thread, PG plane groups, CG channel groups: a workgroup is 64 pixels x PG x CG waves and covers CH * CG
+// channels per pass over the planes.  WAVES = waves per SIMD the register allocation is held to.
+template <int CH, int PG, int CG, int WAVES>
+__global__ __launch_bounds__(kWave* PG* CG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+void cost_volume_bwd_meas_gather_kernel(CostVolumeBwdArgs a) {
+  constexpr int NT = kWave * PG * CG;
+  constexpr int CPP = CH * CG;                  // channels per pass
+  static_assert(CH % PG == 0, "the final sum is split over the plane groups");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const CostVolumeArgs& f = a.fwd;
   const int m = blockIdx.y, b = blockIdx.z;
@@ -352,12 +356,14 @@ __global__ __launch_bounds__(kWave* kGatherGroups) void cost_volume_bwd_meas_gat
   float* s_kt = s_H + DVMVS_MAX_MEASUREMENTS * 9;
   float* s_ktd = s_kt + DVMVS_MAX_MEASUREMENTS * 3;          // [M][D][3]
   float* s_inv = s_ktd + DVMVS_MAX_MEASUREMENTS * f.D * 3;   // [D][9]  reference pixel ~ s_inv * (qx, qy, 1), frame m
-  float* s_red = s_inv + f.D * 9;                            // [groups][channels][64]
-  const int lane = threadIdx.x, ty = threadIdx.y;
-  const int tid = ty * kWave + lane;
-  sweep_setup(f, b, 0, f.D, tid, kWave * kGatherGroups, s_H, s_kt, s_ktd);
+  float* s_red = s_inv + f.D * 9;                            // [PG][CPP][64]
+  // blockDim.x is the wave width: threadIdx.y is wave-uniform, and telling the compiler so keeps every base pointer scalar
+  const int lane = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.y));
+  const int pg = wave % PG, cg = wave / PG;
+  const int tid = threadIdx.y * kWave + lane;
+  sweep_setup(f, b, 0, f.D, tid, NT, s_H, s_kt, s_ktd);
   const float* Hm = s_H + m * 9;
-  for (int d = tid; d < f.D; d += kWave * kGatherGroups) {
+  for (int d = tid; d < f.D; d += NT) {
     // sample position = diag(sx, sy) * (A p) / (A p)_z with A = Hm + (kt / depth_d) e3^T, sx = (W-1)/W, sy = (H-1)/H
     // (utils.py:66-76 and grid_sample's align_corners convention)  =>  p ~ A^-1 diag(1/sx, 1/sy, 1) q
     const float* ktd = s_ktd + (m * f.D + d) * 3;
@@ -383,23 +389,25 @@ __global__ __launch_bounds__(kWave* kGatherGroups) void cost_volume_bwd_meas_gat
   const float* g = a.grad_cost + static_cast<size_t>(b) * f.D * HW;
   gmeas += static_cast<size_t>(b) * f.C * HW;
 
-  for (int c0 = 0; c0 < f.C; c0 += kGatherChannels) {
-    const int nch = min(kGatherChannels, f.C - c0);
-    const float* ref = f.image1 + (static_cast<size_t>(b) * f.C + c0) * HW;
-    float acc[kGatherChannels];
+  for (int c0 = 0; c0 < f.C; c0 += CPP) {
+    const int cbase = c0 + cg * CH;             // this thread's first channel
+    const int nch = max(0, min(CH, f.C - cbase));
+    const float* ref = f.image1 + (static_cast<size_t>(b) * f.C + min(cbase, f.C - 1)) * HW;
+    float acc[CH];
 #pragma unroll
-    for (int c = 0; c < kGatherChannels; ++c) acc[c] = 0.0f;
-    if (live) {
-      for (int d = ty; d < f.D; d += kGatherGroups) {
+    for (int c = 0; c < CH; ++c) acc[c] = 0.0f;
+    if (live && nch > 0) {
+      for (int d = pg; d < f.D; d += PG) {
         const float* iv = s_inv + d * 9;
         const float* ktd = s_ktd + (m * f.D + d) * 3;
-        // inverse images of the corners of (q - 1.01, q + 1.01)^2
+        // inverse images of the corners of (q - 1.01, q + 1.01)^2 (a search window: the hardware reciprocal is good enough)
         float lo_x = 3.0e38f, hi_x = -3.0e38f, lo_y = 3.0e38f, hi_y = -3.0e38f, lo_w = 3.0e38f, hi_w = -3.0e38f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float tx = static_cast<float>(qx) + ((k & 1) ? 1.01f : -1.01f), tyv = static_cast<float>(qy) + ((k & 2) ? 1.01f : -1.01f);
           const float pw = fmaf(iv[6], tx, fmaf(iv[7], tyv, iv[8]));
-          const float px = fmaf(iv[0], tx, fmaf(iv[1], tyv, iv[2])) / pw, py = fmaf(iv[3], tx, fmaf(iv[4], tyv, iv[5])) / pw;
+          const float rw = __builtin_amdgcn_rcpf(pw);
+          const float px = fmaf(iv[0], tx, fmaf(iv[1], tyv, iv[2])) * rw, py = fmaf(iv[3], tx, fmaf(iv[4], tyv, iv[5])) * rw;
           lo_x = fminf(lo_x, px); hi_x = fmaxf(hi_x, px); lo_y = fminf(lo_y, py); hi_y = fmaxf(hi_y, py);
           lo_w = fminf(lo_w, pw); hi_w = fmaxf(hi_w, pw);
         }
@@ -427,31 +435,33 @@ __global__ __launch_bounds__(kWave* kGatherGroups) void cost_volume_bwd_meas_gat
             if (dx < 0 || dx > 1 || dy < 0 || dy > 1) continue;
             const float wxv = dx ? ix - fx : (fx + 1.0f) - ix;
             const float wyv = dy ? iy - fy : (fy + 1.0f) - iy;
+            const float wgt = wxv * wyv;
+            if (wgt == 0.0f) continue;
+            // the upstream gradient and the reference features are loaded together (no branch on the former)
             const int p = py * f.W + px;
-            const float coef = (wxv * wyv) * (gplane[p] * scale);
-            if (coef == 0.0f) continue;
+            const float coef = wgt * (gplane[p] * scale);
 #pragma unroll
-            for (int c = 0; c < kGatherChannels; ++c)
+            for (int c = 0; c < CH; ++c)
               if (c < nch) acc[c] = fmaf(ref[static_cast<size_t>(c) * HW + p], coef, acc[c]);
           }
         }
       }
     }
-    // the four plane groups meet in a fixed order
+    // the plane groups meet in a fixed order
     __syncthreads();                            // previous pass's readers are done
 #pragma unroll
-    for (int c = 0; c < kGatherChannels; ++c) s_red[(ty * kGatherChannels + c) * kWave + lane] = acc[c];
+    for (int c = 0; c < CH; ++c) s_red[(pg * CPP + cg * CH + c) * kWave + lane] = acc[c];
     __syncthreads();
     if (live) {
-      constexpr int kPer = kGatherChannels / kGatherGroups;
+      constexpr int kPer = CH / PG;
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
-        const int c = ty * kPer + k;
-        if (c < nch) {
+        const int cl = cg * CH + pg * kPer + k;  // channel within the pass
+        if (c0 + cl < f.C) {
           float v = 0.0f;
 #pragma unroll
-          for (int gidx = 0; gidx < kGatherGroups; ++gidx) v += s_red[(gidx * kGatherChannels + c) * kWave + lane];
-          float* dst = gmeas + static_cast<size_t>(c0 + c) * HW + q;
+          for (int gidx = 0; gidx < PG; ++gidx) v += s_red[(gidx * CPP + cl) * kWave + lane];
+          float* dst = gmeas + static_cast<size_t>(c0 + cl) * HW + q;
           *dst += v;
         }
       }
@@ -459,23 +469,25 @@ __global__ __launch_bounds__(kWave* kGatherGroups) void cost_volume_bwd_meas_gat
   }
 }
 
+template <int CH, int PG, int CG, int WAVES>
 static int launch_bwd_meas_gather(const CostVolumeBwdArgs& a, int B, int M, int H, int W, int D, hipStream_t s) {
-  const size_t smem = sizeof(float) * (DVMVS_MAX_MEASUREMENTS * 12 + static_cast<size_t>(DVMVS_MAX_MEASUREMENTS) * D * 3 + static_cast<size_t>(D) * 9 +
-                                       static_cast<size_t>(kGatherGroups) * kGatherChannels * kWave);
-  auto kernel = cost_volume_bwd_meas_gather_kernel;
+  auto lds_floats = [](int planes) {
+    return static_cast<size_t>(DVMVS_MAX_MEASUREMENTS) * 12 + static_cast<size_t>(DVMVS_MAX_MEASUREMENTS) * planes * 3 + static_cast<size_t>(planes) * 9 +
+           static_cast<size_t>(PG) * CH * CG * kWave;
+  };
+  auto kernel = cost_volume_bwd_meas_gather_kernel<CH, PG, CG, WAVES>;
   static bool configured[64] = {};
   int device = 0;
   DVMVS_RETURN_IF_HIP(hipGetDevice(&device));
   const bool tracked = device >= 0 && device < 64;
   if (!tracked || !configured[device]) {
     DVMVS_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            static_cast<int>(sizeof(float) * (DVMVS_MAX_MEASUREMENTS * 12 + static_cast<size_t>(DVMVS_MAX_MEASUREMENTS) * DVMVS_MAX_DEPTH_LEVELS * 3 +
-                                                                              static_cast<size_t>(DVMVS_MAX_DEPTH_LEVELS) * 9 + static_cast<size_t>(kGatherGroups) * kGatherChannels * kWave))));
+                                            static_cast<int>(sizeof(float) * lds_floats(DVMVS_MAX_DEPTH_LEVELS))));
     if (tracked) configured[device] = true;
   }
   const int HW = H * W;
-  dim3 block(kWave, kGatherGroups), grid((HW + kWave - 1) / kWave, M, B);
-  hipLaunchKernelGGL(kernel, grid, block, smem, s, a);
+  dim3 block(kWave, PG * CG), grid((HW + kWave - 1) / kWave, M, B);
+  hipLaunchKernelGGL(kernel, grid, block, sizeof(float) * lds_floats(D), s, a);
   return launch_status();
 }
 
@@ -547,10 +559,15 @@ extern "C" int dvmvs_cost_volume_bwd(const float* grad_cost, const float* image1
     case 2: return launch_bwd_meas_tiled<32, 384>(a, B, H, W, D, s);    // 1 channel pass, 50 KB
     case 3: return launch_bwd_meas_tiled<16, 1152>(a, B, H, W, D, s);   // 77 KB: two workgroups per CU
     case 4: return launch_bwd_meas_tiled<16, 576>(a, B, H, W, D, s);    // 38 KB
+    case 6: return launch_bwd_meas_gather<16, 4, 2, 5>(a, B, M, H, W, D, s);
+    case 7: return launch_bwd_meas_gather<8, 4, 4, 8>(a, B, M, H, W, D, s);
+    case 8: return launch_bwd_meas_gather<32, 4, 1, 3>(a, B, M, H, W, D, s);
+    case 10: return launch_bwd_meas_gather<16, 8, 2, 5>(a, B, M, H, W, D, s);
+    case 11: return launch_bwd_meas_gather<32, 8, 1, 4>(a, B, M, H, W, D, s);
     default: break;
   }
 #endif
-  if (config == 5) return launch_bwd_meas_gather(a, B, M, H, W, D, s);
+  if (config == 5) return launch_bwd_meas_gather<32, 4, 1, 4>(a, B, M, H, W, D, s);
   constexpr int kPlanesPerBlock = kBwdPlaneGroups * kBwdPPT;     // the plain global-atomic scatter
   dim3 block(kWave, kBwdPlaneGroups), grid((HW + kWave - 1) / kWave, (D + kPlanesPerBlock - 1) / kPlanesPerBlock, B);
   hipLaunchKernelGGL(cost_volume_bwd_meas_kernel, grid, block, 0, s, a);

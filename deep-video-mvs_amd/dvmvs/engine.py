@@ -29,6 +29,7 @@ MI355X-specific execution choices (none of them changes results beyond fp32 roun
   launch.  ``pose_algebra="exact"`` evaluates them on the device in fp64 inside the captured frame instead.
 """
 import copy
+import os
 from collections import OrderedDict
 
 import torch
@@ -77,6 +78,27 @@ def fold_batchnorm(module):
 # ----------------------------------------------------------------------------------------------------------------------
 # epilogue fusion: conv (MIOpen, no bias) + one in-place HIP kernel for bias and activation
 # ----------------------------------------------------------------------------------------------------------------------
+def _graph_microseconds(fn, reps=10, rounds=3):
+    """GPU time of one ``fn()``: ``reps`` of them captured into a hipGraph, best of ``rounds`` replays (HIP events)."""
+    fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(rounds):
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        graph.replay()
+        end.record()
+        torch.cuda.synchronize()
+        best = min(best, start.elapsed_time(end) * 1e3 / reps)
+    return best
+
+
 class FusedConv2d(nn.Module):
     """Convolution whose bias add and activation run as ONE HIP kernel (dvmvs_bias_act_fwd) instead of two ATen launches
     after the MIOpen convolution.  Same arithmetic (add, then max / sigmoid), so results are identical.  Three launch savers:
@@ -94,6 +116,10 @@ class FusedConv2d(nn.Module):
         self.register_buffer("_no_bias", torch.empty(0, device=conv.weight.device), persistent=False)
         self.defer_epilogue = False      # set by fuse_epilogues: the next (depthwise) layer applies this layer's bias + ReLU
         self.pre_bias = None             # set by fuse_epilogues on that depthwise layer: the deferred bias
+        # Epilogue inside MIOpen's kernel (dvmvs_conv_bias_act_fwd): decided per input shape by timing both forms the first time
+        # the shape is seen outside a stream capture; {input shape: (use the plan, plan us, two-launch us, max |difference|)}
+        self.plan_epilogue = False       # set by DepthEngine(conv_plans=True)
+        self.plans = {}
 
         k = conv.kernel_size
         self.depthwise = (conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1 and k[0] == k[1] and k[0] in (3, 5)
@@ -111,12 +137,45 @@ class FusedConv2d(nn.Module):
                                        pre if pre is not None else self._no_bias, pre is not None)
         if self.pre_bias is not None:
             raise RuntimeError("a depthwise layer with a deferred input epilogue must take the depthwise kernel")
+        if (self.plan_epilogue and residual is None and not raw and not self.defer_epilogue and self._plan_eligible(act)
+                and x.is_contiguous()):
+            key = tuple(x.shape)
+            plan = self.plans.get(key)
+            if plan is None and not torch.cuda.is_current_stream_capturing():
+                plan = self.plans[key] = self._time_plan(x, act)
+            if plan is not None and plan[0]:
+                y = _ops.conv_bias_act_into(x, self.weight, self.bias, out, self.stride[0], self.padding[0], act)
+                if y is not None:
+                    return y
         y = nn.functional.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
         if not y.is_contiguous():
             y = y.contiguous()
         if self.defer_epilogue or raw:
             return y
         return _ops.bias_act_into(y, y if out is None else out, self.bias, act, residual, residual_mode if residual is not None else 0, p0, p1)
+
+    def _plan_eligible(self, act):
+        k = self.weight.shape
+        return (not self.depthwise and self.groups == 1 and self.bias is not None and k[2] == k[3] and self.stride[0] == self.stride[1]
+                and self.padding[0] == self.padding[1] and tuple(self.dilation) == (1, 1)
+                and act in (_ops.ACTIVATIONS["none"], _ops.ACTIVATIONS["relu"]))
+
+
+    def _time_plan(self, x, act):
+        """(use the MIOpen fusion plan for this input shape?, plan us, convolution + epilogue us, max |difference|)."""
+        with torch.no_grad():
+            probe = _ops.conv_bias_act_into(x, self.weight, self.bias, None, self.stride[0], self.padding[0], act)
+            if probe is None:
+                return (False, float("nan"), float("nan"), float("nan"))
+
+            def two_launches():
+                y = nn.functional.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups)
+                return _ops.bias_act_into(y, y, self.bias, act)
+
+            difference = float((two_launches() - probe).abs().max())
+            t_two = _graph_microseconds(two_launches)
+            t_plan = _graph_microseconds(lambda: _ops.conv_bias_act_into(x, self.weight, self.bias, probe, self.stride[0], self.padding[0], act))
+        return (t_plan < t_two, t_plan, t_two, difference)
 
 
 def fuse_epilogues(module):
@@ -184,7 +243,7 @@ class DepthEngine:
     def __init__(self, feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder,
                  device="cuda", min_depth=0.25, max_depth=20.0, n_depth_levels=64, fold_bn=True, cache_features=True,
                  use_graphs=True, cache_size=None, channels_last=False, fuse=True, lstm_channels_last=True, sequences=1,
-                 pose_algebra=None):
+                 pose_algebra=None, conv_plans=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DepthEngine runs on an MI355X; there is no CPU execution path in this package")
@@ -196,6 +255,14 @@ class DepthEngine:
         if channels_last:
             mods = [None if m is None else m.to(memory_format=torch.channels_last) for m in mods]
         self.fe, self.fs, self.enc, self.lstm, self.dec = mods
+        # epilogues inside MIOpen's Winograd kernels where that is measurably faster (FusedConv2d.plans; DVMVS_CONV_PLANS=0 disables)
+        if conv_plans is None:
+            conv_plans = os.environ.get("DVMVS_CONV_PLANS", "1") != "0"
+        self.conv_plans = bool(conv_plans and fuse and not channels_last)
+        for m in mods:
+            for sub in ([] if m is None else m.modules()):
+                if isinstance(sub, FusedConv2d):
+                    sub.plan_epilogue = self.conv_plans
         if lstm_channels_last and self.lstm is not None and not channels_last:
             # the ConvLSTM convolution (1024 -> 2048 channels on an 8x10 map, 75 MB of weights) is weight-bandwidth bound;
             # MIOpen's NHWC kernel for it takes 56 us against 88 us for NCHW, which more than pays for the two small layout
@@ -222,6 +289,16 @@ class DepthEngine:
         self._static = None
         self._warm = set()
         self.reset()
+
+    def conv_plan_report(self):
+        """[(input shape, weight shape, uses the MIOpen fusion plan, plan us, convolution + epilogue us, max |difference|)] of
+        every dense convolution problem timed so far."""
+        rows = []
+        for m in (self.fe, self.fs, self.enc, self.lstm, self.dec):
+            for sub in ([] if m is None else m.modules()):
+                if isinstance(sub, FusedConv2d):
+                    rows += [(shape, tuple(sub.weight.shape)) + tuple(plan) for shape, plan in sub.plans.items()]
+        return rows
 
     # ---- state ------------------------------------------------------------------------------------------------------
     @property

@@ -10,7 +10,8 @@ import threading
 
 # PyTorch-ROCm ships its own libamdhip64.so.  It must be in the process BEFORE libdvmvs_hip.so is dlopen'ed so that the
 # library's DT_NEEDED libamdhip64.so.7 resolves to that already-loaded copy: two HIP runtimes in one process do not
-# share streams or device memory (symptom: "no ROCm-capable device is detected" from the second one).
+# share streams or device memory (symptom: "no ROCm-capable device is detected" from the second one).  The same holds for
+# libMIOpen.so.1 (dvmvs_conv_bias_act_fwd): the process has ONE MIOpen, the one torch's convolutions use.
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -50,6 +51,7 @@ SIGNATURES = {
     "dvmvs_bias_act_fwd": (_c_int, [_c_fp, _c_fp, ctypes.c_longlong, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                     ctypes.c_float, ctypes.c_float, _c_stream]),
     "dvmvs_bias_act_inplace": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "dvmvs_conv_bias_act_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_longlong] + [_c_int] * 10 + [_c_stream]),
     "dvmvs_upsample2x_fwd": (_c_int, [_c_fp, _c_fp, ctypes.c_longlong, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_depth_reproject_lowres_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_tsdf_integrate": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,

@@ -516,6 +516,34 @@ def bias_act_into(x: Tensor, dst: Tensor, bias, activation: int, residual=None, 
     return dst
 
 
+EUNSUPPORTED = -2     # include/dvmvs_hip.h
+
+
+def conv_bias_act_into(x: Tensor, weight: Tensor, bias: Tensor, dst, stride: int, padding: int, activation: int):
+    """conv2d(x, weight, padding, stride) + bias [+ ReLU] as ONE MIOpen fusion plan (dvmvs_conv_bias_act_fwd), written into ``dst``
+    (a dense tensor or a channel slice of a concatenation buffer; None: a new tensor).  Returns the output, or None when MIOpen has
+    no fused plan for the problem (the caller then runs convolution + dvmvs_bias_act_fwd)."""
+    _dev_f32("conv_bias_act_into", x, weight, bias)
+    if activation not in (ACTIVATIONS["none"], ACTIVATIONS["relu"]):
+        raise ValueError("dvmvs::conv_bias_act_into: activation must be none or relu")
+    x, weight = x.contiguous(), weight.contiguous()
+    B, Cin, H, W = x.shape
+    Cout, Cin_w, K, K2 = weight.shape
+    if Cin_w != Cin or K != K2 or bias.numel() != Cout:
+        raise ValueError(f"dvmvs::conv_bias_act_into: weight {tuple(weight.shape)} / bias {bias.numel()} do not fit input {tuple(x.shape)}")
+    Ho, Wo = (H + 2 * padding - K) // stride + 1, (W + 2 * padding - K) // stride + 1
+    if dst is None:
+        dst = torch.empty(B, Cout, Ho, Wo, device=x.device, dtype=torch.float32)
+    batch_stride = _slice_batch_stride("conv_bias_act_into", dst, B, Cout, Ho, Wo)
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().dvmvs_conv_bias_act_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(dst), batch_stride, B, Cin, H, W, Cout, K,
+                                                 int(stride), int(padding), int(activation), _stream(x))
+    if rc == EUNSUPPORTED:
+        return None
+    _capi.check(rc, "dvmvs_conv_bias_act_fwd")
+    return dst
+
+
 def upsample2x_into(x: Tensor, dst: Tensor, pre_bias=None, pre_activation: int = 0) -> Tensor:
     """x2 bilinear (align_corners) up-sampling of ``x`` into ``dst``; with ``pre_activation`` (ACTIVATIONS) ``x`` is a raw convolution
     output and act(x + pre_bias[c]) is applied to the taps on the fly."""

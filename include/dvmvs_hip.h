@@ -33,6 +33,7 @@ extern "C" {
 
 #define DVMVS_EINVAL (-1)             /* null pointer / non-positive dimension / out-of-range count */
 #define DVMVS_EUNSUPPORTED (-2)       /* shape outside what the kernels were built for */
+#define DVMVS_ELIBRARY (-3)           /* a call into MIOpen failed (dvmvs_conv_bias_act_fwd) */
 
 typedef void* dvmvs_stream_t;         /* hipStream_t */
 
@@ -204,6 +205,18 @@ int dvmvs_bias_act_inplace(float* x, const float* bias, const float* residual, i
                            int activation, dvmvs_stream_t stream);
 int dvmvs_upsample2x_fwd(const float* in, float* out, long long out_batch_stride, const float* pre_bias, int pre_activation,
                          int B, int C, int H, int W, dvmvs_stream_t stream);
+/*
+ *   dvmvs_conv_bias_act_fwd: a dense convolution (square kernel K, zero padding, no dilation, one group) WITH its epilogue, as one
+ *                           MIOpen fusion plan (convolution + bias [+ ReLU]): out = act(conv(x, weight) + bias[c]).  The convolution
+ *                           is MIOpen's in either form; what this saves is the dvmvs_bias_act_fwd launch after it, for the problems
+ *                           MIOpen gives to its fp32 Winograd kernel (for the others the plan is slower than convolution + epilogue:
+ *                           the caller times both at warm-up, dvmvs/engine.py).  x [B,Cin,H,W], weight [Cout,Cin,K,K], bias [Cout],
+ *                           out [B,Cout,Ho,Wo] with batch item b at out + b * out_batch_stride (0 = dense); activation 0 none, 1 ReLU.
+ *                           The first call of a problem builds (compiles) its plan -- not inside a stream capture; later calls only
+ *                           launch.  DVMVS_EUNSUPPORTED: MIOpen has no fused plan for the problem; DVMVS_ELIBRARY: a MIOpen call failed.
+ */
+int dvmvs_conv_bias_act_fwd(const float* x, const float* weight, const float* bias, float* out, long long out_batch_stride,
+                            int B, int Cin, int H, int W, int Cout, int K, int stride, int padding, int activation, dvmvs_stream_t stream);
 /*
  *   dvmvs_depthwise_conv_fwd: depthwise convolution (groups == C, weight [C,1,k,k], k in {3,5}, padding k/2, stride 1|2)
  *                           with bias (may be NULL) and activation fused; in [B,C,H,W] -> out [B,C,OH,OW].  The MnasNet

@@ -319,6 +319,30 @@ def test_cost_volume_gradients(ops, dev, golden_dir):
     assert maxerr(bd.grad, bc.grad) < 5e-4 * max(1.0, bc.grad.abs().max().item())
 
 
+def test_convolution_with_its_epilogue_as_one_miopen_plan(ops, dev):
+    """dvmvs_conv_bias_act_fwd (MIOpen fusion plan convolution + bias [+ ReLU]) against torch's convolution + bias + ReLU, into a
+    new tensor and into a channel slice of a larger buffer.  MIOpen may pick a different algorithm (Winograd) than torch's call
+    does: stated bound 1e-4 of the largest output."""
+    g = torch.Generator().manual_seed(5)
+    supported = 0
+    for (cin, cout, h, w, k, stride, act) in ((32, 32, 64, 80, 5, 1, "relu"), (64, 64, 32, 40, 3, 1, "relu"), (16, 24, 20, 28, 3, 1, "none"),
+                                              (32, 64, 32, 40, 3, 2, "relu"), (96, 32, 128, 160, 5, 1, "relu")):
+        x = torch.randn(1, cin, h, w, generator=g).to(dev)
+        wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)
+        b = torch.randn(cout, generator=g).to(dev)
+        exp = torch.nn.functional.conv2d(x, wt, b, stride, k // 2)
+        exp = torch.relu(exp) if act == "relu" else exp
+        got = ops.conv_bias_act_into(x, wt, b, None, stride, k // 2, ops.ACTIVATIONS[act])
+        if got is None:                      # MIOpen has no plan for this problem: the engine keeps the two launches
+            continue
+        supported += 1
+        assert got.shape == exp.shape and maxerr(got, exp) < 1e-4 * exp.abs().max().item(), (cin, cout, k, stride)
+        cat = torch.zeros(1, cout + 5, exp.shape[2], exp.shape[3], device=dev)
+        ops.conv_bias_act_into(x, wt, b, cat[:, 2:2 + cout], stride, k // 2, ops.ACTIVATIONS[act])
+        assert torch.equal(cat[:, 2:2 + cout], got) and float(cat[:, :2].abs().max()) == 0.0 and float(cat[:, 2 + cout:].abs().max()) == 0.0
+    assert supported >= 2
+
+
 def test_cost_volume_gradients_near_the_vanishing_line(ops, dev):
     """The measurement-feature gradient is a gather over the inverse homography of each plane (csrc/cost_volume_bwd.hip); where a
     pixel's 2x2 footprint straddles a plane's vanishing line the inverse is not a search window and the kernel scans the whole
@@ -716,8 +740,8 @@ def test_destination_passing_engine_equals_the_concatenating_one(dev):
     from dvmvs.fusionnet.model import CostVolumeDecoder, CostVolumeEncoder, FeatureExtractor, FeatureShrinker, LSTMFusion
     ctors = (FeatureExtractor, FeatureShrinker, CostVolumeEncoder, LSTMFusion, CostVolumeDecoder)
     mods = syn.build_e2e_modules(ctors)
-    direct = DepthEngine(*mods, device=dev, use_graphs=False)
-    plain = DepthEngine(*mods, device=dev, use_graphs=False)
+    direct = DepthEngine(*mods, device=dev, use_graphs=False, conv_plans=False)
+    plain = DepthEngine(*mods, device=dev, use_graphs=False, conv_plans=False)
     assert direct.direct
     plain.direct = False
     fullK = syn.full_K()
@@ -729,6 +753,36 @@ def test_destination_passing_engine_equals_the_concatenating_one(dev):
         print(f"frame {n}: destination-passing vs concatenating engine, depth rel-L1 {err:.3e}")
         assert err <= 1e-5, (n, err)     # measured 2.6e-6: MIOpen picks per-call algorithms for the differently placed buffers
         assert float((direct._static["h"] - plain._static["h"]).abs().max()) <= 1e-3
+
+
+def test_engine_with_epilogues_inside_miopen_equals_the_two_launch_engine(dev):
+    """DepthEngine(conv_plans=True) -- the default: per convolution problem the epilogue rides inside MIOpen's kernel where that was
+    measured faster at warm-up -- against conv_plans=False (convolution + dvmvs_bias_act_fwd everywhere), eagerly and through the
+    captured graph.  Same convolutions up to MIOpen's choice of algorithm: depth within 1e-5 rel-L1."""
+    from dvmvs.engine import DepthEngine
+    from dvmvs.fusionnet.model import CostVolumeDecoder, CostVolumeEncoder, FeatureExtractor, FeatureShrinker, LSTMFusion
+    ctors = (FeatureExtractor, FeatureShrinker, CostVolumeEncoder, LSTMFusion, CostVolumeDecoder)
+    mods = syn.build_e2e_modules(ctors)
+    planned = DepthEngine(*mods, device=dev, use_graphs=True, conv_plans=True)
+    plain = DepthEngine(*mods, device=dev, use_graphs=True, conv_plans=False)
+    assert planned.conv_plans and not plain.conv_plans
+    fullK = syn.full_K()
+    frames = list(syn.E2E_FRAMES) + [(12, (11, 9)), (13, (12, 10)), (14, (13, 11))]       # the later ones replay the captured graph
+    for n, (r, ms) in enumerate(frames):
+        args = (syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK)
+        a = planned.step(*args, frame_id=r, measurement_ids=list(ms)).clone()
+        b = plain.step(*args, frame_id=r, measurement_ids=list(ms)).clone()
+        err = float(((a - b).abs() / b).mean())
+        print(f"frame {n}: epilogues inside MIOpen vs two launches, depth rel-L1 {err:.3e}")
+        assert err <= 1e-5, (n, err)
+    report = planned.conv_plan_report()
+    chosen = [row for row in report if row[2]]
+    for shape, wshape, use, t_plan, t_two, diff in sorted(report, key=lambda row: -row[4] if row[4] == row[4] else 0):
+        print(f"  in {shape} w {wshape}: plan {t_plan:7.2f} us, two launches {t_two:7.2f} us, max|diff| {diff:.1e} -> {'plan' if use else 'two launches'}")
+    print(f"{len(chosen)} of {len(report)} dense convolution problems take the MIOpen fusion plan")
+    assert report and not plain.conv_plan_report()
+    for row in chosen:
+        assert row[5] <= 1e-3          # against the two-launch result of the same layer
 
 
 def test_cost_volume_backward_is_bit_reproducible(ops, dev):
