@@ -559,15 +559,19 @@ extern "C" int dvmvs_cost_volume_bwd(const float* grad_cost, const float* image1
     case 2: return launch_bwd_meas_tiled<32, 384>(a, B, H, W, D, s);    // 1 channel pass, 50 KB
     case 3: return launch_bwd_meas_tiled<16, 1152>(a, B, H, W, D, s);   // 77 KB: two workgroups per CU
     case 4: return launch_bwd_meas_tiled<16, 576>(a, B, H, W, D, s);    // 38 KB
+    // the gather with other splits of a workgroup (channels per thread, plane groups, channel groups, waves per SIMD); measured
+    // 824 / 684 / 1436 / 1481 / 913 us against the product's 668 us on the training geometry (profiles/r03_bwd_microbench.txt)
     case 6: return launch_bwd_meas_gather<16, 4, 2, 5>(a, B, M, H, W, D, s);
     case 7: return launch_bwd_meas_gather<8, 4, 4, 8>(a, B, M, H, W, D, s);
     case 8: return launch_bwd_meas_gather<32, 4, 1, 3>(a, B, M, H, W, D, s);
-    case 10: return launch_bwd_meas_gather<16, 8, 2, 5>(a, B, M, H, W, D, s);
+    case 10: return launch_bwd_meas_gather<32, 4, 1, 4>(a, B, M, H, W, D, s);
     case 11: return launch_bwd_meas_gather<32, 8, 1, 4>(a, B, M, H, W, D, s);
     default: break;
   }
 #endif
-  if (config == 5) return launch_bwd_meas_gather<32, 4, 1, 4>(a, B, M, H, W, D, s);
+  // 16 channels per thread, 8 plane groups x 2 channel groups = 16 waves per 64 pixels: the kernel is bound by the length of a
+  // wave's chain of dependent gathers, so the planes are spread over as many waves as a workgroup holds
+  if (config == 5) return launch_bwd_meas_gather<16, 8, 2, 5>(a, B, M, H, W, D, s);
   constexpr int kPlanesPerBlock = kBwdPlaneGroups * kBwdPPT;     // the plain global-atomic scatter
   dim3 block(kWave, kBwdPlaneGroups), grid((HW + kWave - 1) / kWave, (D + kPlanesPerBlock - 1) / kPlanesPerBlock, B);
   hipLaunchKernelGGL(cost_volume_bwd_meas_kernel, grid, block, 0, s, a);

@@ -16,6 +16,16 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(dvmvs_[a-z0-9_]+)\s*\(", text)))
 
 
+def declared_parameter_counts():
+    """{symbol: number of parameters} from the header's prototypes (``(void)`` = 0)."""
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    counts = {}
+    for name, params in re.findall(r"\b(dvmvs_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        params = params.strip()
+        counts[name] = 0 if params in ("", "void") else params.count(",") + 1
+    return counts
+
+
 @pytest.fixture(scope="module")
 def library():
     from dvmvs.hip import _capi
@@ -40,6 +50,9 @@ def test_library_exports_every_declared_symbol(library):
 
 def test_binding_table_matches_header(library):
     assert sorted(library.SIGNATURES) == declared_symbols()
+    counts = declared_parameter_counts()
+    for name, (_, argtypes) in library.SIGNATURES.items():
+        assert len(argtypes) == counts[name], f"{name}: {len(argtypes)} ctypes arguments for {counts[name]} declared parameters"
     lib = library.lib()
     assert lib.dvmvs_abi_version() == library.ABI_VERSION
     assert lib.dvmvs_build_arch() == b"gfx950"
