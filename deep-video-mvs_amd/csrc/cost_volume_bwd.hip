@@ -71,23 +71,15 @@ __global__ __launch_bounds__(256) void cost_volume_bwd_ref_kernel(CostVolumeBwdA
     if (k < nch) out[static_cast<size_t>(k) * HW] = acc[k] * scale;
 }
 
-// grad wrt the measurement features.  The adjoint of the bilinear gather is a scatter; done naively it is four fp32
-// atomics per (pixel, plane, channel) into global memory -- 3.7 G device-scope atomics for one training step at
-// 4 x 7 x 256^2 -- which a multi-XCD part serialises at the memory side.  The scatter is therefore PRIVATISED in LDS with
-// the forward kernel's geometry: a workgroup owns a 32x8 reference tile and DP planes; all of its targets lie inside the
-// bounding box of 8 sample positions (see publish_sample_box), and it accumulates into a zero-initialised LDS image of that
-// box with ds_add_f32 (record stride CCH+1 floats: consecutive box positions fall on different banks) and flushes each
-// box element once, coalesced, with a single global atomic.
-//
-// A box of any size is handled on chip: the LDS image holds a WINDOW of whole box rows (CAP positions); the workgroup walks
-// the windows of its box top to bottom, and in each one a sample contributes the tap rows that fall into it (rows are
-// disjoint between windows, so the two rows of a sample may be accumulated in consecutive windows).  Windows nobody samples
-// (the box of eight planes of a wide-baseline pair is a diagonal band) are skipped with one vote.  Round 2 fell back to
-// global atomics whenever four planes of a tile did not fit 768 positions: on the training step's own geometry (frames three
-// apart on the sample scene) that was 10-50 % of the workgroups of a call, and their 128 scattered device-scope atomics per
-// (pixel, plane) were the kernel's time (2.64 ms per call, profiles/r03_train_timed_region.csv).  What still goes straight
-// to global memory: tiles whose box is not well defined (a corner at or behind the measurement camera) and single samples
-// that fall outside the box fitted to the corners (round-off beyond its 0.05 px slack) -- both rare.
+// grad wrt the measurement features, as a SCATTER (rounds 1-3; since the gather kernel further down the product launches this
+// only through the tools-only build, where it is the comparison of tools/cv_bwd_microbench.py, and the plain form below it for
+// degenerate image sizes).  Done naively the adjoint of the bilinear gather is four fp32 atomics per (pixel, plane, channel) into
+// global memory -- 3.7 G device-scope atomics for one training step at 4 x 7 x 256^2 -- which a multi-XCD part serialises at the
+// memory side.  The tiled kernel PRIVATISES the scatter in LDS with the forward kernel's geometry: a workgroup owns a 32x8
+// reference tile and DP planes, accumulates into a zero-initialised LDS image of the bounding box of its sample positions with
+// ds_add_f32 (record stride CCH+1 floats), walking boxes larger than the image in windows of whole rows, and flushes each element
+// once with a single global atomic.  2.67 ms per training call whatever the channel chunk, window size or residency
+// (profiles/r03_other_experiments.md): the LDS float atomic itself is the limit, which is why the product gathers instead.
 constexpr int kBwdPlaneGroups = 4;   // generic fallback geometry (also used when H*W is tiny)
 constexpr int kBwdPPT = 4;
 
@@ -111,6 +103,7 @@ __device__ inline void scatter_sample_global(const CostVolumeArgs& f, const floa
   }
 }
 
+#ifdef DVMVS_SWEEP_TUNING
 template <int TW, int TH, int DP, int CCH, int CAP>
 __global__ __launch_bounds__(TW* TH) void cost_volume_bwd_meas_tiled_kernel(CostVolumeBwdArgs a) {
   constexpr int NT = TW * TH;
@@ -277,6 +270,8 @@ __global__ __launch_bounds__(TW* TH) void cost_volume_bwd_meas_tiled_kernel(Cost
     }
   }
 }
+
+#endif  // DVMVS_SWEEP_TUNING
 
 __global__ __launch_bounds__(256) void cost_volume_bwd_meas_kernel(CostVolumeBwdArgs a) {
   constexpr int kPlanesPerBlock = kBwdPlaneGroups * kBwdPPT;
@@ -491,6 +486,7 @@ static int launch_bwd_meas_gather(const CostVolumeBwdArgs& a, int B, int M, int 
   return launch_status();
 }
 
+#ifdef DVMVS_SWEEP_TUNING
 // Launch of the LDS-privatised scatter: 32x8-pixel tiles x 8 planes per workgroup, CCH channels per pass, CAP box positions in LDS.
 template <int CCH, int CAP>
 static int launch_bwd_meas_tiled(const CostVolumeBwdArgs& a, int B, int H, int W, int D, hipStream_t s) {
@@ -512,7 +508,6 @@ static int launch_bwd_meas_tiled(const CostVolumeBwdArgs& a, int B, int H, int W
   return launch_status();
 }
 
-#ifdef DVMVS_SWEEP_TUNING
 static int g_bwd_tuning_config = -1;   // -1: what the product does
 #endif
 

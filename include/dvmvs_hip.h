@@ -107,8 +107,8 @@ int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, cons
  *   grad_cost   [B,D,H,W]
  *   Hm, kt      as for the forward
  *   grad_image1 [B,C,H,W]   out (overwritten)
- *   grad_image2s host array of M device pointers, each [B,C,H,W]; MUST be zero-filled by the caller
- *               (accumulated with atomics); an entry may be NULL to skip that frame's gradient.
+ *   grad_image2s host array of M device pointers, each [B,C,H,W]; MUST be zero-filled by the caller (the gradient is ADDED to
+ *               it -- by a gather without atomics, so the result is bit-reproducible); an entry may be NULL to skip that frame.
  */
 int dvmvs_cost_volume_bwd(const float* grad_cost, const float* image1, const float* const* image2s,
                           const float* Hm, const float* kt, float* grad_image1, float* const* grad_image2s,
