@@ -35,6 +35,18 @@ std::map<ProblemKey, FusedConvolution> g_problems;
 
 bool ok(miopenStatus_t s) { return s == miopenStatusSuccess; }
 
+// a problem without a usable plan keeps no MIOpen objects (the map entry only remembers the answer)
+void release(FusedConvolution& p) {
+  if (p.plan) miopenDestroyFusionPlan(p.plan);
+  if (p.args) miopenDestroyOperatorArgs(p.args);
+  if (p.conv) miopenDestroyConvolutionDescriptor(p.conv);
+  if (p.x) miopenDestroyTensorDescriptor(p.x);
+  if (p.w) miopenDestroyTensorDescriptor(p.w);
+  if (p.y) miopenDestroyTensorDescriptor(p.y);
+  if (p.bias) miopenDestroyTensorDescriptor(p.bias);
+  p = FusedConvolution();
+}
+
 // conv + bias + activation; for "no activation" first the two-operator plan, then a pass-through activation
 bool build_plan(miopenHandle_t handle, FusedConvolution& p, int activation, bool pass_through) {
   if (!ok(miopenCreateFusionPlan(&p.plan, miopenVerticalFusion, p.x))) return false;
@@ -88,9 +100,13 @@ extern "C" int dvmvs_conv_bias_act_fwd(const float* x, const float* weight, cons
                 ok(miopenInitConvolutionDescriptor(p.conv, miopenConvolution, padding, padding, stride, stride, 1, 1)) &&
                 ok(miopenCreateOperatorArgs(&p.args));
     if (good) {
-      if (!ok(miopenSetStream(handle, static_cast<hipStream_t>(stream)))) return DVMVS_ELIBRARY;
+      if (!ok(miopenSetStream(handle, static_cast<hipStream_t>(stream)))) {
+        release(p);
+        return DVMVS_ELIBRARY;
+      }
       good = build_plan(handle, p, activation, false) || (activation == 0 && build_plan(handle, p, activation, true));
     }
+    if (!good) release(p);
     p.usable = good;
     found = g_problems.emplace(key, p).first;      // failures are remembered too: the answer does not change
   }
