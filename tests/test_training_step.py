@@ -163,10 +163,10 @@ def test_gpu_training_step_matches_cpu_oracle_autograd(hip_device):
 def test_training_step_at_the_config5_size(hip_device):
     """BASELINE.json configs[4] at its stated size: sub-sequences of 8 frames, 4 per GPU, 256x256, 64 planes, batch-norm in
     training mode (fusionnet/run-training.py:184-284).  Too large for a CPU oracle run, so size-independent properties:
-    finite loss, gradient reaching all five modules, the forward pass reproducible to 1e-6 and the backward pass (atomic
-    scatters of the measurement-feature and hidden-state gradients, MIOpen's weight-gradient kernels) to 2e-2, the reference-signature forward_pass agreeing
-    with the bare loss, one Adam step changing the weights -- and the LDS-privatised measurement-gradient scatter of the cost
-    volume checked against autograd through the CPU oracle at this feature size (4096+ pixels select it)."""
+    finite loss, gradient reaching all five modules, the forward pass reproducible to 1e-6 and the backward pass (the atomic
+    scatter of the hidden-state gradient, MIOpen's weight-gradient kernels) to 2e-2, the reference-signature forward_pass agreeing
+    with the bare loss, one Adam step changing the weights -- and the measurement-gradient gather kernel of the cost
+    volume checked against autograd through the CPU oracle at this feature size."""
     import dvmvs_oracle as orc
     from dvmvs.config import Config
     from dvmvs.fusionnet.model import CostVolumeDecoder, CostVolumeEncoder, FeatureExtractor, FeatureShrinker, LSTMFusion
@@ -215,7 +215,7 @@ def test_training_step_at_the_config5_size(hip_device):
     out = train_step(model, opt, reducer, images, depths, poses, K)
     assert torch.isfinite(out) and not torch.equal(before, params[-1].detach())
 
-    # measurement-feature gradient of the cost volume at the training feature size (128 x 128): HIP (LDS-privatised scatter)
+    # measurement-feature gradient of the cost volume at the training feature size (128 x 128): HIP (gather over the planes' inverse homographies)
     # against autograd through the CPU oracle
     f1 = syn.smooth_noise((2, 32, 128, 128), seed=811).requires_grad_(True)
     f2 = syn.smooth_noise((2, 32, 128, 128), seed=812).requires_grad_(True)

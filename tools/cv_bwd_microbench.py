@@ -1,4 +1,4 @@
-"""Times dvmvs_cost_volume_bwd (the measurement-feature gradient = the LDS-privatised scatter) on the training step's own
+"""Times dvmvs_cost_volume_bwd (the measurement-feature gradient; gather kernel, scatter kernels for comparison) on the training step's own
 geometry: B=4, C=32, 128x128 features, 64 planes, one measurement frame, pose pairs three frames apart on the sample scene
 (the pairs bench.py --mode train feeds; BASELINE.json configs[4]).  Run on the GPU box:
 
