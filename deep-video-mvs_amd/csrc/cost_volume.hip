@@ -6,6 +6,16 @@
 // Semantics: /root/reference/dvmvs/utils.py:45-107 (see oracle/dvmvs_oracle.py for the CPU restatement).
 #include "plane_sweep.h"
 
+// coefficients of dvmvs::sweep_model_us (us; per-workgroup statistics), fitted by tools/sweep_select_fit.py
+#define SWEEP_MODEL_BASE_DEFAULT 14.0
+#define SWEEP_MODEL_RUN_DEFAULT 2.2
+#define SWEEP_MODEL_RECORD_DEFAULT 0.004
+#define SWEEP_MODEL_SPILL_DEFAULT 60.0
+#define SWEEP_MODEL_BASE_WIDE 22.0
+#define SWEEP_MODEL_RUN_WIDE 2.2
+#define SWEEP_MODEL_RECORD_WIDE 0.004
+#define SWEEP_MODEL_SPILL_WIDE 60.0
+
 namespace dvmvs {
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -100,7 +110,23 @@ int launch_cost_volume_generic(const CostVolumeArgs& a, bool dot, hipStream_t st
 // sweep_tiled.hip
 size_t sweep_spill_words(int B, int M, int H, int W, int D);
 int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream);
+int launch_sweep_wide(const CostVolumeArgs& a, hipStream_t stream);
+void sweep_plan_stats_host(int configuration, const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,
+                           long long* stats);
 int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream);
+
+// predicted duration (us) of the sweep + second pass in one configuration from its plan statistics; coefficients: see
+// dvmvs_sweep_select_variant.  Work is counted per workgroup slot of the chip so that the model carries over to other shapes.
+inline double sweep_model_us(int configuration, const long long* st, int B, int H, int W, int D) {
+  static const double kBase[2] = {SWEEP_MODEL_BASE_DEFAULT, SWEEP_MODEL_BASE_WIDE};
+  static const double kPerRun[2] = {SWEEP_MODEL_RUN_DEFAULT, SWEEP_MODEL_RUN_WIDE};
+  static const double kPerRecord[2] = {SWEEP_MODEL_RECORD_DEFAULT, SWEEP_MODEL_RECORD_WIDE};
+  static const double kPerSpilledPlane[2] = {SWEEP_MODEL_SPILL_DEFAULT, SWEEP_MODEL_SPILL_WIDE};
+  const double scale = 1.0 / 640.0;   // statistics per workgroup of the 128x160x64 shape the model was fitted on
+  (void)B; (void)H; (void)W; (void)D;
+  return kBase[configuration] + scale * (kPerRun[configuration] * static_cast<double>(st[0]) + kPerRecord[configuration] * static_cast<double>(st[1]) +
+                                         kPerSpilledPlane[configuration] * static_cast<double>(st[4]));
+}
 
 }  // namespace dvmvs
 
@@ -116,8 +142,8 @@ extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* im
                                      float* workspace, size_t workspace_bytes, dvmvs_stream_t stream) {
   using namespace dvmvs;
   if (image2_layout != DVMVS_LAYOUT_NCHW && image2_layout != DVMVS_LAYOUT_NHWC) return DVMVS_EINVAL;
-  if (variant < 0 || (variant > 2 && variant < 32) || variant > 255) return DVMVS_EINVAL;
-  if (variant == 2 && !dot_product) return DVMVS_EUNSUPPORTED;
+  if (variant < 0 || (variant > 3 && variant < 32) || variant > 255) return DVMVS_EINVAL;
+  if ((variant == 2 || variant == 3) && !dot_product) return DVMVS_EUNSUPPORTED;
   CostVolumeArgs a;
   const int rc = fill_sweep_args(&a, image1, image2s, Hm, kt, cost_volume, B, M, C, H, W, D, min_depth, max_depth, true);
   if (rc != 0) return rc;
@@ -135,9 +161,34 @@ extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* im
   }
   // the tiled sweep addresses the maps through 32-bit buffer offsets: one batch item of one map must stay below 2 GiB
   const bool fits = static_cast<long long>(C) * H * W * 4 < (1LL << 31);
-  const bool tiled = dot_product && fits && (variant == 2 || a.image2_nhwc || (variant == 0 && H * W >= 64 * 64));
-  if (variant == 2 && !fits) return DVMVS_EUNSUPPORTED;
+  const bool tiled = dot_product && fits && (variant == 2 || variant == 3 || a.image2_nhwc || (variant == 0 && H * W >= 64 * 64));
+  if ((variant == 2 || variant == 3) && !fits) return DVMVS_EUNSUPPORTED;
   if (a.image2_nhwc && !fits) return DVMVS_EUNSUPPORTED;
+  if (tiled && variant == 3) return launch_sweep_wide(a, s);
   if (tiled) return launch_sweep_default(a, s);
   return launch_cost_volume_generic(a, dot_product != 0, s);
+}
+
+// Host-side model of the LDS-tiled sweep's run plan for HOST copies of the matrices (no HIP call): see sweep_tiled.hip.
+extern "C" int dvmvs_sweep_plan_stats(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
+                                      double min_depth, double max_depth, int configuration, long long* stats) {
+  if (!Hm_host || !kt_host || !stats || B <= 0 || M <= 0 || H <= 0 || W <= 0 || D <= 0) return DVMVS_EINVAL;
+  if (M > DVMVS_MAX_MEASUREMENTS || D > DVMVS_MAX_DEPTH_LEVELS) return DVMVS_EUNSUPPORTED;
+  if (!(min_depth > 0.0) || !(max_depth > 0.0) || (configuration != 0 && configuration != 1)) return DVMVS_EINVAL;
+  const double inv_base = 1.0 / max_depth, inv_step = D > 1 ? (1.0 / min_depth - 1.0 / max_depth) / (D - 1) : 0.0;
+  dvmvs::sweep_plan_stats_host(configuration, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, stats);
+  return 0;
+}
+
+// Which configuration of the LDS-tiled sweep for this keyframe pair: a linear cost model over the plan statistics of both
+// configurations, fitted to per-pair timings of both on all 286 keyframe pairs of the sample scene (tools/sweep_select_fit.py;
+// profiles/r04_sweep_select_fit.md).  Deterministic in the matrices (IEEE fp32 / integer arithmetic only).
+extern "C" int dvmvs_sweep_select_variant(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
+                                          double min_depth, double max_depth) {
+  long long d[6], w[6];
+  int rc = dvmvs_sweep_plan_stats(Hm_host, kt_host, B, M, H, W, D, min_depth, max_depth, 0, d);
+  if (rc != 0) return rc;
+  rc = dvmvs_sweep_plan_stats(Hm_host, kt_host, B, M, H, W, D, min_depth, max_depth, 1, w);
+  if (rc != 0) return rc;
+  return dvmvs::sweep_model_us(0, d, B, H, W, D) <= dvmvs::sweep_model_us(1, w, B, H, W, D) ? 2 : 3;
 }

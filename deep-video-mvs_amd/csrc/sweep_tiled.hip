@@ -53,7 +53,7 @@ struct SweepRay {
   float X0, Y0, Z0;
 };
 
-__device__ inline SweepRay sweep_ray(const float* Hm, float xf, float yf) {
+__host__ __device__ inline SweepRay sweep_ray(const float* Hm, float xf, float yf) {
   SweepRay r;
   r.X0 = fmaf(Hm[2], 1.0f, fmaf(Hm[1], yf, Hm[0] * xf));
   r.Y0 = fmaf(Hm[5], 1.0f, fmaf(Hm[4], yf, Hm[3] * xf));
@@ -160,7 +160,7 @@ __device__ inline int sweep_lane_pixel(int lane32) {
   return lane32 < 4 ? lane32 : lane32 < 12 ? lane32 + 12 : lane32 < 16 ? lane32 - 8 : lane32 < 20 ? lane32 + 8 : lane32 < 28 ? lane32 - 12 : lane32;
 }
 
-__device__ inline int sweep_pitch_residue(float ax, float ay) {
+__host__ __device__ inline int sweep_pitch_residue(float ax, float ay) {
   const float aax = fabsf(ax), aay = fabsf(ay);
   const float c = ceilf(15.0f * aax), r = ceilf(15.0f * aay);
   const float cost0 = 15.0f * aay * fmaxf(0.0f, 1.0f - aax) + fmaxf(0.0f, c - 15.0f);   // rows change while a column repeats
@@ -878,6 +878,102 @@ __global__ __launch_bounds__(Cfg::NPIX) void sweep_spill_kernel(CostVolumeArgs a
   }
 }
 
+// ---- host-side model of the run plan --------------------------------------------------------------------------------------
+// plan_runs restated for the HOST (no HIP call, no device memory): the caller's matrices are on the host before the launch (ABI 3),
+// so which sweep configuration suits a keyframe pair can be decided there, without a device round trip.  Same candidates, same box
+// rule, same greedy choice; the sample positions use IEEE fp32 division, which is what the kernel's refined-reciprocal sequence
+// produces for normal operands, so the model's plan is the kernel's plan (it only has to be close: it selects a configuration, it
+// does not change any configuration's results).  stats[0..5]: staged runs, LDS records of all staged runs, runs entirely outside
+// the image, runs queued for the second pass, their planes (second-pass gathers per pixel), workgroups with at least one queued run.
+#pragma clang fp contract(off)
+inline void host_sweep_position(const SweepRay& r, float kx, float ky, float kz, const SweepScale& s, float* ix, float* iy, float* denom_out) {
+  const float denom = (r.Z0 + kz) + 1e-8f;
+  *denom_out = denom;
+  const float u = (r.X0 + kx) / denom, v = (r.Y0 + ky) / denom;
+  *ix = ((((u - s.wn) / s.wn) + 1.0f) * 0.5f) * s.Wm1;
+  *iy = ((((v - s.hn) / s.hn) + 1.0f) * 0.5f) * s.Hm1;
+}
+
+template <class Cfg>
+void host_plan_stats(const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step, long long* stats) {
+  constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP, CAP = Cfg::CAP, MINSEG = Cfg::MINSEG;
+  SweepScale sc;
+  sc.Wf = static_cast<float>(W); sc.Hf = static_cast<float>(H);
+  sc.wn = sc.Wf * 0.5f; sc.hn = sc.Hf * 0.5f;
+  sc.r_wn = 1.0f / sc.wn; sc.r_hn = 1.0f / sc.hn;
+  sc.Wm1 = static_cast<float>(W - 1); sc.Hm1 = static_cast<float>(H - 1);
+  for (int i = 0; i < 6; ++i) stats[i] = 0;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, chunks = (D + DP - 1) / DP;
+  for (int b = 0; b < B; ++b)
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+      const int d_block = chunk * DP, planes = D - d_block < DP ? D - d_block : DP;
+      float ktd[DVMVS_MAX_MEASUREMENTS][DP][3];
+      for (int m = 0; m < M; ++m)
+        for (int j = 0; j < planes; ++j) {
+          const float depth = static_cast<float>(1.0 / (inv_base + static_cast<double>(d_block + j) * inv_step));
+          for (int k = 0; k < 3; ++k) ktd[m][j][k] = kt[(static_cast<size_t>(b) * M + m) * 3 + k] / depth;
+        }
+      for (int tile_y = 0; tile_y < tiles_y; ++tile_y)
+        for (int tile_x = 0; tile_x < tiles_x; ++tile_x) {
+          const int x_first = tile_x * TW, x_last = x_first + TW - 1 < W - 1 ? x_first + TW - 1 : W - 1;
+          const int y_first = tile_y * TH, y_last = y_first + TH - 1 < H - 1 ? y_first + TH - 1 : H - 1;
+          const float edge = static_cast<float>(x_last - x_first > 1 ? x_last - x_first : 1);
+          bool group_spills = false;
+          for (int m = 0; m < M; ++m) {
+            const float* Hm_m = Hm + (static_cast<size_t>(b) * M + m) * 9;
+            SweepRay ray[4];
+            for (int c = 0; c < 4; ++c)
+              ray[c] = sweep_ray(Hm_m, static_cast<float>((c & 1) ? x_last : x_first), static_cast<float>((c & 2) ? y_last : y_first));
+            int lo = 0, hint = DP;
+            while (lo < planes) {
+              const int len0 = planes - lo < hint ? planes - lo : hint;
+              int picked_len = len0, picked_state = 0, picked_records = 0;
+              for (int candidate = 0; candidate < 4; ++candidate) {
+                int len = len0;
+                for (int i = 0; i < candidate; ++i) len = (len + 1) / 2 > MINSEG ? (len + 1) / 2 : MINSEG;
+                if (len > len0) len = len0;
+                float lo_x = 0, hi_x = 0, lo_y = 0, hi_y = 0, top[2][2] = {{0, 0}, {0, 0}};
+                bool finite = true;
+                for (int corner = 0; corner < 8; ++corner) {
+                  const float* k = ktd[m][(corner & 4) ? lo + len - 1 : lo];
+                  float ux, uy, denom;
+                  host_sweep_position(ray[corner & 3], k[0], k[1], k[2], sc, &ux, &uy, &denom);
+                  finite = finite && (ux > -1e6f) && (ux < 1e6f) && (uy > -1e6f) && (uy < 1e6f) && (denom > 1e-6f);
+                  if (corner < 2) { top[corner][0] = ux; top[corner][1] = uy; }
+                  if (corner == 0) { lo_x = hi_x = ux; lo_y = hi_y = uy; }
+                  else { lo_x = fminf(lo_x, ux); hi_x = fmaxf(hi_x, ux); lo_y = fminf(lo_y, uy); hi_y = fmaxf(hi_y, uy); }
+                }
+                const bool outside = (hi_x + 0.05f <= -1.0f) || (lo_x - 0.05f >= sc.Wf) || (hi_y + 0.05f <= -1.0f) || (lo_y - 0.05f >= sc.Hf);
+                int state = 0, records = 0;
+                if (finite && outside) state = 2;
+                else if (finite) {
+                  const int bx_lo = static_cast<int>(floorf(fmaxf(lo_x - 0.05f, -1.0f))), by_lo = static_cast<int>(floorf(fmaxf(lo_y - 0.05f, -1.0f)));
+                  const int x_lo = bx_lo > -1 ? bx_lo : -1, y_lo = by_lo > -1 ? by_lo : -1;
+                  const int bx_hi = static_cast<int>(floorf(fminf(hi_x + 0.05f, sc.Wf))), by_hi = static_cast<int>(floorf(fminf(hi_y + 0.05f, sc.Hf)));
+                  const int x_hi = (bx_hi < W ? bx_hi : W) + 1, y_hi = (by_hi < H ? by_hi : H) + 1;
+                  const int RW = x_hi - x_lo + 1, RH = y_hi - y_lo + 1;
+                  const int pitch = RW + ((sweep_pitch_residue((top[1][0] - top[0][0]) / edge, (top[1][1] - top[0][1]) / edge) - RW) & 15);
+                  records = pitch * RH;
+                  state = records <= CAP ? 1 : 0;
+                }
+                if (state != 0 || len <= MINSEG || candidate == 3) {
+                  picked_len = len; picked_state = state; picked_records = records;
+                  break;
+                }
+              }
+              if (picked_state == 1) { ++stats[0]; stats[1] += picked_records; }
+              else if (picked_state == 2) ++stats[2];
+              else { ++stats[3]; stats[4] += picked_len; group_spills = true; }
+              lo += picked_len;
+              hint = picked_len > MINSEG ? picked_len : MINSEG;
+            }
+          }
+          if (group_spills) ++stats[5];
+        }
+    }
+}
+#pragma clang fp contract(fast)
+
 // ---- launch ------------------------------------------------------------------------------------------------------------
 constexpr int kMaxDevices = 64;
 constexpr int kSpillGrid = 1024;  // second-pass workgroups, grid-stride over the queued units: four per CU hide the gather's latency (one per
@@ -948,6 +1044,19 @@ size_t sweep_spill_words(int B, int M, int H, int W, int D) {
 }
 
 int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream) { return launch_sweep_tiled<SweepDefault>(a, stream); }
+
+// the wide-baseline configuration: the same 32x8x8 tiling (same spill workspace), 72 KB boxes, planes split over two thread groups of
+// one 512-thread workgroup (two per CU).  Runs that the default configuration has to halve or queue for the second pass are staged
+// whole: -30 us on wide-baseline / forward-motion pairs, +7 us on easy sideways pairs (profiles/r03_sweep_experiment_log.md section 3),
+// so the caller picks per keyframe pair (dvmvs_sweep_select_variant: the host-side plan model below).
+using SweepWide = SweepConfig<32, 8, 8, 8, 1536, 2, 4, 2, 2, true, true, 2>;
+int launch_sweep_wide(const CostVolumeArgs& a, hipStream_t stream) { return launch_sweep_tiled<SweepWide>(a, stream); }
+
+void sweep_plan_stats_host(int configuration, const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,
+                           long long* stats) {
+  if (configuration == 1) host_plan_stats<SweepWide>(Hm, kt, B, M, H, W, D, inv_base, inv_step, stats);
+  else host_plan_stats<SweepDefault>(Hm, kt, B, M, H, W, D, inv_base, inv_step, stats);
+}
 
 #ifdef DVMVS_SWEEP_TUNING   // tools-only builds (`make tuning`, `make trace`); the product library carries the shipped configuration only
 // tuning configurations for tools/cv_microbench.py: <TW, TH, DP, CCH, CAP, MINSEG, WAVES, ORDER, PRE, PLAN0, FASTFULL>.  All use the 32x8x8

@@ -119,8 +119,9 @@ class FusedConv2d(nn.Module):
         self.register_buffer("_no_bias", torch.empty(0, device=conv.weight.device), persistent=False)
         self.defer_epilogue = False      # set by fuse_epilogues: the next (depthwise) layer applies this layer's bias + ReLU
         self.pre_bias = None             # set by fuse_epilogues on that depthwise layer: the deferred bias
-        # Epilogue inside MIOpen's kernel (dvmvs_conv_bias_act_fwd): decided per input shape by timing both forms the first time
-        # the shape is seen outside a stream capture; {input shape: (use the plan, plan us, two-launch us, max |difference|)}
+        # Epilogue inside MIOpen's kernel (dvmvs_conv_bias_act_fwd): decided per input shape the first time the shape is seen outside a
+        # stream capture -- taken only when its output is BIT-IDENTICAL to convolution + epilogue (the Winograd case) and it is faster;
+        # {input shape: (use the plan, plan us, two-launch us, max |difference|)}
         self.plan_epilogue = False       # set by DepthEngine(conv_plans=True)
         self.plans = {}
 
@@ -134,6 +135,9 @@ class FusedConv2d(nn.Module):
         is the destination (default: the convolution's own output buffer); ``activation`` overrides the layer's; ``raw`` returns
         the convolution output without the epilogue (the consumer applies it: up-sampler, depthwise kernel)."""
         act = self.activation if activation is None else activation
+        if (self.defer_epilogue or raw) and (out is not None or residual is not None or (activation is not None and not raw)):
+            raise RuntimeError("this layer hands over its RAW convolution output (its consumer applies bias + activation): "
+                               "out=, residual= and an activation override would be silently ignored")
         if self.depthwise and residual is None and out is None:
             pre = self.pre_bias
             return _ops.depthwise_conv(x, self.weight, self.bias if self.bias is not None else self._no_bias, self.stride[0], act,
@@ -169,7 +173,10 @@ class FusedConv2d(nn.Module):
 
 
     def _time_plan(self, x, act):
-        """(use the MIOpen fusion plan for this input shape?, plan us, convolution + epilogue us, max |difference|)."""
+        """(use the MIOpen fusion plan for this input shape?, plan us, convolution + epilogue us, max |difference|).
+        The plan is used only when its result is bit-identical to the two-launch form on this input AND faster: which of two
+        differently-rounded fp32 results a layer produces must not depend on a timing (the timing then only decides
+        between two ways of computing the same bits)."""
         with torch.no_grad():
             probe = _ops.conv_bias_act_into(x, self.weight, self.bias, None, self.stride[0], self.padding[0], act)
             if probe is None:
@@ -182,7 +189,7 @@ class FusedConv2d(nn.Module):
             difference = float((two_launches() - probe).abs().max())
             t_two = _graph_microseconds(two_launches)
             t_plan = _graph_microseconds(lambda: _ops.conv_bias_act_into(x, self.weight, self.bias, probe, self.stride[0], self.padding[0], act))
-        return (t_plan < t_two, t_plan, t_two, difference)
+        return (difference == 0.0 and t_plan < t_two, t_plan, t_two, difference)
 
 
 def fuse_epilogues(module):
@@ -294,7 +301,9 @@ class DepthEngine:
         self._feature_cache = OrderedDict()
         self._graphs = {}
         self._static = None
+        self._direct_buffers = {}
         self._warm = set()
+        self.sweep_variant_counts = {}     # frames per sweep configuration (dvmvs_cost_volume_fwd's variant) since construction
         self.reset()
 
     def conv_plan_report(self):
@@ -321,6 +330,8 @@ class DepthEngine:
             if self._static is not None:
                 for k in ("h", "c", "prev_depth"):
                     self._static[k].zero_()
+                if self._direct_buffers:      # the splat's all-zero z-buffer invariant, also after a frame that failed half-way
+                    self._direct_buffers["zbuffer"].zero_()
         else:
             self._no_previous[sequence] = True
             if self._static is not None:
@@ -338,7 +349,7 @@ class DepthEngine:
         s["h"].copy_(hidden.reshape(s["h"].shape))
         s["c"].copy_(cell.reshape(s["c"].shape))
         s["prev_depth"].copy_(previous_depth.reshape(S, 1, self.height, self.width))
-        self._prev_pose_host = _pose_algebra._host(previous_pose).reshape(S, 4, 4).clone().float()
+        self._prev_pose_host = _pose_algebra.to_host(previous_pose).reshape(S, 4, 4).clone().float()
         self._no_previous[:] = False
         self.has_previous = True
 
@@ -393,6 +404,8 @@ class DepthEngine:
             view = lambda name, *shape: params[self._param_offsets[name][0]:self._param_offsets[name][0] + self._param_offsets[name][1]].view(*shape)
             direct = {}
             if self.direct:
+                if self.n_depth_levels != 64:
+                    raise ValueError("the destination-passing frame body is laid out for the network's 64 sweep planes")
                 hc = 32
                 direct = dict(enc_cat=[z(1, 32 + 64, H // 2, W // 2), z(1, 32 + 2 * hc, H // 4, W // 4), z(1, 32 + 4 * hc, H // 8, W // 8),
                                        z(1, 32 + 8 * hc, H // 16, W // 16)],
@@ -427,7 +440,7 @@ class DepthEngine:
         the device with ONE asynchronous copy out of a pinned staging slot.  The slot's previous copy (issued _STAGING_SLOTS
         frames ago) must have executed before it is overwritten: its event is waited for, which never blocks in practice."""
         S = self.sequences
-        host = _pose_algebra._host
+        host = _pose_algebra.to_host
         pose, full_K = host(pose).reshape(S, 4, 4), host(full_K).reshape(S, 3, 3)
         measurement_poses = [host(p).reshape(S, 4, 4) for p in measurement_poses]
         half_K, lstm_K = full_K.clone(), full_K.clone()
@@ -446,10 +459,13 @@ class DepthEngine:
             flat = tensor.reshape(-1)
             staging[o:o + flat.numel()].copy_(flat)
 
+        sweep_variant = _utils.COST_VOLUME_VARIANT
         if self.pose_algebra == "reference":
             Hm, kt = _pose_algebra.sweep_matrices_host(pose, measurement_poses, half_K)
             put("Hm", Hm)
             put("kt", kt)
+            # which sweep configuration suits this keyframe geometry: decided here, on the host copies (one graph per configuration)
+            sweep_variant = _utils.sweep_variant((Hm, kt), self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth)
             if self.is_fusionnet:
                 eye = torch.eye(4).expand(S, 4, 4)
                 if bool(self._no_previous.all()):      # nothing to relate to: the identity, exactly (see above)
@@ -466,10 +482,10 @@ class DepthEngine:
         put("pose", pose)
         put("prev_pose", previous)
         put("meas_pose", torch.stack(measurement_poses))
-        self._static["params"].copy_(staging, non_blocking=True)
-        event.record()
-        self._prev_pose_host = pose.clone()
-        self._no_previous[:] = False
+        with torch.cuda.device(self.device):     # the ring guard must be recorded on the engine's device, whichever is current
+            self._static["params"].copy_(staging, non_blocking=True)
+            event.record(torch.cuda.current_stream(self.device))
+        return pose.clone(), sweep_variant      # step() commits the pose as the previous one once the frame has been launched
 
     # ---- destination-passing frame body (one sequence) ------------------------------------------------------------------
     def _fpn_direct(self, taps, outs):
@@ -495,7 +511,7 @@ class DepthEngine:
     def _upsampled_depth_head(head, x, dst):
         _ops.upsample2x_into(head[0](x, raw=True), dst, head[0].bias, _ops.ACTIVATIONS["sigmoid"])
 
-    def _frame_body_direct(self, n_meas, has_previous):
+    def _frame_body_direct(self, n_meas, has_previous, sweep_variant=0):
         s, d = self._static, self._direct_buffers
         enc_cat, dec_cat = d["enc_cat"], d["dec_cat"]
         # features: MnasNet taps -> FPN, each used output into the front of its encoder concatenation buffer
@@ -503,8 +519,7 @@ class DepthEngine:
         Hm, kt = self._sweep_views(n_meas)
         if self.pose_algebra == "exact":
             Hm, kt = _ops.sweep_matrices(s["pose"], s["meas_pose"][:n_meas], s["half_K"])
-        _ops.cost_volume_into(s["ref_half"], s["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, enc_cat[0][:, 32:],
-                              _utils.COST_VOLUME_VARIANT)
+        _ops.cost_volume_into(s["ref_half"], s["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, enc_cat[0][:, 32:], sweep_variant)
         # encoder: aggregator output = skip connection, written where the decoder will read it
         enc, dec = self.enc, self.dec
         x = None
@@ -549,10 +564,10 @@ class DepthEngine:
         dec.depth_layer_full[0](refined, out=s["prev_depth"], activation=_ops.ACTIVATION_SIGMOID_TO_DEPTH,
                                 p0=dec.inverse_depth_multiplier, p1=dec.inverse_depth_base)
 
-    def _frame_body(self, n_meas, has_previous):
+    def _frame_body(self, n_meas, has_previous, sweep_variant=0):
         """The per-frame computation on the static buffers (this is what gets captured into a hipGraph)."""
         if self.direct:
-            return self._frame_body_direct(n_meas, has_previous)
+            return self._frame_body_direct(n_meas, has_previous, sweep_variant)
         s = self._static
         feats = self._features(s["image"])
         ref_half = feats[0].contiguous()
@@ -562,7 +577,7 @@ class DepthEngine:
         if exact:
             Hm, kt = _ops.sweep_matrices(s["pose"], s["meas_pose"][:n_meas], s["half_K"])
         cost_volume = _ops.cost_volume(ref_half, s["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, self.n_depth_levels,
-                                       True, _utils.COST_VOLUME_VARIANT)
+                                       True, sweep_variant)
         skip0, skip1, skip2, skip3, bottom = self.enc(ref_half, feats[1], feats[2], feats[3], cost_volume)
         if self.is_fusionnet:
             if has_previous:
@@ -619,21 +634,30 @@ class DepthEngine:
         for mid, half in fresh:
             self._remember(mid, half)
         s["image"].copy_(reference_image)
-        self._upload_frame_parameters(n_meas, reference_pose, measurement_poses, full_K)
+        committed_pose, sweep_variant = self._upload_frame_parameters(n_meas, reference_pose, measurement_poses, full_K)
 
         # S > 1: always the previous-state path (see the class docstring); S == 1: the reference's two frame kinds
-        key = (n_meas, (self.has_previous or self.sequences > 1) and self.is_fusionnet)
+        kind = (n_meas, (self.has_previous or self.sequences > 1) and self.is_fusionnet)
+        key = kind + (sweep_variant,)
+        self.sweep_variant_counts[sweep_variant] = self.sweep_variant_counts.get(sweep_variant, 0) + 1
         if not self.use_graphs:
             self._frame_body(*key)
-        elif key not in self._warm:
-            # first occurrence: run eagerly (lets MIOpen pick its solvers); state buffers are updated by the body, so
-            # this is a real frame, not a throw-away
+        elif kind not in self._warm:
+            # first occurrence of this kind of frame: run eagerly (lets MIOpen pick its solvers, times the fusion plans); state
+            # buffers are updated by the body, so this is a real frame, not a throw-away
             self._frame_body(*key)
-            self._warm.add(key)
+            self._warm.add(kind)
         else:
             if key not in self._graphs:
-                self._graphs[key] = self._capture(key)
+                # one graph per sweep configuration, both captured the first time the kind is replayed (capture records launches, it
+                # executes nothing): a later frame whose geometry asks for the other configuration finds its graph ready
+                variants = {sweep_variant} | ({2, 3} if sweep_variant in (2, 3) else set())
+                for v in sorted(variants):
+                    if kind + (v,) not in self._graphs:
+                        self._graphs[kind + (v,)] = self._capture(kind + (v,))
             self._graphs[key].replay()
+        self._prev_pose_host = committed_pose
+        self._no_previous[:] = False
         self.has_previous = True
         if self.cache_features and frame_id is not None:
             self._remember(frame_id, s["ref_half"].clone())

@@ -38,6 +38,9 @@ SIGNATURES = {
     "dvmvs_cost_volume_fwd": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fp, _c_fp,
                                        _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                        _c_dbl, _c_dbl, _c_int, _c_int, _c_int, _c_fp, ctypes.c_size_t, _c_stream]),
+    "dvmvs_sweep_plan_stats": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _c_dbl, _c_int,
+                                        ctypes.POINTER(ctypes.c_longlong)]),
+    "dvmvs_sweep_select_variant": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _c_dbl]),
     "dvmvs_cost_volume_bwd": (_c_int, [_c_fp, _c_fp, _c_fpp, _c_fp, _c_fp, _c_fp, _c_fpp,
                                        _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                        _c_dbl, _c_dbl, _c_stream]),

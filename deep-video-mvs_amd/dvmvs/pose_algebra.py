@@ -27,6 +27,7 @@ This is host-side set-up of a few 4x4 products, not a fallback of the hot path: 
 HIP kernels, which raise if the library is missing.
 """
 import os
+import warnings
 from typing import List, Sequence, Tuple
 
 import torch
@@ -44,8 +45,25 @@ def _mode(mode):
     return mode
 
 
-def _host(t: torch.Tensor) -> torch.Tensor:
-    return t if t.device.type == "cpu" else t.cpu()
+_WARNED_DEVICE_POSES = False
+
+
+def to_host(t: torch.Tensor) -> torch.Tensor:
+    """``t`` as a host tensor.  A device tensor is copied back, which synchronises the device: poses and intrinsics come from
+    the host (``poses.txt``, a tracker) and should be handed over as host tensors; the first device tensor seen in "reference"
+    mode is reported once (``DVMVS_POSE_ALGEBRA=exact`` keeps everything on the device instead)."""
+    global _WARNED_DEVICE_POSES
+    if t.device.type == "cpu":
+        return t
+    if not _WARNED_DEVICE_POSES:
+        _WARNED_DEVICE_POSES = True
+        warnings.warn("dvmvs.pose_algebra (mode 'reference'): a pose / intrinsics tensor lives on the device and is copied back to "
+                      "the host for the reference's fp32 pose algebra -- a device synchronisation per call; pass host tensors, or "
+                      "use DVMVS_POSE_ALGEBRA=exact", RuntimeWarning, stacklevel=3)
+    return t.cpu()
+
+
+_host = to_host      # (older name, kept for callers inside the package)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -73,15 +91,36 @@ def sweep_matrices_host(pose1: torch.Tensor, pose2s: Sequence[torch.Tensor], K: 
     return torch.stack(Hm, dim=1).contiguous(), torch.stack(kt, dim=1).contiguous()
 
 
+def sweep_variant_host(Hm: torch.Tensor, kt: torch.Tensor, height: int, width: int, n_depth_levels: int, min_depth: float, max_depth: float) -> int:
+    """Which configuration of the LDS-tiled sweep suits this keyframe geometry: 2 (default: 48 KB sample boxes, three 256-thread
+    workgroups per CU) or 3 (wide-baseline: 72 KB boxes, 512-thread workgroups).  Decided on the HOST from the host copies of the
+    matrices (``Hm`` [B,M,9], ``kt`` [B,M,3], as ``sweep_matrices_host`` returns them) by the library's model of the kernel's run
+    plan (``dvmvs_sweep_select_variant``, include/dvmvs_hip.h: a few hundred flops per workgroup, ~20 us) -- no device round trip.
+    Either configuration is bit-reproducible; the choice is a deterministic function of the matrices."""
+    from dvmvs.hip import _capi
+    Hm, kt = Hm.contiguous(), kt.contiguous()
+    if Hm.device.type != "cpu" or Hm.dtype != torch.float32 or kt.dtype != torch.float32:
+        raise ValueError("sweep_variant_host needs the float32 HOST copies of the sweep matrices")
+    variant = _capi.lib().dvmvs_sweep_select_variant(Hm.data_ptr(), kt.data_ptr(), Hm.shape[0], Hm.shape[1], int(height), int(width),
+                                                     int(n_depth_levels), float(min_depth), float(max_depth))
+    if variant < 0:
+        _capi.check(variant, "dvmvs_sweep_select_variant")
+    return variant
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # public: matrices on the device the kernels run on
 # ----------------------------------------------------------------------------------------------------------------------
-def sweep_matrices(pose1, pose2s, K, device, mode=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Sweep constants of ``cost_volume_fusion`` as device tensors (Hm [B,M,9], kt [B,M,3]) on ``device``."""
+def sweep_matrices(pose1, pose2s, K, device, mode=None, with_host=False):
+    """Sweep constants of ``cost_volume_fusion`` as device tensors (Hm [B,M,9], kt [B,M,3]) on ``device``; with ``with_host`` also
+    their host copies (None in "exact" mode, where they never exist on the host) for ``sweep_variant_host``."""
     pose2s = list(pose2s)
     if _mode(mode) == "reference":
         Hm, kt = sweep_matrices_host(_host(pose1), [_host(p) for p in pose2s], _host(K))
-        return Hm.to(device), kt.to(device)
+        return (Hm.to(device), kt.to(device), (Hm, kt)) if with_host else (Hm.to(device), kt.to(device))
+    if with_host:
+        from dvmvs.hip import ops
+        return ops.sweep_matrices(pose1.to(device), [p.to(device) for p in pose2s], K.to(device)) + (None,)
     from dvmvs.hip import ops
     return ops.sweep_matrices(pose1.to(device), [p.to(device) for p in pose2s], K.to(device))
 

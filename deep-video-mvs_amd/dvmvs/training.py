@@ -18,7 +18,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from dvmvs.config import Config
-from dvmvs.pose_algebra import _host
+from dvmvs.pose_algebra import to_host as _host
 from dvmvs.utils import calculate_cost_volume_by_warping, get_warp_grid_for_cost_volume_calculation
 
 

@@ -31,8 +31,18 @@ import torch
 from dvmvs.hip import ops as _ops
 from dvmvs import pose_algebra as _pose_algebra
 
-# kernel selector for the cost volume: 0 = automatic, 1 = generic reference-order kernel, 2 = tap-reuse kernel
+# kernel selector for the cost volume (include/dvmvs_hip.h): 0 = automatic (generic kernel for small maps / SAD, otherwise the
+# LDS-tiled sweep in the configuration the host-side plan model picks for the keyframe geometry), 1 = generic reference-order
+# kernel, 2 = LDS-tiled sweep, default configuration, 3 = LDS-tiled sweep, wide-baseline configuration
 COST_VOLUME_VARIANT = int(os.environ.get("DVMVS_COST_VOLUME_VARIANT", "0"))
+
+
+def sweep_variant(host_matrices, height, width, n_depth_levels, min_depth, max_depth, dot_product=True):
+    """The ``variant`` argument of dvmvs_cost_volume_fwd for one call: the forced one (DVMVS_COST_VOLUME_VARIANT), or for the
+    dot-product sweep of a map the tiled kernel handles, the configuration picked from the HOST copies of the matrices."""
+    if COST_VOLUME_VARIANT != 0 or host_matrices is None or not dot_product or height * width < 64 * 64:
+        return COST_VOLUME_VARIANT
+    return _pose_algebra.sweep_variant_host(host_matrices[0], host_matrices[1], height, width, n_depth_levels, min_depth, max_depth)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -83,9 +93,9 @@ def cost_volume_fusion(image1, image2s, pose1, pose2s, K, warp_grid, min_depth, 
     image2s, pose2s = list(image2s), list(pose2s)
     if len(image2s) == 0 or len(image2s) != len(pose2s):
         raise ValueError("cost_volume_fusion: need as many measurement poses as measurement feature maps (>= 1)")
-    Hm, kt = _pose_algebra.sweep_matrices(pose1, pose2s, K, image1.device)
-    return _ops.cost_volume(image1, image2s, Hm, kt, float(min_depth), float(max_depth), int(n_depth_levels), bool(dot_product),
-                            COST_VOLUME_VARIANT)
+    Hm, kt, host = _pose_algebra.sweep_matrices(pose1, pose2s, K, image1.device, with_host=True)
+    variant = sweep_variant(host, image1.shape[2], image1.shape[3], n_depth_levels, min_depth, max_depth, dot_product)
+    return _ops.cost_volume(image1, image2s, Hm, kt, float(min_depth), float(max_depth), int(n_depth_levels), bool(dot_product), variant)
 
 
 def calculate_cost_volume_by_warping(image1, image2, pose1, pose2, K, warp_grid, min_depth, max_depth, n_depth_levels,

@@ -81,7 +81,10 @@ int dvmvs_sweep_matrices(const float* pose1, const float* const* pose2s, const f
  *   cost_volume [B,D,H,W]   out; plane 0 = max_depth ... plane D-1 = min_depth, uniform in inverse depth
  *   dot_product 1: sum_c(f1*warp(f2))/C   0: sum_c|f1-warp(f2)|  (utils.py:81-84); result is the mean over M
  *   variant     0 = pick the fastest kernel for the shape; 1 = force the generic reference-order kernel (taps through
- *               the vector L1); 2 = force the LDS-tiled sweep (dot_product only)
+ *               the vector L1); 2 = force the LDS-tiled sweep in its default configuration (dot_product only); 3 = the
+ *               LDS-tiled sweep in its wide-baseline configuration (72 KB sample boxes, 512-thread workgroups: faster where
+ *               the default one has to split or queue runs of planes, slower on easy pairs -- dvmvs_sweep_select_variant
+ *               decides from the matrices).  Each configuration is bit-reproducible; the two differ in summation order.
  *   image2_layout DVMVS_LAYOUT_NCHW, or DVMVS_LAYOUT_NHWC when the MEASUREMENT maps are stored channels-last (a keyframe's
  *               features are reused as measurement features by later frames, so a runner converts them once per
  *               keyframe).  Supported by the LDS-tiled dot-product kernel (C % 4 == 0, H*W >= 4096); image1 and
@@ -100,6 +103,20 @@ int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, cons
                           float* cost_volume, int B, int M, int C, int H, int W, int D,
                           double min_depth, double max_depth, int dot_product, int variant, int image2_layout,
                           float* workspace, size_t workspace_bytes, dvmvs_stream_t stream);
+
+/*
+ * HOST-side model of the LDS-tiled sweep's run plan (no HIP call, no device memory): Hm_host / kt_host are HOST copies of the
+ * matrices the launch will get -- they are on the host before the launch anyway (see "small matrices" above).
+ *   configuration 0 = default (variant 2), 1 = wide-baseline (variant 3)
+ *   stats[6] out: staged runs, LDS records of all staged runs, runs entirely outside the image, runs queued for the second
+ *                 pass, planes of those runs, workgroups with at least one queued run
+ * dvmvs_sweep_select_variant returns the variant (2 or 3) the cost model built on those numbers expects to be faster for this
+ * keyframe pair (negative DVMVS_E* on bad arguments); a captured frame graph per variant is replayed accordingly.
+ */
+int dvmvs_sweep_plan_stats(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
+                           double min_depth, double max_depth, int configuration, long long* stats);
+int dvmvs_sweep_select_variant(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
+                               double min_depth, double max_depth);
 
 /*
  * Gradient of the fused cost volume (dot_product mode) w.r.t. both feature maps; poses/K carry no gradient

@@ -367,6 +367,59 @@ def long_sequence_goldens(ref):
     save("fusionnet_long", **arrays)
 
 
+def reference_state_goldens(ref):
+    """fusionnet_state.npz: the FULL-RESOLUTION recurrent state the reference's loop carries out of every keyframe of the two golden
+    runs (3 golden frames: keys f{n}_*, long run: keys s{n}_*): depth [256,320], h and c [512,8,10], float32, exactly as the
+    reference's modules returned them.  fusionnet_e2e.npz / fusionnet_long.npz hold sub-sampled depth and sampled state entries
+    only; with this file a test (and bench.py's rel_l1 leg) installs the REFERENCE's own state before each step (teacher forcing)
+    instead of the state of a CPU stand-in pipeline.  The run is the same one, re-run in this process: checked here bit for bit
+    against the sub-sampled depth and the depth estimate the two older fixtures hold."""
+    m = ref.fusionnet_model
+    ctors = (m.FeatureExtractor, m.FeatureShrinker, m.CostVolumeEncoder, m.LSTMFusion, m.CostVolumeDecoder)
+    fe, fs, enc, lstm, dec = syn.build_e2e_modules(ctors, with_bn_stats=True)
+    for mod in (fe, fs, enc, lstm, dec):
+        mod.eval()
+    fullK = syn.full_K()
+    halfK = syn.scaled_K(fullK, 2.0)
+    lK = syn.scaled_K(fullK, 32.0)
+    grid = ref.utils.get_warp_grid_for_cost_volume_calculation(160, 128, CPU)
+    lines = syn.keyframe_index_lines(2)
+    z3 = np.load(os.path.join(HERE, "fusionnet_e2e.npz"))
+    zl = np.load(os.path.join(HERE, "fusionnet_long.npz"))
+    runs = [("f", list(syn.E2E_FRAMES), lambda n: (z3[f"f{n}_depth_sub4"], z3[f"f{n}_depth_estimation_full"])),
+            ("s", [None if i is None else lines[i] for i in syn.LONG_SCHEDULE], lambda n: (zl[f"s{n}_depth_sub4"], zl[f"s{n}_depth_estimation"]))]
+    arrays = {}
+    with torch.no_grad():
+        for tag, frames, older in runs:
+            lstm_state, prev_depth, prev_pose = None, None, None
+            for n, item in enumerate(frames):
+                if item is None:                                  # run-testing.py:97-101
+                    lstm_state, prev_depth, prev_pose = None, None, None
+                    continue
+                r, ms = item
+                meas_feats = [fs(*fe(syn.e2e_image(i)))[0] for i in ms]
+                ref_feats = fs(*fe(syn.e2e_image(r)))
+                cv = ref.utils.cost_volume_fusion(ref_feats[0], meas_feats, syn.pose(r), [syn.pose(i) for i in ms], halfK, grid,
+                                                  0.25, 20.0, 64, CPU, True)
+                skip0, skip1, skip2, skip3, bottom = enc(*ref_feats, cv)
+                if prev_depth is not None:
+                    de = ref.utils.get_non_differentiable_rectangle_depth_estimation(syn.pose(r), prev_pose, prev_depth, fullK, halfK, 320, 256)
+                    de = torch.nn.functional.interpolate(de, scale_factor=1.0 / 16.0, mode="nearest")
+                else:
+                    de = torch.zeros(1, 1, 8, 10)
+                lstm_state = lstm(bottom, lstm_state, prev_pose, syn.pose(r), de, lK)
+                pred = dec(syn.e2e_image(r), skip0, skip1, skip2, skip3, lstm_state[0])[0]
+                prev_depth, prev_pose = pred.view(1, 1, 256, 320), syn.pose(r)
+                old_depth, old_estimate = older(n)
+                assert np.array_equal(pred[0, ::4, ::4].numpy(), old_depth), f"{tag}{n}: this run is not the run of the older fixture"
+                assert np.array_equal(de.numpy().reshape(old_estimate.shape), old_estimate), f"{tag}{n}: depth estimate differs"
+                arrays[f"{tag}{n}_depth"] = pred[0].clone()
+                arrays[f"{tag}{n}_h"] = lstm_state[0][0].clone()
+                arrays[f"{tag}{n}_c"] = lstm_state[1][0].clone()
+                print(f"reference state {tag}{n}: depth {pred.min().item():.3f} .. {pred.max().item():.3f} (equal to the older fixture's sub-sampled depth)")
+    save("fusionnet_state", **arrays)
+
+
 def pose_algebra_goldens(ref):
     """host_pose_algebra.npz: the small fp32 matrices of THIS host -- the one every other fixture here was captured on -- for
     the pose pairs the fixture-comparing tests use (syn.golden_algebra_pairs), by the reference's own expressions
@@ -535,11 +588,15 @@ def main():
     if "--only-pose-algebra" in sys.argv:
         pose_algebra_goldens(ref)
         return
+    if "--only-reference-state" in sys.argv:
+        reference_state_goldens(ref)
+        return
     cost_volume_goldens(ref)
     de16 = reprojection_goldens(ref)
     lstm_goldens(ref, de16)
     end_to_end_goldens(ref)
     long_sequence_goldens(ref)
+    reference_state_goldens(ref)
     pose_algebra_goldens(ref)
     keyframe_goldens(ref)
     error_metric_goldens(ref)

@@ -117,72 +117,62 @@ def test_fusionnet_three_frames_match_the_reference(hip_device, golden_dir, mode
     assert report[0][2] <= ENGINE_VS_REFERENCE
 
 
-def run_teacher_forced(engine, reference, dev, frames, expected_sub4):
-    """Every frame from the REFERENCE's state: (h, c, previous depth, previous pose) of the all-CPU reference pipeline are
-    installed in the engine before the step.  ``frames``: (reference pose index, measurement indices) or None = tracking loss.
-    Returns [(step, engine-vs-reference-pipeline rel-L1 (full resolution), engine-vs-golden rel-L1 (sub-sampled),
-    estimate pixels on which the engine's z-buffer decision differs from the pipeline's, estimate pixels on which the PIPELINE
-    differs from the golden run (the CPU pipeline is itself a float32 evaluation ~1e-5 from the reference run; once one of its
-    own estimate pixels flips it stops being a stand-in for the golden until the next restart))]."""
+def run_teacher_forced(engine, dev, tag, frames, state, golden_estimate):
+    """Every frame from the REFERENCE's own state: (h, c, previous depth) of tests/golden/fusionnet_state.npz -- the full-resolution
+    tensors the reference's modules returned in the golden run -- and the previous pose are installed in the engine before the step.
+    ``frames``: (reference pose index, measurement indices) or None = tracking loss.  Returns [(step, engine-vs-reference rel-L1 at
+    full resolution, pixels of the 8x10 depth estimate on which the engine's z-buffer decision differs from the reference's)]."""
     from dvmvs.hip import ops
     fullK = syn.full_K()
     fullK_dev, halfK_dev = fullK.to(dev), syn.scaled_K(fullK, 2.0).to(dev)
-    rows = []
+    rows, previous = [], None
     for n, item in enumerate(frames):
         if item is None:
             engine.reset()
-            reference.reset()
+            previous = None
             continue
         r, ms = item
-        flipped, pipeline_flipped = 0, 0
-        if reference.previous_depth is not None:
-            h, c = reference.lstm_state
-            engine.load_state(h.to(dev), c.to(dev), reference.previous_depth.to(dev), reference.previous_pose)
-            _, low = hipcall.depth_reproject(ops, syn.pose(r), reference.previous_pose, reference.previous_depth.to(dev), fullK_dev, halfK_dev, 16)
-        rec = {}
-        d_ref = reference.step(syn.e2e_image(r), syn.pose(r), [syn.e2e_image(i) for i in ms], [syn.pose(i) for i in ms], fullK,
-                               record=lambda **kw: rec.update(kw))
-        if rec["depth_estimation"] is not None and float(rec["depth_estimation"].abs().max()) > 0:
-            flipped = flipped_pixels(low.cpu().numpy(), rec["depth_estimation"].numpy())
+        flipped = 0
+        if previous is not None:
+            k, r_prev = previous
+            prev_depth = torch.from_numpy(state[f"{tag}{k}_depth"]).to(dev).view(1, 1, 256, 320)
+            engine.load_state(torch.from_numpy(state[f"{tag}{k}_h"]).to(dev), torch.from_numpy(state[f"{tag}{k}_c"]).to(dev), prev_depth, syn.pose(r_prev))
+            _, low = hipcall.depth_reproject(ops, syn.pose(r), syn.pose(r_prev), prev_depth, fullK_dev, halfK_dev, 16)
+            flipped = flipped_pixels(low.cpu().numpy(), golden_estimate(n))
         depth = engine.step(syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK,
                             frame_id=r, measurement_ids=list(ms))
-        d = depth.cpu().numpy().astype(np.float64)
-        golden, golden_estimate = expected_sub4(n)
-        if rec["depth_estimation"] is not None:
-            pipeline_flipped = flipped_pixels(rec["depth_estimation"].numpy(), golden_estimate)
-        rows.append((n, rel_l1(d, d_ref.numpy().astype(np.float64)), rel_l1(d[0, ::4, ::4], golden.astype(np.float64)), flipped, pipeline_flipped))
+        if previous is not None and engine._direct_buffers:      # the estimate the engine's own frame body fed its ConvLSTM
+            flipped = max(flipped, flipped_pixels(engine._direct_buffers["estimate"].cpu().numpy(), golden_estimate(n)))
+        rows.append((n, rel_l1(depth[0].cpu().numpy().astype(np.float64), state[f"{tag}{n}_depth"].astype(np.float64)), flipped))
+        previous = (n, r)
     return rows
 
 
 @pytest.mark.parametrize("mode", ["eager_unfolded", "graphs_folded_cached"])
 def test_fusionnet_frames_from_the_reference_state(hip_device, golden_dir, mode, fixture_host_algebra):
     """Teacher forcing over the 3 golden frames and the 14-keyframe reference run (tracking loss, wide-baseline lines 200-204,
-    249-251): given the reference's inputs and state, EVERY frame's depth is within ENGINE_VS_REFERENCE of the reference's, and
-    the engine's z-buffer decision on the reference's previous depth has 0 flipped pixels."""
+    249-251): given the reference's inputs and the reference's OWN state, EVERY one of the 17 frames is within the north-star
+    bound (1e-4 depth rel-L1, full resolution) of the reference's depth, and the engine's z-buffer decision on the reference's
+    previous depth has 0 flipped pixels.  (Round 3 could assert engine-vs-golden on 4-5 of the long run's frames only: the
+    fixtures held sub-sampled depth and the full-resolution state came from a CPU stand-in that itself left the golden run.)"""
     dev = hip_device
     fast = mode == "graphs_folded_cached"
     z3 = np.load(os.path.join(golden_dir, "fusionnet_e2e.npz"))
     zl = np.load(os.path.join(golden_dir, "fusionnet_long.npz"))
+    state = np.load(os.path.join(golden_dir, "fusionnet_state.npz"))
     lines = syn.keyframe_index_lines(2)
-    runs = [("3 golden frames", list(syn.E2E_FRAMES), lambda n: (z3[f"f{n}_depth_sub4"], z3[f"f{n}_depth_estimation_full"])),
-            ("long reference run", [None if i is None else lines[i] for i in syn.LONG_SCHEDULE],
-             lambda n: (zl[f"s{n}_depth_sub4"], zl[f"s{n}_depth_estimation"]))]
-    for name, frames, expected in runs:
+    runs = [("3 golden frames", "f", list(syn.E2E_FRAMES), lambda n: z3[f"f{n}_depth_estimation_full"]),
+            ("long reference run", "s", [None if i is None else lines[i] for i in syn.LONG_SCHEDULE], lambda n: zl[f"s{n}_depth_estimation"])]
+    checked = 0
+    for name, tag, frames, golden_estimate in runs:
         mods, engine = build(dev, fusion=True, fold_bn=fast, cache_features=fast, use_graphs=fast)
-        rows = run_teacher_forced(engine, reference_pipeline(mods), dev, frames, expected)
-        on_golden, checked_vs_golden = True, 0
-        for n, vs_pipeline, vs_golden, flipped, pipeline_flipped in rows:
-            if frames[n - 1] is None or n == 0:
-                on_golden = True      # restart: the pipeline is on the golden run's inputs again
-            on_golden = on_golden and pipeline_flipped == 0
-            print("%s, %s step %2d: engine depth rel-L1 vs the reference pipeline %.3e, vs the reference golden %.3e%s, flipped estimate pixels %d"
-                  % (mode, name, n, vs_pipeline, vs_golden, "" if on_golden else " [the CPU pipeline itself has left the golden run]", flipped))
-            assert vs_pipeline <= REL_L1_TARGET, (name, n, vs_pipeline)
+        for n, vs_reference, flipped in run_teacher_forced(engine, dev, tag, frames, state, golden_estimate):
+            print("%s, %s step %2d: engine depth rel-L1 vs the reference (full resolution, reference's state installed) %.3e, flipped estimate pixels %d"
+                  % (mode, name, n, vs_reference, flipped))
+            assert vs_reference <= REL_L1_TARGET, (name, n, vs_reference)
             assert flipped == 0, (name, n, flipped)
-            if on_golden:
-                assert vs_golden <= REL_L1_TARGET, (name, n, vs_golden)
-                checked_vs_golden += 1
-        assert checked_vs_golden >= min(4, len(rows)), (name, checked_vs_golden)
+            checked += 1
+    assert checked == 17
 
 
 def test_fusionnet_long_reference_run(hip_device, golden_dir, fixture_host_algebra):

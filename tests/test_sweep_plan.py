@@ -1,0 +1,150 @@
+"""Host-side run-plan model of the LDS-tiled sweep (dvmvs_sweep_plan_stats / dvmvs_sweep_select_variant, csrc/sweep_tiled.hip:
+host_plan_stats) -- runs on the CPU, no GPU needed.  Checked against an independent pure-Python restatement of the plan rule
+(corner boxes of a tile over a run of planes, greedy halving, LDS capacity) on real keyframe geometries, and for the properties the
+engine relies on: deterministic, 2 or 3 only, the wide configuration never queues more than the default one."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import synthetic as syn
+from dvmvs import pose_algebra
+from dvmvs.hip import _capi
+
+H, W, D = 128, 160, 64
+f32 = np.float32
+
+
+def lib_stats(Hm, kt, configuration, shape=(H, W, D)):
+    out = (ctypes.c_longlong * 6)()
+    rc = _capi.lib().dvmvs_sweep_plan_stats(Hm.contiguous().data_ptr(), kt.contiguous().data_ptr(), Hm.shape[0], Hm.shape[1], shape[0], shape[1],
+                                            shape[2], 0.25, 20.0, configuration, out)
+    assert rc == 0
+    return list(out)
+
+
+def fma(a, b, c):      # fmaf through float64: the product is exact there
+    return f32(np.float64(a) * np.float64(b) + np.float64(c))
+
+
+def pitch_residue(ax, ay):
+    aax, aay = abs(ax), abs(ay)
+    c, r = math.ceil(15.0 * aax), math.ceil(15.0 * aay)
+    cost0 = 15.0 * aay * max(0.0, 1.0 - aax) + max(0.0, c - 15.0)
+    cost1 = max(0.0, c + r - 15.0)
+    if not cost1 < cost0:
+        return 0
+    return 15 if (ax < 0) != (ay < 0) else 1
+
+
+def python_plan_stats(Hm, kt, cap, tw=32, th=8, dp=8, minseg=2):
+    """The kernel's plan rule, one (tile, chunk, frame) at a time, in numpy float32 scalars."""
+    M = Hm.shape[0]
+    stats = [0] * 6
+    inv_base, inv_step = 1.0 / 20.0, (1.0 / 0.25 - 1.0 / 20.0) / (D - 1)
+    wn, hn, Wm1, Hm1 = f32(W) * f32(0.5), f32(H) * f32(0.5), f32(W - 1), f32(H - 1)
+
+    def position(ray, k):
+        denom = f32(f32(ray[2] + k[2]) + f32(1e-8))
+        u, v = f32(f32(ray[0] + k[0]) / denom), f32(f32(ray[1] + k[1]) / denom)
+        ix = f32(f32(f32(f32(f32(u - wn) / wn) + f32(1.0)) * f32(0.5)) * Wm1)
+        iy = f32(f32(f32(f32(f32(v - hn) / hn) + f32(1.0)) * f32(0.5)) * Hm1)
+        return ix, iy, denom
+
+    with np.errstate(all="ignore"):
+        for chunk in range(D // dp):
+            ktd = [[[f32(kt[m][k] / f32(1.0 / (inv_base + (chunk * dp + j) * inv_step))) for k in range(3)] for j in range(dp)] for m in range(M)]
+            for ty in range(math.ceil(H / th)):
+                for tx in range(math.ceil(W / tw)):
+                    x0, x1 = tx * tw, min(tx * tw + tw - 1, W - 1)
+                    y0, y1 = ty * th, min(ty * th + th - 1, H - 1)
+                    edge = f32(max(1, x1 - x0))
+                    spills = False
+                    for m in range(M):
+                        h = Hm[m]
+                        rays = []
+                        for c in range(4):
+                            xf, yf = f32(x1 if c & 1 else x0), f32(y1 if c & 2 else y0)
+                            rays.append(tuple(fma(h[3 * r + 2], f32(1.0), fma(h[3 * r + 1], yf, f32(h[3 * r] * xf))) for r in range(3)))
+                        lo, hint = 0, dp
+                        while lo < dp:
+                            len0 = min(dp - lo, hint)
+                            for candidate in range(4):
+                                length = len0
+                                for _ in range(candidate):
+                                    length = max((length + 1) // 2, minseg)
+                                length = min(length, len0)
+                                pts = [position(rays[c & 3], ktd[m][lo + length - 1 if c & 4 else lo]) for c in range(8)]
+                                finite = all(-1e6 < p[0] < 1e6 and -1e6 < p[1] < 1e6 and p[2] > 1e-6 for p in pts)
+                                state, records = 0, 0
+                                if finite:
+                                    lo_x, hi_x = min(p[0] for p in pts), max(p[0] for p in pts)
+                                    lo_y, hi_y = min(p[1] for p in pts), max(p[1] for p in pts)
+                                    s = f32(0.05)
+                                    if f32(hi_x + s) <= -1 or f32(lo_x - s) >= W or f32(hi_y + s) <= -1 or f32(lo_y - s) >= H:
+                                        state = 2
+                                    else:
+                                        bx0, by0 = max(-1, math.floor(max(f32(lo_x - s), -1))), max(-1, math.floor(max(f32(lo_y - s), -1)))
+                                        bx1, by1 = min(W, math.floor(min(f32(hi_x + s), W))) + 1, min(H, math.floor(min(f32(hi_y + s), H))) + 1
+                                        RW, RH = bx1 - bx0 + 1, by1 - by0 + 1
+                                        step = (f32(f32(pts[1][0] - pts[0][0]) / edge), f32(f32(pts[1][1] - pts[0][1]) / edge))
+                                        pitch = RW + ((pitch_residue(float(step[0]), float(step[1])) - RW) & 15)
+                                        records = pitch * RH
+                                        state = 1 if records <= cap else 0
+                                if state != 0 or length <= minseg or candidate == 3:
+                                    break
+                            if state == 1:
+                                stats[0] += 1
+                                stats[1] += records
+                            elif state == 2:
+                                stats[2] += 1
+                            else:
+                                stats[3] += 1
+                                stats[4] += length
+                                spills = True
+                            lo += length
+                            hint = max(length, minseg)
+                    stats[5] += spills
+    return stats
+
+
+def matrices(line):
+    r, ms = syn.keyframe_index_lines(2)[line]
+    return pose_algebra.sweep_matrices_host(syn.pose(r), [syn.pose(m) for m in ms], syn.scaled_K(syn.full_K(), 2.0))
+
+
+@pytest.mark.parametrize("line", [0, 117, 202])
+def test_plan_model_equals_the_python_restatement(line):
+    Hm, kt = matrices(line)
+    for configuration, cap in ((0, 1024), (1, 1536)):
+        assert lib_stats(Hm, kt, configuration) == python_plan_stats(Hm[0].numpy().astype(f32), kt[0].numpy().astype(f32), cap), (line, configuration)
+
+
+def test_selection_properties_on_the_whole_keyframe_index():
+    lib = _capi.lib()
+    chosen = []
+    for line in range(len(syn.keyframe_index_lines(2))):
+        Hm, kt = matrices(line)
+        d, w = lib_stats(Hm, kt, 0), lib_stats(Hm, kt, 1)
+        assert w[4] <= d[4] and w[5] <= d[5], (line, d, w)              # larger boxes never queue more
+        assert d[0] + d[2] + d[3] >= 2 * 640 and sum(d) > 0             # every (tile, chunk, frame) is covered by at least one run
+        v = pose_algebra.sweep_variant_host(Hm, kt, H, W, D, 0.25, 20.0)
+        assert v in (2, 3) and v == lib.dvmvs_sweep_select_variant(Hm.data_ptr(), kt.data_ptr(), 1, 2, H, W, D, 0.25, 20.0)    # deterministic
+        chosen.append(v)
+    # easy sideways pairs keep the default configuration, the pairs whose footprints do not fit 48 KB boxes take the wide one
+    assert chosen[0] == 2 and chosen[153] == 2
+    assert chosen[170] == 3 and chosen[202] == 3
+    assert 0 < chosen.count(3) < len(chosen) // 2
+
+
+def test_plan_model_rejects_bad_arguments():
+    Hm, kt = matrices(0)
+    out = (ctypes.c_longlong * 6)()
+    lib = _capi.lib()
+    assert lib.dvmvs_sweep_plan_stats(None, kt.data_ptr(), 1, 2, H, W, D, 0.25, 20.0, 0, out) == -1
+    assert lib.dvmvs_sweep_plan_stats(Hm.data_ptr(), kt.data_ptr(), 1, 2, H, W, D, 0.25, 20.0, 2, out) == -1
+    assert lib.dvmvs_sweep_plan_stats(Hm.data_ptr(), kt.data_ptr(), 1, 9, H, W, D, 0.25, 20.0, 0, out) == -2
+    with pytest.raises(ValueError):
+        pose_algebra.sweep_variant_host(Hm.double(), kt.double(), H, W, D, 0.25, 20.0)

@@ -5,7 +5,7 @@ Run on the GPU box:
     python tools/cv_microbench.py [--lines 0,40,117,202] [--variants 0,32,33] [--layouts nchw,nhwc] [--batch 1] [--lib tuning]
 
 Each (geometry, layout, variant) is captured into a hipGraph of REPS back-to-back ops and timed with HIP events (no host gaps).
-Variant numbers: include/dvmvs_hip.h (0-2); 32 + k = tuning configuration k of csrc/sweep_tiled.hip (+ 16 / 32 / 48: second-pass
+Variant numbers: include/dvmvs_hip.h (0-3; 2 / 3 = the two configurations of the LDS-tiled sweep); 32 + k = tuning configuration k of csrc/sweep_tiled.hip (+ 16 / 32 / 48: second-pass
 grid of 512 / 1024 / 2048 workgroups), which exist only in the tools-only library built by `make -C deep-video-mvs_amd/csrc tuning`
 (--lib tuning) -- the product library answers them with "invalid argument".
 Prints one table (us per op) and writes it as JSON when --out is given.
@@ -71,7 +71,7 @@ def main():
     alg_bytes = (1 + M) * B * C * H * W * 4 + B * D * H * W * 4
     print(f"shape B={B} C={C} {H}x{W} D={D} M={M}; algorithmic bytes {alg_bytes}; library: {args.lib}")
     results = {}
-    for li in [int(v) for v in args.lines.split(",")]:
+    for li in (range(len(lines)) if args.lines == "all" else [int(v) for v in args.lines.split(",")]):
         if li < 0:
             traj = torch.from_numpy(syn.synthetic_trajectory(10, seed=1000)).float()
             ids, pose_src = [8, 7, 6], traj
