@@ -282,17 +282,24 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
     lib = _capi.lib()
     workspace, ws_bytes = _ops.sweep_workspace(ref.device, B, n_meas, H, W, D)
 
+    use_list = engine.sweep_work_list            # as the engine launches it: with the host-planned work list of the geometry
+    work_list = torch.zeros(_ops.sweep_work_list_words(B, H, W, D), dtype=torch.int32, device=ref.device)
+
     def set_geometry(ref_pose, meas_poses):
         h, k, host = pose_algebra.sweep_matrices(ref_pose, meas_poses[:n_meas], half_K, ref.device, engine.pose_algebra, with_host=True)
         Hm.copy_(h)
         kt.copy_(k)
-        return utils.sweep_variant(host, H, W, D, engine.min_depth, engine.max_depth)
+        variant = utils.sweep_variant(host, H, W, D, engine.min_depth, engine.max_depth)
+        if use_list:
+            work_list.copy_(_ops.sweep_work_list_host(host[0], host[1], H, W, D, engine.min_depth, engine.max_depth, variant))
+        return variant
 
     def launch(variant):
-        rc = lib.dvmvs_cost_volume_fwd(ref.data_ptr(), img_ptrs, Hm.data_ptr(), kt.data_ptr(), out.data_ptr(),
-                                       B, n_meas, C, H, W, D, engine.min_depth, engine.max_depth, 1, variant, layout,
-                                       workspace.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
-        _capi.check(rc, "dvmvs_cost_volume_fwd")
+        rc = lib.dvmvs_cost_volume_planned_fwd(ref.data_ptr(), img_ptrs, Hm.data_ptr(), kt.data_ptr(), out.data_ptr(),
+                                               B, n_meas, C, H, W, D, engine.min_depth, engine.max_depth, 1, variant, layout,
+                                               workspace.data_ptr(), ws_bytes, work_list.data_ptr() if use_list else None,
+                                               torch.cuda.current_stream().cuda_stream)
+        _capi.check(rc, "dvmvs_cost_volume_planned_fwd")
 
     graphs = {}
 

@@ -1,0 +1,221 @@
+// 3x3 convolutions on the bottleneck maps of a frame (8x10 and 16x20 pixels at 320x256) as a weight-streaming fp32 MFMA GEMM, gfx950.
+//
+// Which layers: the ConvLSTM convolution (1024 -> 2048 channels on the 8x10 map, /root/reference/dvmvs/convlstm.py:43-44,
+// fusionnet/model.py:308-337) and the 256 / 512-channel 3x3 layers of the encoder's last block and the decoder's first block
+// (fusionnet/model.py:167-305) -- 80 or 320 output pixels against 2 304 ... 9 216-term reductions, i.e. GEMMs with a tiny M whose
+// cost is streaming the weights (75.5 MB for the ConvLSTM: 9.4 us at 8 TB/s) and 3.0 GFLOP of exact-fp32 arithmetic (19 us at the
+// 157 TF fp32 MFMA rate).  Why not MIOpen here (it stays the path of every other convolution): for exactly these problems MIOpen
+// picks its `igemm_fwd_gtcx35_nhwc_..._gkgs` kernels -- K split over workgroups and accumulated with float ATOMICS -- so the result
+// differs from run to run (measured: tools/conv_determinism_probe.py), which through the discrete depth estimate makes whole depth
+// maps process-dependent; and they cost 50 us + two layout transposes for the ConvLSTM (rocBLAS on an im2col
+// operand, split-K as a batched GEMM: 30-32 us, tools/lstm_conv_probe.py).
+//
+// Formulation.  out[n, p] = sum_{c, tap} W[n, c, tap] * x[c, p @ tap].  A wave owns 16 output channels (MFMA rows) x 80 pixels (five
+// 16-column tiles of v_mfma_f32_16x16x4_f32, 20 accumulator registers) x one split of the input channels; a workgroup is four waves
+// = 64 output channels that share the split's slice of x, staged once into LDS with its zero ring (padding = 1), so the B operand
+// of every MFMA is one ds_read_b32 at (channel plane + pixel offset + tap offset) and no im2col operand ever exists.  The weights
+// are re-packed once (they are constants at inference) into the A-operand order -- [16-channel tile][16 input channels][tap][lane]
+// float4 -- so a wave streams them with fully coalesced 1 KB loads, 9 per 16 input channels, double-buffered against 180 MFMAs.
+// Splits are summed by the consumer in a fixed order (dvmvs_lstm_gates_partials_fwd, dvmvs_partial_sums_bias_act_fwd): the result
+// is bit-reproducible.  An fp32 MFMA is an fmaf chain over k (cdna guide, "exact f32"): no reduced precision anywhere.
+#include "dvmvs_device.h"
+
+namespace dvmvs {
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+constexpr int kBcRows = 16;     // output channels per wave
+constexpr int kBcPixels = 80;   // pixels per wave
+constexpr int kBcPT = kBcPixels / 16;
+constexpr int kBcWaves = 4;
+constexpr int kBcTargetWaves = 2048;   // two per SIMD
+
+struct BottleneckConvArgs {
+  const float* x;        // [B, C_in, H_in, W_in]
+  const float* packed;   // [n_tiles][C_in / 16][9][64] float4
+  float* partials;       // [splits][B][C_out][P]
+  int B, C_in, C_out, n_tiles, cs, splits;
+};
+
+// split count: the smallest divisor of C_in / 16 that gives at least kBcTargetWaves waves (or all of them)
+__host__ __device__ inline int bottleneck_splits(int B, int C_out, int C_in, int P) {
+  const int n_tiles = (C_out + kBcRows - 1) / kBcRows, groups = C_in / 16, pixel_groups = P / kBcPixels;
+  const int per_split = n_tiles * pixel_groups * B;
+  const int wanted = (kBcTargetWaves + per_split - 1) / per_split;
+  for (int d = 1; d <= groups; ++d)
+    if (groups % d == 0 && d >= wanted) return d;
+  return groups;
+}
+
+template <int H_IN, int W_IN, int STRIDE>
+__global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(BottleneckConvArgs a) {
+  constexpr int PW = W_IN + 2, PLANE = (H_IN + 2) * PW;
+  constexpr int W_OUT = W_IN / STRIDE, H_OUT = H_IN / STRIDE, P = H_OUT * W_OUT, PG = P / kBcPixels;
+  static_assert(P % kBcPixels == 0, "the map must split into 80-pixel groups");
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // [cs][PLANE]: the split's channels with their zero ring
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_tile = blockIdx.x * kBcWaves + wave;
+  const int split = blockIdx.y;
+  const int b = blockIdx.z / PG, pg = blockIdx.z - b * PG;
+  const int c0 = split * a.cs;
+
+  // ---- stage x[b, c0 : c0 + cs] into LDS ----
+  gcfloat_p xg = as_global(a.x) + (static_cast<size_t>(b) * a.C_in + c0) * (H_IN * W_IN);
+  for (int i = tid; i < a.cs * PLANE; i += kBcWaves * 64) {
+    const int c = i / PLANE, r = i - c * PLANE;
+    const int yy = r / PW, xx = r - yy * PW;
+    const bool in = yy >= 1 && yy <= H_IN && xx >= 1 && xx <= W_IN;
+    xs[i] = in ? xg[c * (H_IN * W_IN) + (yy - 1) * W_IN + (xx - 1)] : 0.0f;
+  }
+  __syncthreads();
+  if (n_tile >= a.n_tiles) return;
+
+  // this lane's B-operand position: input channel (lane >> 4) of a group of four, pixel (lane & 15) of each 16-pixel tile
+  int pix[kBcPT];
+#pragma unroll
+  for (int pt = 0; pt < kBcPT; ++pt) {
+    const int p = pg * kBcPixels + pt * 16 + (lane & 15);
+    const int py = p / W_OUT, px = p - py * W_OUT;
+    pix[pt] = (py * STRIDE) * PW + px * STRIDE + (lane >> 4) * PLANE;
+  }
+  float4v acc[kBcPT];
+#pragma unroll
+  for (int pt = 0; pt < kBcPT; ++pt) acc[pt] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+
+  const int groups = a.cs / 16;
+  const float4v DVMVS_GLOBAL* wp = reinterpret_cast<const float4v DVMVS_GLOBAL*>(as_global(a.packed)) +
+                                   (static_cast<size_t>(n_tile) * (a.C_in / 16) + c0 / 16) * (9 * 64) + lane;
+  float4v cur[9], nxt[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) cur[t] = wp[t * 64];
+  for (int g = 0; g < groups; ++g) {
+    if (g + 1 < groups) {   // the next 16 input channels' weights are in flight while these are multiplied
+#pragma unroll
+      for (int t = 0; t < 9; ++t) nxt[t] = wp[(g + 1) * (9 * 64) + t * 64];
+    }
+    const float* xc = xs + g * 16 * PLANE;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int toff = (t / 3) * PW + (t % 3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int pt = 0; pt < kBcPT; ++pt)
+          acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[t][j], xc[j * 4 * PLANE + pix[pt] + toff], acc[pt], 0, 0, 0);
+      }
+    }
+    if (g + 1 < groups) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) cur[t] = nxt[t];
+    }
+  }
+
+  // D[row = (lane >> 4) * 4 + r][col = lane & 15] -> partials[split][b][n][p]
+  gfloat_p out = as_global(a.partials) + ((static_cast<size_t>(split) * a.B + b) * a.C_out) * P;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n_tile * kBcRows + (lane >> 4) * 4 + r;
+    if (n < a.C_out) {
+#pragma unroll
+      for (int pt = 0; pt < kBcPT; ++pt) out[static_cast<size_t>(n) * P + pg * kBcPixels + pt * 16 + (lane & 15)] = acc[pt][r];
+    }
+  }
+}
+
+// packed[((tile * G + g) * 9 + tap) * 64 + lane][j] = W[16 tile + (lane & 15)][16 g + 4 j + (lane >> 4)][tap]
+__global__ __launch_bounds__(256) void bottleneck_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int C_out, int C_in, long long total) {
+  const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int j = static_cast<int>(i & 3), lane = static_cast<int>((i >> 2) & 63);
+  long long rest = i >> 8;
+  const int tap = static_cast<int>(rest % 9);
+  rest /= 9;
+  const int G = C_in / 16;
+  const int g = static_cast<int>(rest % G), tile = static_cast<int>(rest / G);
+  const int n = tile * 16 + (lane & 15), c = g * 16 + j * 4 + (lane >> 4);
+  packed[i] = n < C_out ? w[(static_cast<size_t>(n) * C_in + c) * 9 + tap] : 0.0f;
+}
+
+// dst[b, n, :] = act(sum_s partials[s, b, n, :] + bias[n]): the splits in ascending order, then the bias -- one fixed order.
+template <int ACT>
+__global__ __launch_bounds__(256) void partial_sums_bias_act_kernel(const float* __restrict__ partials, int n_partials, float* __restrict__ dst,
+                                                                    long long dst_batch_stride, const float* __restrict__ bias, int B, int C, int HW) {
+  const long long per_split = static_cast<long long>(B) * C * HW;
+  for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < per_split; i += static_cast<long long>(gridDim.x) * 256) {
+    float v = partials[i];
+    for (int s = 1; s < n_partials; ++s) v += partials[s * per_split + i];
+    const int plane = static_cast<int>(i / HW), b = plane / C, c = plane - b * C;
+    v += bias ? bias[c] : 0.0f;
+    if (ACT == 1) v = fmaxf(v, 0.0f);
+    dst[static_cast<size_t>(b) * dst_batch_stride + static_cast<size_t>(c) * HW + (i - static_cast<long long>(plane) * HW)] = v;
+  }
+}
+
+template <int H_IN, int W_IN, int STRIDE>
+int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
+  constexpr int P = (H_IN / STRIDE) * (W_IN / STRIDE), PLANE = (H_IN + 2) * (W_IN + 2);
+  const size_t lds = sizeof(float) * static_cast<size_t>(a.cs) * PLANE;
+  if (lds > 64 * 1024) return DVMVS_EUNSUPPORTED;
+  const dim3 grid((a.n_tiles + kBcWaves - 1) / kBcWaves, a.splits, a.B * (P / kBcPixels));
+  hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE>), grid, dim3(kBcWaves * 64), lds, stream, a);
+  return launch_status();
+}
+
+inline bool bottleneck_shape_ok(int C_out, int C_in, int H_in, int W_in, int stride) {
+  if (C_out <= 0 || C_in <= 0 || C_in % 16 != 0) return false;
+  // the 1/32 and 1/16 maps of a 320x256 frame (80-pixel groups); other sizes stay on MIOpen
+  return (H_in == 8 && W_in == 10 && stride == 1) || (H_in == 16 && W_in == 20 && (stride == 1 || stride == 2));
+}
+
+}  // namespace dvmvs
+
+extern "C" size_t dvmvs_bottleneck_conv_packed_bytes(int C_out, int C_in) {
+  if (C_out <= 0 || C_in <= 0 || C_in % 16 != 0) return 0;
+  return sizeof(float) * static_cast<size_t>((C_out + 15) / 16) * 16 * C_in * 9;
+}
+
+extern "C" int dvmvs_bottleneck_conv_pack(const float* weight, float* packed, int C_out, int C_in, dvmvs_stream_t stream) {
+  if (!weight || !packed) return DVMVS_EINVAL;
+  const size_t bytes = dvmvs_bottleneck_conv_packed_bytes(C_out, C_in);
+  if (bytes == 0) return DVMVS_EUNSUPPORTED;
+  const long long total = static_cast<long long>(bytes / sizeof(float));
+  hipLaunchKernelGGL(dvmvs::bottleneck_pack_kernel, dim3(static_cast<unsigned int>((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     weight, packed, C_out, C_in, total);
+  return dvmvs::launch_status();
+}
+
+extern "C" int dvmvs_bottleneck_conv_splits(int B, int C_out, int C_in, int H_in, int W_in, int stride) {
+  if (B <= 0 || !dvmvs::bottleneck_shape_ok(C_out, C_in, H_in, W_in, stride)) return DVMVS_EUNSUPPORTED;
+  return dvmvs::bottleneck_splits(B, C_out, C_in, (H_in / stride) * (W_in / stride));
+}
+
+extern "C" int dvmvs_bottleneck_conv_fwd(const float* x, const float* packed, float* partials, int B, int C_in, int H_in, int W_in, int C_out,
+                                         int stride, dvmvs_stream_t stream) {
+  using namespace dvmvs;
+  if (!x || !packed || !partials || B <= 0) return DVMVS_EINVAL;
+  if (!bottleneck_shape_ok(C_out, C_in, H_in, W_in, stride)) return DVMVS_EUNSUPPORTED;
+  BottleneckConvArgs a;
+  a.x = x; a.packed = packed; a.partials = partials;
+  a.B = B; a.C_in = C_in; a.C_out = C_out;
+  a.n_tiles = (C_out + kBcRows - 1) / kBcRows;
+  a.splits = bottleneck_splits(B, C_out, C_in, (H_in / stride) * (W_in / stride));
+  a.cs = C_in / a.splits;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (H_in == 8 && W_in == 10) return launch_bottleneck_conv<8, 10, 1>(a, s);
+  if (stride == 1) return launch_bottleneck_conv<16, 20, 1>(a, s);
+  return launch_bottleneck_conv<16, 20, 2>(a, s);
+}
+
+extern "C" int dvmvs_partial_sums_bias_act_fwd(const float* partials, int n_partials, float* dst, long long dst_batch_stride, const float* bias,
+                                               int B, int C, int HW, int activation, dvmvs_stream_t stream) {
+  using namespace dvmvs;
+  if (!partials || !dst || n_partials <= 0 || B <= 0 || C <= 0 || HW <= 0) return DVMVS_EINVAL;
+  if (activation != 0 && activation != 1) return DVMVS_EUNSUPPORTED;
+  const long long total = static_cast<long long>(B) * C * HW;
+  const unsigned int grid = static_cast<unsigned int>((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (activation == 1) hipLaunchKernelGGL((partial_sums_bias_act_kernel<1>), dim3(grid), dim3(256), 0, s, partials, n_partials, dst, dst_batch_stride, bias, B, C, HW);
+  else hipLaunchKernelGGL((partial_sums_bias_act_kernel<0>), dim3(grid), dim3(256), 0, s, partials, n_partials, dst, dst_batch_stride, bias, B, C, HW);
+  return launch_status();
+}

@@ -111,6 +111,9 @@ int launch_cost_volume_generic(const CostVolumeArgs& a, bool dot, hipStream_t st
 size_t sweep_spill_words(int B, int M, int H, int W, int D);
 int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream);
 int launch_sweep_wide(const CostVolumeArgs& a, hipStream_t stream);
+size_t sweep_work_list_words(int B, int H, int W, int D);
+int sweep_work_list_host(int configuration, const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,
+                         unsigned int* items, size_t capacity_words);
 void sweep_plan_stats_host(int configuration, const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,
                            long long* stats);
 int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream);
@@ -140,6 +143,28 @@ extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* im
                                      float* cost_volume, int B, int M, int C, int H, int W, int D,
                                      double min_depth, double max_depth, int dot_product, int variant, int image2_layout,
                                      float* workspace, size_t workspace_bytes, dvmvs_stream_t stream) {
+  return dvmvs_cost_volume_planned_fwd(image1, image2s, Hm, kt, cost_volume, B, M, C, H, W, D, min_depth, max_depth, dot_product, variant,
+                                       image2_layout, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" size_t dvmvs_sweep_work_list_bytes(int B, int H, int W, int D) {
+  if (B <= 0 || H <= 0 || W <= 0 || D <= 0) return 0;
+  return sizeof(unsigned int) * dvmvs::sweep_work_list_words(B, H, W, D);
+}
+
+extern "C" int dvmvs_sweep_work_list(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
+                                     double min_depth, double max_depth, int configuration, unsigned int* work_list_host, size_t work_list_bytes) {
+  if (!Hm_host || !kt_host || !work_list_host || B <= 0 || M <= 0 || H <= 0 || W <= 0 || D <= 0) return DVMVS_EINVAL;
+  if (M > DVMVS_MAX_MEASUREMENTS || D > DVMVS_MAX_DEPTH_LEVELS) return DVMVS_EUNSUPPORTED;
+  if (!(min_depth > 0.0) || !(max_depth > 0.0) || (configuration != 0 && configuration != 1)) return DVMVS_EINVAL;
+  const double inv_base = 1.0 / max_depth, inv_step = D > 1 ? (1.0 / min_depth - 1.0 / max_depth) / (D - 1) : 0.0;
+  return dvmvs::sweep_work_list_host(configuration, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, work_list_host, work_list_bytes / sizeof(unsigned int));
+}
+
+extern "C" int dvmvs_cost_volume_planned_fwd(const float* image1, const float* const* image2s, const float* Hm, const float* kt,
+                                             float* cost_volume, int B, int M, int C, int H, int W, int D,
+                                             double min_depth, double max_depth, int dot_product, int variant, int image2_layout,
+                                             float* workspace, size_t workspace_bytes, const unsigned int* work_list, dvmvs_stream_t stream) {
   using namespace dvmvs;
   if (image2_layout != DVMVS_LAYOUT_NCHW && image2_layout != DVMVS_LAYOUT_NHWC) return DVMVS_EINVAL;
   if (variant < 0 || (variant > 3 && variant < 32) || variant > 255) return DVMVS_EINVAL;
@@ -164,6 +189,8 @@ extern "C" int dvmvs_cost_volume_fwd(const float* image1, const float* const* im
   const bool tiled = dot_product && fits && (variant == 2 || variant == 3 || a.image2_nhwc || (variant == 0 && H * W >= 64 * 64));
   if ((variant == 2 || variant == 3) && !fits) return DVMVS_EUNSUPPORTED;
   if (a.image2_nhwc && !fits) return DVMVS_EUNSUPPORTED;
+  // the work list belongs to the tiled sweep's two-pass form (its items index the spill slots)
+  if (tiled && work_list != nullptr && a.spill != nullptr) a.items = work_list;
   if (tiled && variant == 3) return launch_sweep_wide(a, s);
   if (tiled) return launch_sweep_default(a, s);
   return launch_cost_volume_generic(a, dot_product != 0, s);
@@ -185,7 +212,7 @@ extern "C" int dvmvs_sweep_plan_stats(const float* Hm_host, const float* kt_host
 // profiles/r04_sweep_select_fit.md).  Deterministic in the matrices (IEEE fp32 / integer arithmetic only).
 extern "C" int dvmvs_sweep_select_variant(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
                                           double min_depth, double max_depth) {
-  long long d[6], w[6];
+  long long d[8], w[8];
   int rc = dvmvs_sweep_plan_stats(Hm_host, kt_host, B, M, H, W, D, min_depth, max_depth, 0, d);
   if (rc != 0) return rc;
   rc = dvmvs_sweep_plan_stats(Hm_host, kt_host, B, M, H, W, D, min_depth, max_depth, 1, w);

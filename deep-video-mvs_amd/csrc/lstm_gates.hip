@@ -45,9 +45,11 @@ __device__ inline void row_stats(const float (&v)[EPL], const bool (&ok)[EPL], f
 template <int LPR, int EPL>
 // c_next may alias c_cur (the frame engine updates its state buffers in place): a row is read completely into registers before
 // anything of it is written, and rows are owned by disjoint lane groups -- hence no __restrict__ on the two state pointers.
+// n_partials > 1: the convolution output arrives as that many partial sums (K-splits of dvmvs_bottleneck_conv_fwd, partial_stride
+// floats apart); they are added here in ascending order -- a fixed order, so the gates stay bit-reproducible.
 __global__ __launch_bounds__(256) void lstm_gates_fwd_kernel(const float* __restrict__ cc, const float* c_cur,
                                                              float* __restrict__ h_next, float* c_next,
-                                                             int B, int hidden, int HW) {
+                                                             int B, int hidden, int HW, int n_partials, long long partial_stride) {
   constexpr int kRowsPerBlock = 256 / LPR;
   const int row = blockIdx.x * kRowsPerBlock + threadIdx.x / LPR;  // (b, channel)
   const int lane = threadIdx.x % LPR;
@@ -71,6 +73,17 @@ __global__ __launch_bounds__(256) void lstm_gates_fwd_kernel(const float* __rest
     go[k] = cc[cc_base + 2 * gate_stride + es];
     gg[k] = cc[cc_base + 3 * gate_stride + es];
     cc_[k] = c_cur[st_base + es];
+  }
+  for (int s = 1; s < n_partials; ++s) {
+    const float* part = cc + static_cast<size_t>(s) * partial_stride;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+      const int es = ok[k] ? lane + k * LPR : 0;
+      gi[k] += part[cc_base + es];
+      gf[k] += part[cc_base + gate_stride + es];
+      go[k] += part[cc_base + 2 * gate_stride + es];
+      gg[k] += part[cc_base + 3 * gate_stride + es];
+    }
   }
   float mu, rstd;
   row_stats<LPR, EPL>(gg, ok, inv_n, &mu, &rstd);
@@ -203,7 +216,16 @@ extern "C" int dvmvs_lstm_gates_fwd(const float* combined_conv, const float* c_c
   if (!combined_conv || !c_cur || !h_next || !c_next) return DVMVS_EINVAL;
   if (B <= 0 || hidden <= 0 || H <= 0 || W <= 0) return DVMVS_EINVAL;
   return dispatch_gates<true>(static_cast<hipStream_t>(stream), B * hidden, H * W, combined_conv, c_cur, h_next, c_next, B,
-                              hidden, H * W);
+                              hidden, H * W, 1, 0LL);
+}
+
+extern "C" int dvmvs_lstm_gates_partials_fwd(const float* conv_partials, int n_partials, const float* c_cur, float* h_next, float* c_next,
+                                             int B, int hidden, int H, int W, dvmvs_stream_t stream) {
+  using namespace dvmvs;
+  if (!conv_partials || !c_cur || !h_next || !c_next) return DVMVS_EINVAL;
+  if (B <= 0 || hidden <= 0 || H <= 0 || W <= 0 || n_partials <= 0) return DVMVS_EINVAL;
+  return dispatch_gates<true>(static_cast<hipStream_t>(stream), B * hidden, H * W, conv_partials, c_cur, h_next, c_next, B,
+                              hidden, H * W, n_partials, static_cast<long long>(B) * 4 * hidden * H * W);
 }
 
 extern "C" int dvmvs_lstm_gates_bwd(const float* grad_h, const float* grad_c, const float* combined_conv,

@@ -16,6 +16,7 @@ struct CostVolumeArgs {
   double inv_depth_base, inv_depth_step;
   int image2_nhwc;     // measurement maps are channels-last ([B,H,W,C]); reference map and output stay NCHW
   unsigned int* spill;   // optional spill workspace of the two-pass tiled sweep (layout: sweep_tiled.hip); nullptr = gather inline
+  const unsigned int* items;   // optional work list of the tiled sweep (dvmvs_sweep_work_list; layout: sweep_tiled.hip); nullptr = static numbering
 };
 
 // Per-(batch, measurement) sweep constants in fp64, rounded once (dvmvs_sweep_matrices: the opt-in "exact" pose algebra).
@@ -101,6 +102,7 @@ inline int fill_sweep_args(CostVolumeArgs* a, const float* image1, const float* 
   a->inv_depth_base = 1.0 / max_depth;
   a->inv_depth_step = D > 1 ? (1.0 / min_depth - 1.0 / max_depth) / (D - 1) : 0.0;
   a->spill = nullptr;
+  a->items = nullptr;
   a->image2_nhwc = 0;
   return 0;
 }

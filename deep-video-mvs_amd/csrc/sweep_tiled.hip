@@ -370,6 +370,15 @@ __device__ inline int plan_runs(const CostVolumeArgs& a, const float* s_H, const
 // 1), so the caller zero-fills a workspace once, when it allocates it, and never again.
 constexpr int kSpillHeaderWords = 4;
 
+// Work items (see host_build_work_list below): a launch has at most twice as many as there are (tile, chunk) pairs -- the static
+// ones plus the pieces cut off long ones --, and the spill workspace has one slot per possible item.
+constexpr int kWorkListHeaderWords = 2;
+__host__ __device__ inline size_t work_list_capacity_items(int B, int H, int W, int D, int TW, int TH, int DP) {
+  const size_t tiles = static_cast<size_t>((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+  const size_t total = tiles * ((D + DP - 1) / DP) * B;
+  return 2 * ((total + 7) / 8 * 8);
+}
+
 __host__ __device__ inline int spill_slot_words(int M, int DP) { return 1 + M * DP; }
 __device__ inline unsigned int spill_pack(int m, int seg_lo, int seg_len) {
   return (static_cast<unsigned int>(m) << 16) | (static_cast<unsigned int>(seg_lo) << 8) | static_cast<unsigned int>(seg_len);
@@ -432,7 +441,7 @@ struct SweepWork {
 };
 
 template <int ORDER>
-__device__ inline SweepWork decode_work(int block, int tiles, int chunks, int B) {
+__host__ __device__ inline SweepWork decode_work(int block, int tiles, int chunks, int B) {
   SweepWork w;
   const int per_b = tiles * chunks, total = per_b * B;
   int v = block;
@@ -473,13 +482,30 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
 
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
   const int chunks = (a.D + DP - 1) / DP;
-  const SweepWork work = decode_work<Cfg::ORDER>(blockIdx.x, tiles_x * tiles_y, chunks, a.B);
-  if (!work.valid) return;
+  // the work item: from the caller's work list (plane sub-ranges cut on the host so that no workgroup has a long chain of runs,
+  // see host_build_work_list), or the static (tile, chunk) numbering
+  SweepWork work;
+  int d_block, planes;
+  if (a.items != nullptr) {
+    const guint_p items = as_global(const_cast<unsigned int*>(a.items));
+    if (blockIdx.x >= items[0]) return;
+    const unsigned int w0 = items[kWorkListHeaderWords + 2 * blockIdx.x], w1 = items[kWorkListHeaderWords + 2 * blockIdx.x + 1];
+    work.b = static_cast<int>(w0 >> 16);
+    work.tile = static_cast<int>(w0 & 0xffffu);
+    work.group = static_cast<int>(blockIdx.x);
+    work.chunk = 0;
+    d_block = static_cast<int>(w1 & 0xffffu);
+    planes = static_cast<int>(w1 >> 16);
+    if (planes == 0) return;
+  } else {
+    work = decode_work<Cfg::ORDER>(blockIdx.x, tiles_x * tiles_y, chunks, a.B);
+    if (!work.valid) return;
+    d_block = work.chunk * DP;
+    planes = min(DP, a.D - d_block);
+  }
   const int b = work.b;
   const int tile_y = work.tile / tiles_x, tile_x = work.tile - tile_y * tiles_x;
-  const int d_block = work.chunk * DP;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int planes = min(DP, a.D - d_block);
   SWEEP_TRACE(unsigned long long tr_stage = 0, tr_taps = 0, tr_passes = 0, tr_records = 0, tr_switch = 0, tr_setup = 0;)
   SWEEP_TRACE(const unsigned long long tr_start = __builtin_amdgcn_s_memtime(); const unsigned long long tr_real0 = __builtin_amdgcn_s_memrealtime();)
 
@@ -533,7 +559,7 @@ __global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_
 
   guint_p slot = nullptr;   // this workgroup's spill slot
   if (!GATHER) {
-    const size_t groups = static_cast<size_t>(tiles_x) * tiles_y * chunks * a.B;
+    const size_t groups = work_list_capacity_items(a.B, a.H, a.W, a.D, TW, TH, DP);
     slot = as_global(a.spill) + kSpillHeaderWords + groups + static_cast<size_t>(work.group) * spill_slot_words(a.M, DP);
   }
   int n_spilled = 0;      // workgroup-uniform
@@ -827,15 +853,25 @@ __global__ __launch_bounds__(Cfg::NPIX) void sweep_spill_kernel(CostVolumeArgs a
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
   const int chunks = (a.D + DP - 1) / DP;
   const int per_b = tiles_x * tiles_y * chunks;
-  const size_t groups = static_cast<size_t>(per_b) * a.B;
+  const size_t groups = work_list_capacity_items(a.B, a.H, a.W, a.D, TW, TH, DP);
   const SweepScale sc = sweep_scale(a.W, a.H);
   for (unsigned int u = blockIdx.x; u < units; u += gridDim.x) {
     const int j = static_cast<int>(u % DP);
     const int group = static_cast<int>(spill[kSpillHeaderWords + u / DP]);
     const guint_p slot = spill + kSpillHeaderWords + groups + static_cast<size_t>(group) * spill_slot_words(a.M, DP);
-    const int b = group / per_b, rem = group - b * per_b;
-    const int tile = rem / chunks, chunk = chunks - 1 - (rem - tile * chunks);
-    const int d = chunk * DP + j;
+    int b, tile, d;
+    if (a.items != nullptr) {      // the group is an item of the work list: its own plane range
+      const guint_p items = as_global(const_cast<unsigned int*>(a.items));
+      const unsigned int w0 = items[kWorkListHeaderWords + 2 * group], w1 = items[kWorkListHeaderWords + 2 * group + 1];
+      b = static_cast<int>(w0 >> 16);
+      tile = static_cast<int>(w0 & 0xffffu);
+      d = j < static_cast<int>(w1 >> 16) ? static_cast<int>(w1 & 0xffffu) + j : a.D;      // (planes beyond the item: nothing to do)
+    } else {
+      b = group / per_b;
+      const int rem = group - b * per_b;
+      tile = rem / chunks;
+      d = (chunks - 1 - (rem - tile * chunks)) * DP + j;
+    }
     const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
     const int x = tile_x * TW + tid % TW, y = tile_y * TH + tid / TW;
     const bool live = d < a.D && x < a.W && y < a.H;
@@ -884,7 +920,9 @@ __global__ __launch_bounds__(Cfg::NPIX) void sweep_spill_kernel(CostVolumeArgs a
 // rule, same greedy choice; the sample positions use IEEE fp32 division, which is what the kernel's refined-reciprocal sequence
 // produces for normal operands, so the model's plan is the kernel's plan (it only has to be close: it selects a configuration, it
 // does not change any configuration's results).  stats[0..5]: staged runs, LDS records of all staged runs, runs entirely outside
-// the image, runs queued for the second pass, their planes (second-pass gathers per pixel), workgroups with at least one queued run.
+// the image, runs queued for the second pass, their planes (second-pass gathers per pixel), workgroups with at least one queued run,
+// the largest number of staged runs any ONE workgroup has (its chain of (run x channel pass) stages is the launch's span: all workgroups
+// are resident at once, so the slowest one decides), the largest number of queued planes of one workgroup.
 #pragma clang fp contract(off)
 inline void host_sweep_position(const SweepRay& r, float kx, float ky, float kz, const SweepScale& s, float* ix, float* iy, float* denom_out) {
   const float denom = (r.Z0 + kz) + 1e-8f;
@@ -894,83 +932,180 @@ inline void host_sweep_position(const SweepRay& r, float kx, float ky, float kz,
   *iy = ((((v - s.hn) / s.hn) + 1.0f) * 0.5f) * s.Hm1;
 }
 
+// One (batch item, tile, chunk) of the sweep on the host: the corner rays per measurement frame and the K t / depth table of the
+// chunk's planes; plan(lo, hi) walks planes [lo, hi) of every frame exactly as plan_runs does for a work item with those planes.
+struct HostRunCounts {
+  long long staged_runs, staged_records, empty_runs, queued_runs, queued_planes;
+};
+
+template <class Cfg>
+struct HostTilePlanner {
+  static constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP, CAP = Cfg::CAP, MINSEG = Cfg::MINSEG;
+  int M, H, W;
+  SweepScale sc;
+  float edge;
+  SweepRay ray[DVMVS_MAX_MEASUREMENTS][4];
+  float ktd[DVMVS_MAX_MEASUREMENTS][DP][3];
+
+  void set_shape(int M_, int H_, int W_) {
+    M = M_; H = H_; W = W_;
+    sc.Wf = static_cast<float>(W); sc.Hf = static_cast<float>(H);
+    sc.wn = sc.Wf * 0.5f; sc.hn = sc.Hf * 0.5f;
+    sc.r_wn = 1.0f / sc.wn; sc.r_hn = 1.0f / sc.hn;
+    sc.Wm1 = static_cast<float>(W - 1); sc.Hm1 = static_cast<float>(H - 1);
+  }
+  void set_chunk(const float* kt_b, int d_block, int planes, double inv_base, double inv_step) {
+    for (int m = 0; m < M; ++m)
+      for (int j = 0; j < planes; ++j) {
+        const float depth = static_cast<float>(1.0 / (inv_base + static_cast<double>(d_block + j) * inv_step));
+        for (int k = 0; k < 3; ++k) ktd[m][j][k] = kt_b[m * 3 + k] / depth;
+      }
+  }
+  void set_tile(const float* Hm_b, int tile_x, int tile_y) {
+    const int x_first = tile_x * TW, x_last = x_first + TW - 1 < W - 1 ? x_first + TW - 1 : W - 1;
+    const int y_first = tile_y * TH, y_last = y_first + TH - 1 < H - 1 ? y_first + TH - 1 : H - 1;
+    edge = static_cast<float>(x_last - x_first > 1 ? x_last - x_first : 1);
+    for (int m = 0; m < M; ++m)
+      for (int c = 0; c < 4; ++c)
+        ray[m][c] = sweep_ray(Hm_b + m * 9, static_cast<float>((c & 1) ? x_last : x_first), static_cast<float>((c & 2) ? y_last : y_first));
+  }
+  // planes [first, last) of the chunk (indices into ktd), all frames
+  HostRunCounts plan(int first, int last) const {
+    HostRunCounts n = {0, 0, 0, 0, 0};
+    for (int m = 0; m < M; ++m) {
+      int lo = first, hint = DP;
+      while (lo < last) {
+        const int len0 = last - lo < hint ? last - lo : hint;
+        int picked_len = len0, picked_state = 0, picked_records = 0;
+        for (int candidate = 0; candidate < 4; ++candidate) {
+          int len = len0;
+          for (int i = 0; i < candidate; ++i) len = (len + 1) / 2 > MINSEG ? (len + 1) / 2 : MINSEG;
+          if (len > len0) len = len0;
+          float lo_x = 0, hi_x = 0, lo_y = 0, hi_y = 0, top[2][2] = {{0, 0}, {0, 0}};
+          bool finite = true;
+          for (int corner = 0; corner < 8; ++corner) {
+            const float* k = ktd[m][(corner & 4) ? lo + len - 1 : lo];
+            float ux, uy, denom;
+            host_sweep_position(ray[m][corner & 3], k[0], k[1], k[2], sc, &ux, &uy, &denom);
+            finite = finite && (ux > -1e6f) && (ux < 1e6f) && (uy > -1e6f) && (uy < 1e6f) && (denom > 1e-6f);
+            if (corner < 2) { top[corner][0] = ux; top[corner][1] = uy; }
+            if (corner == 0) { lo_x = hi_x = ux; lo_y = hi_y = uy; }
+            else { lo_x = fminf(lo_x, ux); hi_x = fmaxf(hi_x, ux); lo_y = fminf(lo_y, uy); hi_y = fmaxf(hi_y, uy); }
+          }
+          const bool outside = (hi_x + 0.05f <= -1.0f) || (lo_x - 0.05f >= sc.Wf) || (hi_y + 0.05f <= -1.0f) || (lo_y - 0.05f >= sc.Hf);
+          int state = 0, records = 0;
+          if (finite && outside) state = 2;
+          else if (finite) {
+            const int bx_lo = static_cast<int>(floorf(fmaxf(lo_x - 0.05f, -1.0f))), by_lo = static_cast<int>(floorf(fmaxf(lo_y - 0.05f, -1.0f)));
+            const int x_lo = bx_lo > -1 ? bx_lo : -1, y_lo = by_lo > -1 ? by_lo : -1;
+            const int bx_hi = static_cast<int>(floorf(fminf(hi_x + 0.05f, sc.Wf))), by_hi = static_cast<int>(floorf(fminf(hi_y + 0.05f, sc.Hf)));
+            const int x_hi = (bx_hi < W ? bx_hi : W) + 1, y_hi = (by_hi < H ? by_hi : H) + 1;
+            const int RW = x_hi - x_lo + 1, RH = y_hi - y_lo + 1;
+            const int pitch = RW + ((sweep_pitch_residue((top[1][0] - top[0][0]) / edge, (top[1][1] - top[0][1]) / edge) - RW) & 15);
+            records = pitch * RH;
+            state = records <= CAP ? 1 : 0;
+          }
+          if (state != 0 || len <= MINSEG || candidate == 3) {
+            picked_len = len; picked_state = state; picked_records = records;
+            break;
+          }
+        }
+        if (picked_state == 1) { ++n.staged_runs; n.staged_records += picked_records; }
+        else if (picked_state == 2) ++n.empty_runs;
+        else { ++n.queued_runs; n.queued_planes += picked_len; }
+        lo += picked_len;
+        hint = picked_len > MINSEG ? picked_len : MINSEG;
+      }
+    }
+    return n;
+  }
+};
+
 template <class Cfg>
 void host_plan_stats(const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step, long long* stats) {
-  constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP, CAP = Cfg::CAP, MINSEG = Cfg::MINSEG;
-  SweepScale sc;
-  sc.Wf = static_cast<float>(W); sc.Hf = static_cast<float>(H);
-  sc.wn = sc.Wf * 0.5f; sc.hn = sc.Hf * 0.5f;
-  sc.r_wn = 1.0f / sc.wn; sc.r_hn = 1.0f / sc.hn;
-  sc.Wm1 = static_cast<float>(W - 1); sc.Hm1 = static_cast<float>(H - 1);
-  for (int i = 0; i < 6; ++i) stats[i] = 0;
+  constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP;
+  HostTilePlanner<Cfg> planner;
+  planner.set_shape(M, H, W);
+  for (int i = 0; i < 8; ++i) stats[i] = 0;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, chunks = (D + DP - 1) / DP;
   for (int b = 0; b < B; ++b)
     for (int chunk = 0; chunk < chunks; ++chunk) {
       const int d_block = chunk * DP, planes = D - d_block < DP ? D - d_block : DP;
-      float ktd[DVMVS_MAX_MEASUREMENTS][DP][3];
-      for (int m = 0; m < M; ++m)
-        for (int j = 0; j < planes; ++j) {
-          const float depth = static_cast<float>(1.0 / (inv_base + static_cast<double>(d_block + j) * inv_step));
-          for (int k = 0; k < 3; ++k) ktd[m][j][k] = kt[(static_cast<size_t>(b) * M + m) * 3 + k] / depth;
-        }
+      planner.set_chunk(kt + static_cast<size_t>(b) * M * 3, d_block, planes, inv_base, inv_step);
       for (int tile_y = 0; tile_y < tiles_y; ++tile_y)
         for (int tile_x = 0; tile_x < tiles_x; ++tile_x) {
-          const int x_first = tile_x * TW, x_last = x_first + TW - 1 < W - 1 ? x_first + TW - 1 : W - 1;
-          const int y_first = tile_y * TH, y_last = y_first + TH - 1 < H - 1 ? y_first + TH - 1 : H - 1;
-          const float edge = static_cast<float>(x_last - x_first > 1 ? x_last - x_first : 1);
-          bool group_spills = false;
-          for (int m = 0; m < M; ++m) {
-            const float* Hm_m = Hm + (static_cast<size_t>(b) * M + m) * 9;
-            SweepRay ray[4];
-            for (int c = 0; c < 4; ++c)
-              ray[c] = sweep_ray(Hm_m, static_cast<float>((c & 1) ? x_last : x_first), static_cast<float>((c & 2) ? y_last : y_first));
-            int lo = 0, hint = DP;
-            while (lo < planes) {
-              const int len0 = planes - lo < hint ? planes - lo : hint;
-              int picked_len = len0, picked_state = 0, picked_records = 0;
-              for (int candidate = 0; candidate < 4; ++candidate) {
-                int len = len0;
-                for (int i = 0; i < candidate; ++i) len = (len + 1) / 2 > MINSEG ? (len + 1) / 2 : MINSEG;
-                if (len > len0) len = len0;
-                float lo_x = 0, hi_x = 0, lo_y = 0, hi_y = 0, top[2][2] = {{0, 0}, {0, 0}};
-                bool finite = true;
-                for (int corner = 0; corner < 8; ++corner) {
-                  const float* k = ktd[m][(corner & 4) ? lo + len - 1 : lo];
-                  float ux, uy, denom;
-                  host_sweep_position(ray[corner & 3], k[0], k[1], k[2], sc, &ux, &uy, &denom);
-                  finite = finite && (ux > -1e6f) && (ux < 1e6f) && (uy > -1e6f) && (uy < 1e6f) && (denom > 1e-6f);
-                  if (corner < 2) { top[corner][0] = ux; top[corner][1] = uy; }
-                  if (corner == 0) { lo_x = hi_x = ux; lo_y = hi_y = uy; }
-                  else { lo_x = fminf(lo_x, ux); hi_x = fmaxf(hi_x, ux); lo_y = fminf(lo_y, uy); hi_y = fmaxf(hi_y, uy); }
-                }
-                const bool outside = (hi_x + 0.05f <= -1.0f) || (lo_x - 0.05f >= sc.Wf) || (hi_y + 0.05f <= -1.0f) || (lo_y - 0.05f >= sc.Hf);
-                int state = 0, records = 0;
-                if (finite && outside) state = 2;
-                else if (finite) {
-                  const int bx_lo = static_cast<int>(floorf(fmaxf(lo_x - 0.05f, -1.0f))), by_lo = static_cast<int>(floorf(fmaxf(lo_y - 0.05f, -1.0f)));
-                  const int x_lo = bx_lo > -1 ? bx_lo : -1, y_lo = by_lo > -1 ? by_lo : -1;
-                  const int bx_hi = static_cast<int>(floorf(fminf(hi_x + 0.05f, sc.Wf))), by_hi = static_cast<int>(floorf(fminf(hi_y + 0.05f, sc.Hf)));
-                  const int x_hi = (bx_hi < W ? bx_hi : W) + 1, y_hi = (by_hi < H ? by_hi : H) + 1;
-                  const int RW = x_hi - x_lo + 1, RH = y_hi - y_lo + 1;
-                  const int pitch = RW + ((sweep_pitch_residue((top[1][0] - top[0][0]) / edge, (top[1][1] - top[0][1]) / edge) - RW) & 15);
-                  records = pitch * RH;
-                  state = records <= CAP ? 1 : 0;
-                }
-                if (state != 0 || len <= MINSEG || candidate == 3) {
-                  picked_len = len; picked_state = state; picked_records = records;
-                  break;
-                }
-              }
-              if (picked_state == 1) { ++stats[0]; stats[1] += picked_records; }
-              else if (picked_state == 2) ++stats[2];
-              else { ++stats[3]; stats[4] += picked_len; group_spills = true; }
-              lo += picked_len;
-              hint = picked_len > MINSEG ? picked_len : MINSEG;
-            }
-          }
-          if (group_spills) ++stats[5];
+          planner.set_tile(Hm + static_cast<size_t>(b) * M * 9, tile_x, tile_y);
+          const HostRunCounts n = planner.plan(0, planes);
+          stats[0] += n.staged_runs; stats[1] += n.staged_records; stats[2] += n.empty_runs; stats[3] += n.queued_runs; stats[4] += n.queued_planes;
+          if (n.queued_runs > 0) ++stats[5];
+          if (n.staged_runs > stats[6]) stats[6] = n.staged_runs;
+          if (n.queued_planes > stats[7]) stats[7] = n.queued_planes;
         }
     }
+}
+
+// ---- work list ------------------------------------------------------------------------------------------------------------
+// All workgroups of a launch are resident at once, so the launch lasts as long as its slowest workgroup: one whose sample boxes had
+// to be halved works through (runs x channel passes) stages -- 5 to 8 runs instead of 2 on wide-baseline and forward-motion pairs,
+// 55-135 us instead of 35 (tools/sweep_select_fit.py on all 285 keyframe pairs of the sample scene).  The host knows the plan before
+// the launch, so it hands the kernel a WORK LIST in which such a (tile, chunk) is cut into plane sub-ranges with at most
+// kMaxRunsPerItem staged runs each, processed by separate workgroups in parallel.  Words: [0] = number of items, [1] = 0, then per item
+// {tile | batch item << 16, first plane | number of planes << 16}.  The first `static` items sit at the positions the static numbering
+// gives their (tile, chunk) -- XCD locality and the CU mix stay as decode_work arranges them --, the extra pieces follow.
+constexpr int kMaxRunsPerItem = 3;
+
+template <class Cfg>
+int host_build_work_list(const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,
+                         unsigned int* items, size_t capacity_words) {
+  constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, chunks = (D + DP - 1) / DP;
+  const int tiles = tiles_x * tiles_y;
+  const long long total = static_cast<long long>(tiles) * chunks * B;
+  if (tiles > 65535 || B > 65535 || D > 65535) return DVMVS_EUNSUPPORTED;
+  const size_t positions = static_cast<size_t>((total + 7) / 8 * 8);
+  const size_t capacity = work_list_capacity_items(B, H, W, D, TW, TH, DP);
+  if (capacity_words < kWorkListHeaderWords + 2 * capacity) return DVMVS_EINVAL;
+  HostTilePlanner<Cfg> planner;
+  planner.set_shape(M, H, W);
+  size_t extra = positions;      // next free position behind the statically numbered ones
+  int cached_b = -1, cached_chunk = -1;
+  for (size_t block = 0; block < positions; ++block) {
+    const SweepWork work = decode_work<Cfg::ORDER>(static_cast<int>(block), tiles, chunks, B);
+    unsigned int* item = items + kWorkListHeaderWords + 2 * block;
+    item[0] = 0u; item[1] = 0u;      // (padding positions: no planes)
+    if (!work.valid) continue;
+    const int d_block = work.chunk * DP, planes = D - d_block < DP ? D - d_block : DP;
+    if (work.b != cached_b || work.chunk != cached_chunk) {
+      planner.set_chunk(kt + static_cast<size_t>(work.b) * M * 3, d_block, planes, inv_base, inv_step);
+      cached_b = work.b; cached_chunk = work.chunk;
+    }
+    planner.set_tile(Hm + static_cast<size_t>(work.b) * M * 9, work.tile % tiles_x, work.tile / tiles_x);
+    // cut [0, planes) into pieces of at most kMaxRunsPerItem staged runs (halving; a piece of MINSEG planes is never cut)
+    int piece_lo[DP], piece_hi[DP], n_pieces = 0;
+    int stack_lo[2 * DP], stack_hi[2 * DP], top = 0;
+    stack_lo[0] = 0; stack_hi[0] = planes; top = 1;
+    while (top > 0) {
+      --top;
+      const int lo = stack_lo[top], hi = stack_hi[top];
+      const bool cut = hi - lo > Cfg::MINSEG && planner.plan(lo, hi).staged_runs > kMaxRunsPerItem && extra + n_pieces < capacity;
+      if (cut) {
+        const int mid = lo + (hi - lo + 1) / 2;
+        stack_lo[top] = mid; stack_hi[top] = hi; ++top;     // (popped second: pieces come out in plane order)
+        stack_lo[top] = lo; stack_hi[top] = mid; ++top;
+      } else {
+        piece_lo[n_pieces] = lo; piece_hi[n_pieces] = hi; ++n_pieces;
+      }
+    }
+    const unsigned int w0 = static_cast<unsigned int>(work.tile) | (static_cast<unsigned int>(work.b) << 16);
+    for (int i = 0; i < n_pieces; ++i) {
+      unsigned int* dst = i == 0 ? item : items + kWorkListHeaderWords + 2 * extra++;
+      dst[0] = w0;
+      dst[1] = static_cast<unsigned int>(d_block + piece_lo[i]) | (static_cast<unsigned int>(piece_hi[i] - piece_lo[i]) << 16);
+    }
+  }
+  items[0] = static_cast<unsigned int>(extra);
+  items[1] = 0u;
+  return static_cast<int>(kWorkListHeaderWords + 2 * extra);
 }
 #pragma clang fp contract(fast)
 
@@ -999,7 +1134,9 @@ int launch_sweep_tiled_layout(const CostVolumeArgs& a, hipStream_t stream, int s
   const long long tiles = static_cast<long long>((a.W + Cfg::TW - 1) / Cfg::TW) * ((a.H + Cfg::TH - 1) / Cfg::TH);
   const long long total = tiles * ((a.D + Cfg::DP - 1) / Cfg::DP) * a.B;
   if (total > (1LL << 30)) return DVMVS_EUNSUPPORTED;
-  const unsigned int grid = static_cast<unsigned int>(Cfg::ORDER >= 1 ? (total + 7) / 8 * 8 : total);
+  // with a work list: one workgroup per possible item (those beyond the list's count return at once)
+  const unsigned int grid = a.items != nullptr ? static_cast<unsigned int>(work_list_capacity_items(a.B, a.H, a.W, a.D, Cfg::TW, Cfg::TH, Cfg::DP))
+                                               : static_cast<unsigned int>(Cfg::ORDER >= 1 ? (total + 7) / 8 * 8 : total);
   if (a.spill == nullptr) {
     static bool configured[kMaxDevices] = {};
     auto kernel = sweep_tiled_kernel<Cfg, NHWC, true>;
@@ -1032,15 +1169,20 @@ using SweepDefault = SweepConfig<32, 8, 8, 8, 1024, 2>;   // <TW, TH, DP, CCH, C
 
 template <class Cfg>
 size_t spill_words_for(int B, int M, int H, int W, int D) {
-  const size_t tiles = static_cast<size_t>((W + Cfg::TW - 1) / Cfg::TW) * ((H + Cfg::TH - 1) / Cfg::TH);
-  const size_t groups = tiles * ((D + Cfg::DP - 1) / Cfg::DP) * B;
+  const size_t groups = work_list_capacity_items(B, H, W, D, Cfg::TW, Cfg::TH, Cfg::DP);
   return kSpillHeaderWords + groups + groups * spill_slot_words(M, Cfg::DP);
 }
 
-// sized for the finest tiling among the configurations that may use it (each launch indexes it with its own tiling)
+// one slot per possible work item of the product configurations (both use the 32x8x8 tiling); the tools-only tuning build also sizes it
+// for its finest tiling (each launch indexes it with its own tiling)
 size_t sweep_spill_words(int B, int M, int H, int W, int D) {
-  const size_t a = spill_words_for<SweepDefault>(B, M, H, W, D), b = spill_words_for<SweepConfig<32, 4, 8, 8, 640, 2>>(B, M, H, W, D);
+  const size_t a = spill_words_for<SweepDefault>(B, M, H, W, D);
+#ifdef DVMVS_SWEEP_TUNING
+  const size_t b = spill_words_for<SweepConfig<32, 4, 8, 8, 640, 2>>(B, M, H, W, D);
   return a > b ? a : b;
+#else
+  return a;
+#endif
 }
 
 int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream) { return launch_sweep_tiled<SweepDefault>(a, stream); }
@@ -1051,6 +1193,16 @@ int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream) { return l
 // so the caller picks per keyframe pair (dvmvs_sweep_select_variant: the host-side plan model below).
 using SweepWide = SweepConfig<32, 8, 8, 8, 1536, 2, 4, 2, 2, true, true, 2>;
 int launch_sweep_wide(const CostVolumeArgs& a, hipStream_t stream) { return launch_sweep_tiled<SweepWide>(a, stream); }
+
+size_t sweep_work_list_words(int B, int H, int W, int D) {
+  return kWorkListHeaderWords + 2 * work_list_capacity_items(B, H, W, D, SweepDefault::TW, SweepDefault::TH, SweepDefault::DP);
+}
+
+int sweep_work_list_host(int configuration, const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,
+                         unsigned int* items, size_t capacity_words) {
+  if (configuration == 1) return host_build_work_list<SweepWide>(Hm, kt, B, M, H, W, D, inv_base, inv_step, items, capacity_words);
+  return host_build_work_list<SweepDefault>(Hm, kt, B, M, H, W, D, inv_base, inv_step, items, capacity_words);
+}
 
 void sweep_plan_stats_host(int configuration, const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,
                            long long* stats) {

@@ -40,6 +40,14 @@ from dvmvs.hip import ops as _ops
 from dvmvs import pose_algebra as _pose_algebra
 from dvmvs import utils as _utils
 
+# MIOpen's fp32 `igemm_fwd_gtcx35_nhwc_*_gkgs` kernels split the reduction over workgroups and accumulate with float ATOMICS: their
+# result differs from run to run (measured: tools/conv_determinism_probe.py -- four layers of a frame, among them 64 -> 64 5x5 at quarter
+# resolution), which a depth engine whose recurrent state passes through a discrete z-buffer cannot tolerate (one flipped pixel and the
+# runs diverge).  MIOpen reads this switch when it looks for solvers; with the family off it solves those layers with its GEMM /
+# Winograd / direct kernels, which are deterministic.  (The bottleneck layers do not reach MIOpen at all: csrc/bottleneck_conv.hip.)
+# Set before the first convolution; a caller that exported its own value keeps it.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC", "0")
+
 _MAX_MEAS = 8            # DVMVS_MAX_MEASUREMENTS of the C ABI
 _STAGING_SLOTS = 8       # pinned staging ring: the host may run this many frames ahead of the device
 
@@ -124,6 +132,11 @@ class FusedConv2d(nn.Module):
         # {input shape: (use the plan, plan us, two-launch us, max |difference|)}
         self.plan_epilogue = False       # set by DepthEngine(conv_plans=True)
         self.plans = {}
+        # 3x3 layers on the bottleneck maps (8x10, 16x20): the deterministic weight-streaming MFMA kernel instead of MIOpen's
+        # atomically accumulated split-K kernels (csrc/bottleneck_conv.hip); {input shape: (splits, partial-sum buffer) or None}
+        self.bottleneck = False          # set by DepthEngine(bottleneck_convs=True)
+        self._bottleneck_packed = None
+        self._bottleneck_buffers = {}
 
         k = conv.kernel_size
         self.depthwise = (conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1 and k[0] == k[1] and k[0] in (3, 5)
@@ -144,6 +157,15 @@ class FusedConv2d(nn.Module):
                                        pre if pre is not None else self._no_bias, pre is not None)
         if self.pre_bias is not None:
             raise RuntimeError("a depthwise layer with a deferred input epilogue must take the depthwise kernel")
+        if self.bottleneck and residual is None and not raw and not self.defer_epilogue and x.is_contiguous() and \
+                act in (_ops.ACTIVATIONS["none"], _ops.ACTIVATIONS["relu"]):
+            buffers = self._bottleneck_for(x)
+            if buffers is not None:
+                B, _, H, W = x.shape
+                shape = (B, self.weight.shape[0], H // self.stride[0], W // self.stride[0])
+                splits = _ops.bottleneck_conv_into(x, self._bottleneck_packed, shape[1], self.stride[0], buffers)
+                dst = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
+                return _ops.partial_sums_bias_act_into(buffers, splits, dst, self.bias, act, shape)
         if (self.plan_epilogue and residual is None and not raw and not self.defer_epilogue and self._plan_eligible(act)
                 and x.is_contiguous()):
             key = tuple(x.shape)
@@ -164,6 +186,26 @@ class FusedConv2d(nn.Module):
         if self.defer_epilogue or raw:
             return y
         return _ops.bias_act_into(y, y if out is None else out, self.bias, act, residual, residual_mode if residual is not None else 0, p0, p1)
+
+    def _bottleneck_for(self, x):
+        """The partial-sum buffer for this input shape if the bottleneck kernel takes the problem (else None); packs the weights the
+        first time (outside a stream capture: the first frame of every kind runs eagerly)."""
+        key = tuple(x.shape)
+        if key not in self._bottleneck_buffers:
+            k = self.weight.shape
+            ok = (not self.depthwise and self.groups == 1 and k[2] == 3 and k[3] == 3 and tuple(self.padding) == (1, 1) and
+                  tuple(self.dilation) == (1, 1) and self.stride[0] == self.stride[1])
+            splits = _ops.bottleneck_conv_splits(x.shape[0], k[0], k[1], x.shape[2], x.shape[3], self.stride[0]) if ok else 0
+            if splits == 0:
+                self._bottleneck_buffers[key] = None
+            elif torch.cuda.is_current_stream_capturing():
+                return None      # (not cached: decided at the next eager call)
+            else:
+                if self._bottleneck_packed is None:
+                    self._bottleneck_packed = _ops.bottleneck_conv_pack(self.weight.detach())
+                P = (x.shape[2] // self.stride[0]) * (x.shape[3] // self.stride[0])
+                self._bottleneck_buffers[key] = torch.empty(splits * x.shape[0] * k[0] * P, device=x.device, dtype=torch.float32)
+        return self._bottleneck_buffers[key]
 
     def _plan_eligible(self, act):
         k = self.weight.shape
@@ -257,7 +299,7 @@ class DepthEngine:
     def __init__(self, feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder,
                  device="cuda", min_depth=0.25, max_depth=20.0, n_depth_levels=64, fold_bn=True, cache_features=True,
                  use_graphs=True, cache_size=None, channels_last=False, fuse=True, lstm_channels_last=True, sequences=1,
-                 pose_algebra=None, conv_plans=None):
+                 pose_algebra=None, conv_plans=None, bottleneck_convs=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DepthEngine runs on an MI355X; there is no CPU execution path in this package")
@@ -277,6 +319,16 @@ class DepthEngine:
             for sub in ([] if m is None else m.modules()):
                 if isinstance(sub, FusedConv2d):
                     sub.plan_epilogue = self.conv_plans
+        # the 3x3 layers on the 8x10 / 16x20 maps and the ConvLSTM convolution through the deterministic MFMA kernel
+        # (csrc/bottleneck_conv.hip; DVMVS_BOTTLENECK_CONVS=0: MIOpen as everywhere else)
+        if bottleneck_convs is None:
+            bottleneck_convs = os.environ.get("DVMVS_BOTTLENECK_CONVS", "1") != "0"
+        self.bottleneck_convs = bool(bottleneck_convs and fuse and not channels_last)
+        for m in mods:
+            for sub in ([] if m is None else m.modules()):
+                if isinstance(sub, FusedConv2d):
+                    sub.bottleneck = self.bottleneck_convs
+        self._lstm_packed, self._lstm_partials = None, None
         if lstm_channels_last and self.lstm is not None and not channels_last:
             # the ConvLSTM convolution (1024 -> 2048 channels on an 8x10 map, 75 MB of weights) is weight-bandwidth bound;
             # MIOpen's NHWC kernel for it takes 56 us against 88 us for NCHW, which more than pays for the two small layout
@@ -304,6 +356,8 @@ class DepthEngine:
         self._direct_buffers = {}
         self._warm = set()
         self.sweep_variant_counts = {}     # frames per sweep configuration (dvmvs_cost_volume_fwd's variant) since construction
+        # host-planned work list for the sweep: only where the matrices exist on the host, and one plan per launch (one sequence)
+        self.sweep_work_list = bool(_utils.SWEEP_WORK_LIST and self.pose_algebra == "reference" and _utils.COST_VOLUME_VARIANT in (0, 2, 3))
         self.reset()
 
     def conv_plan_report(self):
@@ -395,7 +449,9 @@ class DepthEngine:
             # pointing at the right place; Hm / kt are sized for the ABI's maximum number of measurement frames
             sizes = [("Hm", S * _MAX_MEAS * 9), ("kt", S * _MAX_MEAS * 3), ("reproject_T", S * 16), ("lstm_T", S * 16),
                      ("full_K", S * 9), ("half_K", S * 9), ("lstm_K", S * 9), ("pose", S * 16), ("prev_pose", S * 16),
-                     ("meas_pose", _MAX_MEAS * S * 16)]
+                     ("meas_pose", _MAX_MEAS * S * 16),
+                     # the sweep's work list (32-bit words, planned on the host per frame: dvmvs_sweep_work_list) rides in the same upload
+                     ("sweep_items", _ops.sweep_work_list_words(S, H // 2, W // 2, self.n_depth_levels))]
             self._param_offsets, total = {}, 0
             for name, n in sizes:
                 self._param_offsets[name] = (total, n)
@@ -435,6 +491,13 @@ class DepthEngine:
         o_h, o_k = self._param_offsets["Hm"][0], self._param_offsets["kt"][0]
         return p[o_h:o_h + S * n_meas * 9].view(S, n_meas, 9), p[o_k:o_k + S * n_meas * 3].view(S, n_meas, 3)
 
+    def _sweep_items(self):
+        """The device copy of this frame's work list (a fixed region of the parameter buffer: captured graphs keep pointing at it)."""
+        if not self.sweep_work_list:
+            return None
+        o, n = self._param_offsets["sweep_items"]
+        return self._static["params"].view(torch.int32)[o:o + n]
+
     def _upload_frame_parameters(self, n_meas, pose, measurement_poses, full_K):
         """Evaluates the frame's small matrices on the host (reference mode) and sends them, the intrinsics and the poses to
         the device with ONE asynchronous copy out of a pinned staging slot.  The slot's previous copy (issued _STAGING_SLOTS
@@ -466,6 +529,10 @@ class DepthEngine:
             put("kt", kt)
             # which sweep configuration suits this keyframe geometry: decided here, on the host copies (one graph per configuration)
             sweep_variant = _utils.sweep_variant((Hm, kt), self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth)
+            if self.sweep_work_list:
+                o, n = self._param_offsets["sweep_items"]
+                _ops.sweep_work_list_host(Hm, kt, self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth, sweep_variant,
+                                          out=staging.view(torch.int32)[o:o + n])
             if self.is_fusionnet:
                 eye = torch.eye(4).expand(S, 4, 4)
                 if bool(self._no_previous.all()):      # nothing to relate to: the identity, exactly (see above)
@@ -511,6 +578,21 @@ class DepthEngine:
     def _upsampled_depth_head(head, x, dst):
         _ops.upsample2x_into(head[0](x, raw=True), dst, head[0].bias, _ops.ACTIVATIONS["sigmoid"])
 
+    def _lstm_bottleneck(self, x):
+        """Whether the ConvLSTM convolution of input ``x`` goes through the bottleneck kernel (packs its weights the first time)."""
+        if not self.bottleneck_convs:
+            return False
+        if self._lstm_packed is None:
+            conv = self.lstm.lstm_cell.conv
+            k = conv.weight.shape
+            ok = conv.bias is None and tuple(k[2:]) == (3, 3) and tuple(conv.padding) == (1, 1) and tuple(conv.stride) == (1, 1) and conv.groups == 1
+            splits = _ops.bottleneck_conv_splits(x.shape[0], k[0], k[1], x.shape[2], x.shape[3], 1) if ok else 0
+            if splits == 0 or torch.cuda.is_current_stream_capturing():
+                return False
+            self._lstm_packed = _ops.bottleneck_conv_pack(conv.weight.detach())
+            self._lstm_partials = torch.empty(splits * x.shape[0] * k[0] * x.shape[2] * x.shape[3], device=x.device, dtype=torch.float32)
+        return True
+
     def _frame_body_direct(self, n_meas, has_previous, sweep_variant=0):
         s, d = self._static, self._direct_buffers
         enc_cat, dec_cat = d["enc_cat"], d["dec_cat"]
@@ -519,7 +601,8 @@ class DepthEngine:
         Hm, kt = self._sweep_views(n_meas)
         if self.pose_algebra == "exact":
             Hm, kt = _ops.sweep_matrices(s["pose"], s["meas_pose"][:n_meas], s["half_K"])
-        _ops.cost_volume_into(s["ref_half"], s["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, enc_cat[0][:, 32:], sweep_variant)
+        _ops.cost_volume_into(s["ref_half"], s["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, enc_cat[0][:, 32:], sweep_variant,
+                              self._sweep_items())
         # encoder: aggregator output = skip connection, written where the decoder will read it
         enc, dec = self.enc, self.dec
         x = None
@@ -547,10 +630,16 @@ class DepthEngine:
                 _ops.hidden_warp_into(s["h"], d["estimate"], lstm_T, s["lstm_K"], True, d["lstm_cat"][:, 512:])
             else:
                 d["lstm_cat"][:, 512:].copy_(s["h"])      # first frame of a sequence: the (zero) state as it is, no warp (convlstm.py:29)
-            combined = cell.conv(d["lstm_cat"])
-            if not combined.is_contiguous():       # channels-last convolution (lstm_channels_last): back to the gates' NCHW rows
-                combined = combined.contiguous()
-            _ops.lstm_gates_into(combined, s["c"], s["h"])
+            if self._lstm_bottleneck(d["lstm_cat"]):
+                # the 1024 -> 2048-channel convolution as K-split partial sums (75 MB of weights streamed once through the MFMA
+                # pipe), added up in a fixed order by the gates kernel itself
+                splits = _ops.bottleneck_conv_into(d["lstm_cat"], self._lstm_packed, cell.conv.weight.shape[0], 1, self._lstm_partials)
+                _ops.lstm_gates_partials_into(self._lstm_partials, splits, s["c"], s["h"])
+            else:
+                combined = cell.conv(d["lstm_cat"])
+                if not combined.is_contiguous():       # channels-last convolution (lstm_channels_last): back to the gates' NCHW rows
+                    combined = combined.contiguous()
+                _ops.lstm_gates_into(combined, s["c"], s["h"])
             bottom = s["h"]
         d1 = self._decoder_block_direct(dec.decoder_block1, bottom, dec_cat[0], None, None)
         d2 = self._decoder_block_direct(dec.decoder_block2, d1, dec_cat[1], dec.depth_layer_one_sixteen, d1)
@@ -577,7 +666,7 @@ class DepthEngine:
         if exact:
             Hm, kt = _ops.sweep_matrices(s["pose"], s["meas_pose"][:n_meas], s["half_K"])
         cost_volume = _ops.cost_volume(ref_half, s["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, self.n_depth_levels,
-                                       True, sweep_variant)
+                                       True, sweep_variant, self._sweep_items())
         skip0, skip1, skip2, skip3, bottom = self.enc(ref_half, feats[1], feats[2], feats[3], cost_volume)
         if self.is_fusionnet:
             if has_previous:

@@ -41,6 +41,11 @@ SIGNATURES = {
     "dvmvs_sweep_plan_stats": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _c_dbl, _c_int,
                                         ctypes.POINTER(ctypes.c_longlong)]),
     "dvmvs_sweep_select_variant": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _c_dbl]),
+    "dvmvs_sweep_work_list_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int]),
+    "dvmvs_sweep_work_list": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _c_dbl, _c_int, _c_fp, ctypes.c_size_t]),
+    "dvmvs_cost_volume_planned_fwd": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fp, _c_fp,
+                                               _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                               _c_dbl, _c_dbl, _c_int, _c_int, _c_int, _c_fp, ctypes.c_size_t, _c_fp, _c_stream]),
     "dvmvs_cost_volume_bwd": (_c_int, [_c_fp, _c_fp, _c_fpp, _c_fp, _c_fp, _c_fp, _c_fpp,
                                        _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                        _c_dbl, _c_dbl, _c_stream]),
@@ -49,6 +54,12 @@ SIGNATURES = {
     "dvmvs_relative_pose": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_stream]),
     "dvmvs_lstm_gates_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_lstm_gates_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "dvmvs_lstm_gates_partials_fwd": (_c_int, [_c_fp, _c_int, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "dvmvs_bottleneck_conv_packed_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
+    "dvmvs_bottleneck_conv_pack": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_stream]),
+    "dvmvs_bottleneck_conv_splits": (_c_int, [_c_int] * 6),
+    "dvmvs_bottleneck_conv_fwd": (_c_int, [_c_fp, _c_fp, _c_fp] + [_c_int] * 6 + [_c_stream]),
+    "dvmvs_partial_sums_bias_act_fwd": (_c_int, [_c_fp, _c_int, _c_fp, ctypes.c_longlong, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_depth_reproject_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int,
                                            _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_bias_act_fwd": (_c_int, [_c_fp, _c_fp, ctypes.c_longlong, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

@@ -6,7 +6,7 @@ whole frame can be captured into a hipGraph (``torch.cuda.graph``).  Tensors tha
 the CPU restatement lives in ``oracle/`` and is test infrastructure only.
 """
 import os
-from typing import Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor
@@ -81,10 +81,45 @@ def _check_sweep_matrices(name, Hm, kt, B, M):
                          f"got {tuple(Hm.shape)} and {tuple(kt.shape)}")
 
 
+def sweep_work_list_words(B: int, H: int, W: int, D: int) -> int:
+    """32-bit words of a sweep work list for this shape (dvmvs_sweep_work_list_bytes / 4)."""
+    return int(_capi.lib().dvmvs_sweep_work_list_bytes(int(B), int(H), int(W), int(D))) // 4
+
+
+def sweep_work_list_host(Hm: Tensor, kt: Tensor, H: int, W: int, D: int, min_depth: float, max_depth: float, variant: int, out: Optional[Tensor] = None):
+    """The tiled sweep's work list for HOST matrices ``Hm`` [B,M,9] / ``kt`` [B,M,3] (dvmvs_sweep_work_list: (tile, chunk) pairs whose
+    sample boxes had to be halved are cut into plane sub-ranges that separate workgroups process in parallel), as an int32 host tensor
+    (``out``: a caller-owned one, e.g. a slice of pinned staging memory).  ``variant``: the launch's (3 = wide configuration)."""
+    Hm, kt = Hm.contiguous(), kt.contiguous()
+    if Hm.device.type != "cpu" or Hm.dtype != torch.float32 or kt.dtype != torch.float32:
+        raise ValueError("sweep_work_list_host needs the float32 HOST copies of the sweep matrices")
+    B, M = Hm.shape[0], Hm.shape[1]
+    words = sweep_work_list_words(B, H, W, D)
+    if out is None:
+        out = torch.empty(words, dtype=torch.int32)
+    if out.device.type != "cpu" or out.dtype != torch.int32 or out.numel() < words or not out.is_contiguous():
+        raise ValueError(f"work list buffer must be a contiguous int32 host tensor of at least {words} words")
+    used = _capi.lib().dvmvs_sweep_work_list(Hm.data_ptr(), kt.data_ptr(), B, M, int(H), int(W), int(D), float(min_depth), float(max_depth),
+                                             1 if variant == 3 else 0, out.data_ptr(), out.numel() * 4)
+    if used < 0:
+        _capi.check(used, "dvmvs_sweep_work_list")
+    return out
+
+
+def _work_list_ptr(work_list, image1, B, H, W, D):
+    if work_list is None:
+        return None
+    if work_list.device != image1.device or work_list.dtype != torch.int32 or not work_list.is_contiguous() or \
+            work_list.numel() < sweep_work_list_words(B, H, W, D):
+        raise ValueError("dvmvs::cost_volume: work_list must be a contiguous int32 tensor of dvmvs_sweep_work_list_bytes on the features' device")
+    return work_list.data_ptr()
+
+
 @torch.library.custom_op("dvmvs::cost_volume", mutates_args=(), device_types="cuda")
 def cost_volume(image1: Tensor, image2s: Sequence[Tensor], Hm: Tensor, kt: Tensor,
-                min_depth: float, max_depth: float, n_depth_levels: int, dot_product: bool, variant: int) -> Tensor:
-    """``Hm`` [B,M,9] = K R K^-1 and ``kt`` [B,M,3] = K t per (batch item, measurement frame): dvmvs.pose_algebra."""
+                min_depth: float, max_depth: float, n_depth_levels: int, dot_product: bool, variant: int, work_list: Optional[Tensor] = None) -> Tensor:
+    """``Hm`` [B,M,9] = K R K^-1 and ``kt`` [B,M,3] = K t per (batch item, measurement frame): dvmvs.pose_algebra.  ``work_list``: the
+    device copy of ``sweep_work_list_host``'s result for these matrices (optional; the tiled sweep then cuts long workgroups)."""
     _dev_f32("cost_volume", image1, Hm, kt, *image2s)
     M = len(image2s)
     if M == 0:
@@ -104,30 +139,31 @@ def cost_volume(image1: Tensor, image2s: Sequence[Tensor], Hm: Tensor, kt: Tenso
     out = torch.empty((B, n_depth_levels, H, W), dtype=torch.float32, device=image1.device)
     lib = _capi.lib()
     workspace, ws_bytes = sweep_workspace(image1.device, B, M, H, W, n_depth_levels) if COST_VOLUME_TWO_PASS else (None, 0)
+    items = _work_list_ptr(work_list, image1, B, H, W, n_depth_levels)
     with torch.cuda.device(image1.device):
-        rc = lib.dvmvs_cost_volume_fwd(
+        rc = lib.dvmvs_cost_volume_planned_fwd(
             _ptr(image1), _capi.pointer_array([_ptr(t) for t in image2s]), _ptr(Hm), _ptr(kt), _ptr(out),
             B, M, C, H, W, n_depth_levels, float(min_depth), float(max_depth), int(bool(dot_product)), int(variant),
-            _capi.LAYOUT_NHWC if nhwc else _capi.LAYOUT_NCHW, _ptr(workspace) if workspace is not None else None, ws_bytes, _stream(image1))
+            _capi.LAYOUT_NHWC if nhwc else _capi.LAYOUT_NCHW, _ptr(workspace) if workspace is not None else None, ws_bytes, items, _stream(image1))
     if rc != 0 and workspace is not None:
         drop_sweep_workspace(image1.device, B, M, H, W, n_depth_levels)
-    _capi.check(rc, "dvmvs_cost_volume_fwd")
+    _capi.check(rc, "dvmvs_cost_volume_planned_fwd")
     return out
 
 
 @cost_volume.register_fake
-def _(image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant):
+def _(image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant, work_list=None):
     B, C, H, W = image1.shape
     return image1.new_empty((B, n_depth_levels, H, W))
 
 
 @cost_volume.register_kernel("cpu")
-def _(image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant):
+def _(image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant, work_list=None):
     _no_cpu("cost_volume")
 
 
 def _cost_volume_setup(ctx, inputs, output):
-    image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant = inputs
+    image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant = inputs[:9]
     if not dot_product and (image1.requires_grad or any(t.requires_grad for t in image2s)):
         raise NotImplementedError("dvmvs::cost_volume: gradients are implemented for dot_product=True only")
     ctx.M = len(image2s)
@@ -155,7 +191,7 @@ def _cost_volume_backward(ctx, grad):
             _ptr(g1), _capi.pointer_array([_ptr(t) for t in g2] if need2 else [None] * M),
             B, M, C, H, W, D, float(min_depth), float(max_depth), _stream(image1))
     _capi.check(rc, "dvmvs_cost_volume_bwd")
-    return g1, (g2 if need2 else [None] * M), None, None, None, None, None, None, None
+    return g1, (g2 if need2 else [None] * M), None, None, None, None, None, None, None, None
 
 
 torch.library.register_autograd("dvmvs::cost_volume", _cost_volume_backward, setup_context=_cost_volume_setup)
@@ -573,6 +609,72 @@ def lstm_gates_into(combined_conv: Tensor, c_state: Tensor, h_state: Tensor) -> 
     _capi.check(rc, "dvmvs_lstm_gates_fwd")
 
 
+# ---- 3x3 convolutions on the bottleneck maps (csrc/bottleneck_conv.hip): weight-streaming fp32 MFMA GEMM, deterministic split-K ----
+def bottleneck_conv_splits(B: int, C_out: int, C_in: int, H_in: int, W_in: int, stride: int) -> int:
+    """Number of K-splits (partial sums) dvmvs_bottleneck_conv_fwd produces for this problem; 0 when the kernel does not take it
+    (other map sizes, C_in not a multiple of 16): the caller stays on MIOpen."""
+    n = _capi.lib().dvmvs_bottleneck_conv_splits(int(B), int(C_out), int(C_in), int(H_in), int(W_in), int(stride))
+    return n if n > 0 else 0
+
+
+def bottleneck_conv_pack(weight: Tensor) -> Tensor:
+    """[C_out, C_in, 3, 3] convolution weights re-packed once into the MFMA A-operand order the kernel streams."""
+    _dev_f32("bottleneck_conv_pack", weight)
+    C_out, C_in, kh, kw = weight.shape
+    nbytes = _capi.lib().dvmvs_bottleneck_conv_packed_bytes(C_out, C_in) if (kh, kw) == (3, 3) else 0
+    if nbytes == 0:
+        raise ValueError(f"dvmvs::bottleneck_conv_pack: need a 3x3 kernel and C_in % 16 == 0, got {tuple(weight.shape)}")
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = _capi.lib().dvmvs_bottleneck_conv_pack(_ptr(weight.contiguous()), _ptr(packed), C_out, C_in, _stream(weight))
+    _capi.check(rc, "dvmvs_bottleneck_conv_pack")
+    return packed
+
+
+def bottleneck_conv_into(x: Tensor, packed: Tensor, C_out: int, stride: int, partials: Tensor) -> int:
+    """3x3, padding 1 convolution of ``x`` [B,C_in,H,W] with ``bottleneck_conv_pack``-ed weights as K-split partial sums into
+    ``partials`` (at least splits * B * C_out * H_out * W_out floats, laid out [split][B][C_out][H_out*W_out]).  Returns the number of
+    splits; the consumer adds them in ascending order (``partial_sums_bias_act_into`` / ``lstm_gates_partials_into``)."""
+    _dev_f32("bottleneck_conv_into", x, packed, partials)
+    B, C_in, H, W = x.shape
+    splits = bottleneck_conv_splits(B, C_out, C_in, H, W, stride)
+    if splits == 0:
+        raise ValueError(f"dvmvs::bottleneck_conv_into: problem {tuple(x.shape)} -> {C_out} (stride {stride}) is not one of the bottleneck shapes")
+    if not x.is_contiguous() or partials.numel() < splits * B * C_out * (H // stride) * (W // stride) or not partials.is_contiguous():
+        raise ValueError("dvmvs::bottleneck_conv_into: expected a contiguous input and a partial-sum buffer of splits * B * C_out * H_out * W_out floats")
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().dvmvs_bottleneck_conv_fwd(_ptr(x), _ptr(packed), _ptr(partials), B, C_in, H, W, int(C_out), int(stride), _stream(x))
+    _capi.check(rc, "dvmvs_bottleneck_conv_fwd")
+    return splits
+
+
+def partial_sums_bias_act_into(partials: Tensor, n_partials: int, dst: Tensor, bias, activation: int, shape) -> Tensor:
+    """dst = act(sum of the partial sums + bias[c]); ``dst`` a dense [B,C,H,W] tensor or a channel slice of a concatenation buffer."""
+    _dev_f32("partial_sums_bias_act_into", partials, dst)
+    B, C, H, W = shape
+    stride = _slice_batch_stride("partial_sums_bias_act_into", dst, B, C, H, W)
+    with torch.cuda.device(dst.device):
+        rc = _capi.lib().dvmvs_partial_sums_bias_act_fwd(_ptr(partials), int(n_partials), _ptr(dst), stride,
+                                                         _ptr(bias) if bias is not None and bias.numel() else None, B, C, H * W, int(activation),
+                                                         _stream(dst))
+    _capi.check(rc, "dvmvs_partial_sums_bias_act_fwd")
+    return dst
+
+
+def lstm_gates_partials_into(conv_partials: Tensor, n_partials: int, c_state: Tensor, h_state: Tensor) -> None:
+    """``lstm_gates_into`` on a convolution output that arrives as ``n_partials`` partial sums ([split][B][4*hidden][H*W])."""
+    _dev_f32("lstm_gates_partials_into", conv_partials, c_state, h_state)
+    B, hidden, H, W = c_state.shape
+    if conv_partials.numel() < n_partials * B * 4 * hidden * H * W or tuple(h_state.shape) != tuple(c_state.shape):
+        raise ValueError("dvmvs::lstm_gates_partials_into: shapes do not match")
+    if not (conv_partials.is_contiguous() and c_state.is_contiguous() and h_state.is_contiguous()):
+        raise ValueError("dvmvs::lstm_gates_partials_into: expected contiguous tensors")
+    with torch.cuda.device(c_state.device):
+        rc = _capi.lib().dvmvs_lstm_gates_partials_fwd(_ptr(conv_partials), int(n_partials), _ptr(c_state), _ptr(h_state), _ptr(c_state), B, hidden, H, W,
+                                                       _stream(c_state))
+    _capi.check(rc, "dvmvs_lstm_gates_partials_fwd")
+
+
 def hidden_warp_into(image_src: Tensor, depth_dst: Tensor, src_trans_dst: Tensor, camera_matrix: Tensor, zero_invalid: bool, dst: Tensor) -> Tensor:
     _dev_f32("hidden_warp_into", image_src, depth_dst, src_trans_dst, camera_matrix, dst)
     B, C, H, W = image_src.shape
@@ -601,7 +703,8 @@ def depth_reproject_lowres_into(transformation: Tensor, previous_depth: Tensor, 
     return out_lowres
 
 
-def cost_volume_into(image1: Tensor, image2s, Hm: Tensor, kt: Tensor, min_depth: float, max_depth: float, dst: Tensor, variant: int = 0) -> Tensor:
+def cost_volume_into(image1: Tensor, image2s, Hm: Tensor, kt: Tensor, min_depth: float, max_depth: float, dst: Tensor, variant: int = 0,
+                     work_list: Optional[Tensor] = None) -> Tensor:
     """Dot-product cost volume written into ``dst`` [B,D,H,W] (contiguous: for B == 1 a channel slice of a larger buffer is)."""
     _dev_f32("cost_volume_into", image1, Hm, kt, dst, *image2s)
     B, C, H, W = image1.shape
@@ -610,11 +713,12 @@ def cost_volume_into(image1: Tensor, image2s, Hm: Tensor, kt: Tensor, min_depth:
     if not (image1.is_contiguous() and dst.is_contiguous() and tuple(dst.shape) == (B, D, H, W) and all(t.is_contiguous() for t in image2s)):
         raise ValueError("dvmvs::cost_volume_into: expected contiguous NCHW tensors")
     workspace, ws_bytes = sweep_workspace(image1.device, B, M, H, W, D) if COST_VOLUME_TWO_PASS else (None, 0)
+    items = _work_list_ptr(work_list, image1, B, H, W, D)
     with torch.cuda.device(image1.device):
-        rc = _capi.lib().dvmvs_cost_volume_fwd(_ptr(image1), _capi.pointer_array([_ptr(t) for t in image2s]), _ptr(Hm.contiguous()), _ptr(kt.contiguous()),
-                                               _ptr(dst), B, M, C, H, W, D, float(min_depth), float(max_depth), 1, int(variant), _capi.LAYOUT_NCHW,
-                                               _ptr(workspace) if workspace is not None else None, ws_bytes, _stream(image1))
+        rc = _capi.lib().dvmvs_cost_volume_planned_fwd(_ptr(image1), _capi.pointer_array([_ptr(t) for t in image2s]), _ptr(Hm.contiguous()),
+                                                       _ptr(kt.contiguous()), _ptr(dst), B, M, C, H, W, D, float(min_depth), float(max_depth), 1, int(variant),
+                                                       _capi.LAYOUT_NCHW, _ptr(workspace) if workspace is not None else None, ws_bytes, items, _stream(image1))
     if rc != 0 and workspace is not None:
         drop_sweep_workspace(image1.device, B, M, H, W, D)
-    _capi.check(rc, "dvmvs_cost_volume_fwd")
+    _capi.check(rc, "dvmvs_cost_volume_planned_fwd")
     return dst

@@ -35,6 +35,8 @@ from dvmvs import pose_algebra as _pose_algebra
 # LDS-tiled sweep in the configuration the host-side plan model picks for the keyframe geometry), 1 = generic reference-order
 # kernel, 2 = LDS-tiled sweep, default configuration, 3 = LDS-tiled sweep, wide-baseline configuration
 COST_VOLUME_VARIANT = int(os.environ.get("DVMVS_COST_VOLUME_VARIANT", "0"))
+# host-planned work list for the tiled sweep (dvmvs_sweep_work_list); DVMVS_SWEEP_WORK_LIST=0: the static (tile, chunk) numbering
+SWEEP_WORK_LIST = os.environ.get("DVMVS_SWEEP_WORK_LIST", "1") != "0"
 
 
 def sweep_variant(host_matrices, height, width, n_depth_levels, min_depth, max_depth, dot_product=True):
@@ -94,8 +96,13 @@ def cost_volume_fusion(image1, image2s, pose1, pose2s, K, warp_grid, min_depth, 
     if len(image2s) == 0 or len(image2s) != len(pose2s):
         raise ValueError("cost_volume_fusion: need as many measurement poses as measurement feature maps (>= 1)")
     Hm, kt, host = _pose_algebra.sweep_matrices(pose1, pose2s, K, image1.device, with_host=True)
-    variant = sweep_variant(host, image1.shape[2], image1.shape[3], n_depth_levels, min_depth, max_depth, dot_product)
-    return _ops.cost_volume(image1, image2s, Hm, kt, float(min_depth), float(max_depth), int(n_depth_levels), bool(dot_product), variant)
+    H, W = image1.shape[2], image1.shape[3]
+    variant = sweep_variant(host, H, W, n_depth_levels, min_depth, max_depth, dot_product)
+    work_list = None
+    if host is not None and dot_product and variant in (0, 2, 3) and H * W >= 64 * 64 and SWEEP_WORK_LIST:
+        # the tiled sweep's work list, planned on the host copies of the matrices (long workgroups cut into parallel pieces)
+        work_list = _ops.sweep_work_list_host(host[0], host[1], H, W, n_depth_levels, min_depth, max_depth, variant).to(image1.device)
+    return _ops.cost_volume(image1, image2s, Hm, kt, float(min_depth), float(max_depth), int(n_depth_levels), bool(dot_product), variant, work_list)
 
 
 def calculate_cost_volume_by_warping(image1, image2, pose1, pose2, K, warp_grid, min_depth, max_depth, n_depth_levels,

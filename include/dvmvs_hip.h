@@ -108,8 +108,10 @@ int dvmvs_cost_volume_fwd(const float* image1, const float* const* image2s, cons
  * HOST-side model of the LDS-tiled sweep's run plan (no HIP call, no device memory): Hm_host / kt_host are HOST copies of the
  * matrices the launch will get -- they are on the host before the launch anyway (see "small matrices" above).
  *   configuration 0 = default (variant 2), 1 = wide-baseline (variant 3)
- *   stats[6] out: staged runs, LDS records of all staged runs, runs entirely outside the image, runs queued for the second
- *                 pass, planes of those runs, workgroups with at least one queued run
+ *   stats[8] out: staged runs, LDS records of all staged runs, runs entirely outside the image, runs queued for the second
+ *                 pass, planes of those runs, workgroups with at least one queued run, the largest number of staged runs of
+ *                 one workgroup (all workgroups are resident at once: the longest chain is the launch's span), the largest
+ *                 number of queued planes of one workgroup
  * dvmvs_sweep_select_variant returns the variant (2 or 3) the cost model built on those numbers expects to be faster for this
  * keyframe pair (negative DVMVS_E* on bad arguments); a captured frame graph per variant is replayed accordingly.
  */
@@ -117,6 +119,25 @@ int dvmvs_sweep_plan_stats(const float* Hm_host, const float* kt_host, int B, in
                            double min_depth, double max_depth, int configuration, long long* stats);
 int dvmvs_sweep_select_variant(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
                                double min_depth, double max_depth);
+
+/*
+ * Work list of the LDS-tiled sweep, built on the HOST from the host copies of the matrices (no HIP call).  All workgroups of a sweep
+ * launch are resident at once, so the launch lasts as long as its slowest workgroup; on wide-baseline / forward-motion pairs a few
+ * (tile, 8-plane chunk) pairs need 5-8 staged runs instead of 2.  The list cuts those into plane sub-ranges of at most 3 staged runs
+ * that separate workgroups process in parallel.  Upload it (dvmvs_sweep_work_list_bytes(B, H, W, D) bytes; the returned value is the
+ * number of 32-bit words actually used, negative on error) and pass the DEVICE copy to dvmvs_cost_volume_planned_fwd, which is
+ * dvmvs_cost_volume_fwd with that one extra argument (NULL = static numbering; used only together with a workspace).  `configuration`
+ * as for dvmvs_sweep_plan_stats; it must match the variant of the launch (2 -> 0, 3 -> 1; 0 picks the default configuration).
+ * Results do not depend on the list beyond fp32 summation order (a cut can turn a queued run into staged ones); with a given list the
+ * volume is bit-reproducible.
+ */
+size_t dvmvs_sweep_work_list_bytes(int B, int H, int W, int D);
+int dvmvs_sweep_work_list(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
+                          double min_depth, double max_depth, int configuration, unsigned int* work_list_host, size_t work_list_bytes);
+int dvmvs_cost_volume_planned_fwd(const float* image1, const float* const* image2s, const float* Hm, const float* kt,
+                                  float* cost_volume, int B, int M, int C, int H, int W, int D,
+                                  double min_depth, double max_depth, int dot_product, int variant, int image2_layout,
+                                  float* workspace, size_t workspace_bytes, const unsigned int* work_list, dvmvs_stream_t stream);
 
 /*
  * Gradient of the fused cost volume (dot_product mode) w.r.t. both feature maps; poses/K carry no gradient
@@ -177,6 +198,30 @@ int dvmvs_lstm_gates_fwd(const float* combined_conv, const float* c_cur, float* 
 int dvmvs_lstm_gates_bwd(const float* grad_h, const float* grad_c, const float* combined_conv,
                          const float* c_cur, float* grad_cc, float* grad_c_cur,
                          int B, int hidden, int H, int W, dvmvs_stream_t stream);
+
+/*
+ * 3x3, padding-1 convolutions on the bottleneck maps of a 320x256 frame (8x10, and 16x20 with stride 1 or 2) as a weight-streaming
+ * fp32 MFMA GEMM with a DETERMINISTIC split-K (csrc/bottleneck_conv.hip).  Replaces, for those shapes only, the nn.Conv2d of the
+ * ConvLSTM cell (/root/reference/dvmvs/convlstm.py:43-44: 1024 -> 2048 channels) and the 256 / 512-channel layers around it
+ * (fusionnet/model.py:167-305), which MIOpen solves with split-K kernels that accumulate with float atomics (results vary from
+ * run to run).  Inference only (no gradient); every other convolution stays on MIOpen.
+ *   dvmvs_bottleneck_conv_pack    weight [C_out,C_in,3,3] -> packed (dvmvs_bottleneck_conv_packed_bytes; C_in % 16 == 0), once
+ *   dvmvs_bottleneck_conv_splits  number S of partial sums for a problem, DVMVS_EUNSUPPORTED for shapes the kernel does not take
+ *   dvmvs_bottleneck_conv_fwd     x [B,C_in,H_in,W_in] -> partials [S][B][C_out][H_out*W_out]: partial s holds the contribution of
+ *                                 input channels [s*C_in/S, (s+1)*C_in/S); their sum in ascending s is the convolution
+ *   dvmvs_partial_sums_bias_act_fwd  dst[b,c,:] = act(sum_s partials[s,b,c,:] + bias[c]); activation 0 none / 1 ReLU; dst batch
+ *                                 item b starts at dst + b*dst_batch_stride (a channel slice of a concatenation buffer)
+ *   dvmvs_lstm_gates_partials_fwd dvmvs_lstm_gates_fwd on a convolution output that arrives as n_partials partial sums
+ */
+size_t dvmvs_bottleneck_conv_packed_bytes(int C_out, int C_in);
+int dvmvs_bottleneck_conv_pack(const float* weight, float* packed, int C_out, int C_in, dvmvs_stream_t stream);
+int dvmvs_bottleneck_conv_splits(int B, int C_out, int C_in, int H_in, int W_in, int stride);
+int dvmvs_bottleneck_conv_fwd(const float* x, const float* packed, float* partials, int B, int C_in, int H_in, int W_in, int C_out,
+                              int stride, dvmvs_stream_t stream);
+int dvmvs_partial_sums_bias_act_fwd(const float* partials, int n_partials, float* dst, long long dst_batch_stride, const float* bias,
+                                    int B, int C, int HW, int activation, dvmvs_stream_t stream);
+int dvmvs_lstm_gates_partials_fwd(const float* conv_partials, int n_partials, const float* c_cur, float* h_next, float* c_next,
+                                  int B, int hidden, int H, int W, dvmvs_stream_t stream);
 
 /*
  * Forward splat (z-buffer, farthest wins) of the previous full-resolution depth into the current view at half

@@ -75,9 +75,10 @@ def test_argument_validation_without_gpu(library):
 
 def test_workspace_sizes(library):
     lib = library.lib()
-    # spill workspace of the two-pass sweep: 4 header words + per workgroup one id and one slot of (1 + 8 M) words, sized for the
-    # finest tiling that may use it (32x4-pixel tiles x 8-plane chunks)
-    groups = (160 // 32) * (128 // 4) * 8
+    # spill workspace of the two-pass sweep: 4 header words + per possible work item one id and one slot of (1 + 8 M) words; a launch
+    # has at most twice as many work items as (32x8-pixel tile, 8-plane chunk) pairs (dvmvs_sweep_work_list cuts long ones)
+    groups = 2 * (160 // 32) * (128 // 8) * 8
+    assert lib.dvmvs_sweep_work_list_bytes(1, 128, 160, 64) == 4 * (2 + 2 * groups)
     assert lib.dvmvs_cost_volume_workspace_bytes(1, 2, 128, 160, 64) == 4 * (4 + groups + groups * (1 + 2 * 8))
     assert lib.dvmvs_cost_volume_workspace_bytes(0, 2, 128, 160, 64) == 0
     assert lib.dvmvs_cost_volume_workspace_bytes(2, 3, 33, 47, 10) > 0

@@ -18,7 +18,7 @@ f32 = np.float32
 
 
 def lib_stats(Hm, kt, configuration, shape=(H, W, D)):
-    out = (ctypes.c_longlong * 6)()
+    out = (ctypes.c_longlong * 8)()
     rc = _capi.lib().dvmvs_sweep_plan_stats(Hm.contiguous().data_ptr(), kt.contiguous().data_ptr(), Hm.shape[0], Hm.shape[1], shape[0], shape[1],
                                             shape[2], 0.25, 20.0, configuration, out)
     assert rc == 0
@@ -42,7 +42,7 @@ def pitch_residue(ax, ay):
 def python_plan_stats(Hm, kt, cap, tw=32, th=8, dp=8, minseg=2):
     """The kernel's plan rule, one (tile, chunk, frame) at a time, in numpy float32 scalars."""
     M = Hm.shape[0]
-    stats = [0] * 6
+    stats = [0] * 8
     inv_base, inv_step = 1.0 / 20.0, (1.0 / 0.25 - 1.0 / 20.0) / (D - 1)
     wn, hn, Wm1, Hm1 = f32(W) * f32(0.5), f32(H) * f32(0.5), f32(W - 1), f32(H - 1)
 
@@ -62,6 +62,7 @@ def python_plan_stats(Hm, kt, cap, tw=32, th=8, dp=8, minseg=2):
                     y0, y1 = ty * th, min(ty * th + th - 1, H - 1)
                     edge = f32(max(1, x1 - x0))
                     spills = False
+                    group_runs = group_queued = 0
                     for m in range(M):
                         h = Hm[m]
                         rays = []
@@ -98,15 +99,19 @@ def python_plan_stats(Hm, kt, cap, tw=32, th=8, dp=8, minseg=2):
                             if state == 1:
                                 stats[0] += 1
                                 stats[1] += records
+                                group_runs += 1
                             elif state == 2:
                                 stats[2] += 1
                             else:
                                 stats[3] += 1
                                 stats[4] += length
+                                group_queued += length
                                 spills = True
                             lo += length
                             hint = max(length, minseg)
                     stats[5] += spills
+                    stats[6] = max(stats[6], group_runs)        # the longest chain of staged runs of one workgroup ...
+                    stats[7] = max(stats[7], group_queued)      # ... and the most planes one workgroup queues for the second pass
     return stats
 
 
@@ -141,10 +146,57 @@ def test_selection_properties_on_the_whole_keyframe_index():
 
 def test_plan_model_rejects_bad_arguments():
     Hm, kt = matrices(0)
-    out = (ctypes.c_longlong * 6)()
+    out = (ctypes.c_longlong * 8)()
     lib = _capi.lib()
     assert lib.dvmvs_sweep_plan_stats(None, kt.data_ptr(), 1, 2, H, W, D, 0.25, 20.0, 0, out) == -1
     assert lib.dvmvs_sweep_plan_stats(Hm.data_ptr(), kt.data_ptr(), 1, 2, H, W, D, 0.25, 20.0, 2, out) == -1
     assert lib.dvmvs_sweep_plan_stats(Hm.data_ptr(), kt.data_ptr(), 1, 9, H, W, D, 0.25, 20.0, 0, out) == -2
     with pytest.raises(ValueError):
         pose_algebra.sweep_variant_host(Hm.double(), kt.double(), H, W, D, 0.25, 20.0)
+
+
+def work_list(Hm, kt, variant, shape=(H, W, D)):
+    from dvmvs.hip import ops
+    words = ops.sweep_work_list_host(Hm, kt, shape[0], shape[1], shape[2], 0.25, 20.0, variant).numpy().astype(np.int64) & 0xffffffff
+    n = int(words[0])
+    return n, words[2:2 + 2 * n].reshape(n, 2)
+
+
+@pytest.mark.parametrize("line", [0, 74, 170, 202, 242])
+def test_work_list_covers_every_plane_of_every_tile_exactly_once(line):
+    """dvmvs_sweep_work_list: the items partition (tile, plane); a (tile, chunk) with a long chain of staged runs is cut, an easy
+    geometry is not; the static positions keep their (tile, chunk); at most twice the static count; deterministic."""
+    Hm, kt = matrices(line)
+    for variant, cap in ((2, 1024), (3, 1536)):
+        n, items = work_list(Hm, kt, variant)
+        cover = np.zeros((80, D), dtype=np.int64)
+        for w0, w1 in items:
+            assert (w0 >> 16) == 0
+            cover[w0 & 0xffff, (w1 & 0xffff):(w1 & 0xffff) + (w1 >> 16)] += 1
+        assert (cover == 1).all(), (line, variant)
+        assert 640 <= n <= 1280
+        sizes = items[:, 1] >> 16
+        assert set(np.unique(sizes)) <= {2, 4, 8}
+        stats = lib_stats(Hm, kt, 0 if variant == 2 else 1)
+        if stats[6] <= 3:
+            assert n == 640 and (sizes == 8).all()                  # nothing to cut
+        else:
+            assert n > 640 and (sizes < 8).any()
+        assert (sizes[:640] > 0).all()
+        n2, items2 = work_list(Hm, kt, variant)
+        assert n2 == n and np.array_equal(items, items2)
+    # the first 640 positions are the static numbering's (tile, chunk) pairs: every pair once
+    pairs = {(int(w0 & 0xffff), int(w1 & 0xffff) // 8) for w0, w1 in items[:640]}
+    assert len(pairs) == 640
+
+
+def test_work_list_rejects_bad_arguments():
+    from dvmvs.hip import ops
+    Hm, kt = matrices(0)
+    with pytest.raises(ValueError):
+        ops.sweep_work_list_host(Hm.double(), kt.double(), H, W, D, 0.25, 20.0, 2)
+    with pytest.raises(ValueError):
+        ops.sweep_work_list_host(Hm, kt, H, W, D, 0.25, 20.0, 2, out=torch.empty(16, dtype=torch.int32))
+    lib = _capi.lib()
+    assert lib.dvmvs_sweep_work_list(Hm.data_ptr(), kt.data_ptr(), 1, 2, H, W, D, 0.25, 20.0, 0, None, 0) == -1
+    assert lib.dvmvs_sweep_work_list_bytes(0, H, W, D) == 0

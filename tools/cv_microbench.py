@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--lib", default="product", choices=["product", "tuning", "trace"])
     ap.add_argument("--small-workspace", action="store_true", help="no spill workspace (single-pass sweep, inline gather)")
+    ap.add_argument("--work-list", action="store_true", help="launch with the host-planned work list (dvmvs_sweep_work_list) of each geometry")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -79,14 +80,21 @@ def main():
             ids, pose_src = lines[li], allp
         pose1 = pose_src[ids[0]:ids[0] + 1].repeat(B, 1, 1)
         pose2s = [pose_src[i:i + 1].repeat(B, 1, 1) for i in (ids[1:] * M)[:M]]
-        Hm, kt = pose_algebra.sweep_matrices(pose1, pose2s, K, dev, "reference")
+        Hm, kt, host = pose_algebra.sweep_matrices(pose1, pose2s, K, dev, "reference", with_host=True)
+        lists = {}
+        if args.work_list:
+            from dvmvs.hip import ops as _ops
+            for v in variants:
+                if v in (0, 2, 3):
+                    lists[v] = _ops.sweep_work_list_host(host[0], host[1], H, W, D, 0.25, 20.0, v).to(dev)
 
         def launch(variant, dst, layout):
             meas = feats_cl if layout == "nhwc" else feats[1:]
             img_ptrs = _capi.pointer_array([t.data_ptr() for t in meas])
-            rc = lib.dvmvs_cost_volume_fwd(feats[0].data_ptr(), img_ptrs, Hm.data_ptr(), kt.data_ptr(), dst.data_ptr(),
-                                           B, M, C, H, W, D, 0.25, 20.0, 1, variant, 1 if layout == "nhwc" else 0,
-                                           ws.data_ptr() if ws_bytes else None, ws_bytes, torch.cuda.current_stream().cuda_stream)
+            rc = lib.dvmvs_cost_volume_planned_fwd(feats[0].data_ptr(), img_ptrs, Hm.data_ptr(), kt.data_ptr(), dst.data_ptr(),
+                                                   B, M, C, H, W, D, 0.25, 20.0, 1, variant, 1 if layout == "nhwc" else 0,
+                                                   ws.data_ptr() if ws_bytes else None, ws_bytes,
+                                                   lists[variant].data_ptr() if variant in lists else None, torch.cuda.current_stream().cuda_stream)
             if rc != 0:
                 raise RuntimeError(f"variant {variant}: code {rc}: {lib.dvmvs_error_string(rc).decode()}")
 

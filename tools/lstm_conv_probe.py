@@ -35,6 +35,34 @@ def main():
         xc, wc = x.contiguous(memory_format=torch.channels_last), w.contiguous(memory_format=torch.channels_last)
         report(f"MIOpen conv NHWC (benchmark={bench})", lambda: F.conv2d(xc, wc, padding=1), lambda: F.conv2d(xc, wc, padding=1).contiguous())
 
+    # the product path: csrc/bottleneck_conv.hip (weight-streaming fp32 MFMA, deterministic split-K), LSTM layer and the other layers
+    from dvmvs.hip import ops as _ops
+    for (ci, co, h, wd, st) in ((1024, 2048, 8, 10, 1), (512, 512, 8, 10, 1), (256, 512, 16, 20, 2), (512, 256, 16, 20, 1), (256, 256, 16, 20, 1)):
+        xx = torch.randn(1, ci, h, wd, generator=g).to(dev)
+        ww = (torch.randn(co, ci, 3, 3, generator=g) / 96).to(dev)
+        packed = _ops.bottleneck_conv_pack(ww)
+        S = _ops.bottleneck_conv_splits(1, co, ci, h, wd, st)
+        parts = torch.empty(S * co * (h // st) * (wd // st), device=dev)
+        dst = torch.empty(1, co, h // st, wd // st, device=dev)
+        bias = torch.zeros(co, device=dev)
+        exact = F.conv2d(xx.double(), ww.double(), padding=1, stride=st).float()
+        _ops.bottleneck_conv_into(xx, packed, co, st, parts)
+        _ops.partial_sums_bias_act_into(parts, S, dst, bias, 0, tuple(dst.shape))
+        err = float((dst - exact).abs().max())
+        t_conv = _graph_microseconds(lambda: _ops.bottleneck_conv_into(xx, packed, co, st, parts), reps=10, rounds=5)
+        t_both = _graph_microseconds(lambda: (_ops.bottleneck_conv_into(xx, packed, co, st, parts),
+                                              _ops.partial_sums_bias_act_into(parts, S, dst, bias, 1, tuple(dst.shape))), reps=10, rounds=5)
+        t_mi = _graph_microseconds(lambda: F.conv2d(xx, ww, padding=1, stride=st), reps=10, rounds=5)
+        flop = 2.0 * co * ci * 9 * (h // st) * (wd // st)
+        print(f"bottleneck kernel {ci:4d}->{co:4d} {h}x{wd} s{st}: {S:2d} splits  conv {t_conv:7.2f} us ({flop / t_conv / 1e6:6.1f} TFLOP/s, weights "
+              f"{co * ci * 36 / t_conv / 1e3:6.0f} GB/s)  + epilogue {t_both:7.2f} us   MIOpen conv alone {t_mi:7.2f} us   max|err vs fp64| {err:.2e}", flush=True)
+    cc_parts = torch.randn(16 * 2048 * 80, device=dev)
+    c_state, h_state = torch.randn(1, 512, 8, 10, device=dev), torch.zeros(1, 512, 8, 10, device=dev)
+    print(f"lstm gates on 16 partial sums: {_graph_microseconds(lambda: _ops.lstm_gates_partials_into(cc_parts, 16, c_state, h_state), reps=10, rounds=5):.2f} us; "
+          f"on one: {_graph_microseconds(lambda: _ops.lstm_gates_into(cc_parts[:2048 * 80].view(1, 2048, 8, 10), c_state, h_state), reps=10, rounds=5):.2f} us", flush=True)
+    if "--kernel-only" in sys.argv:
+        return
+
     col = F.unfold(x, 3, padding=1)[0].contiguous()            # [9216, 80], row = c * 9 + tap
     w2 = w.view(2048, 9216)
     report("unfold (im2col through ATen)", lambda: F.unfold(x, 3, padding=1), lambda: w2 @ F.unfold(x, 3, padding=1)[0])

@@ -28,7 +28,7 @@ H, W, D = 128, 160, 64
 
 
 def plan_stats(Hm, kt, configuration):
-    out = (ctypes.c_longlong * 6)()
+    out = (ctypes.c_longlong * 8)()
     Hm, kt = Hm.contiguous().float(), kt.contiguous().float()
     B, M = Hm.shape[0], Hm.shape[1]
     rc = _capi.lib().dvmvs_sweep_plan_stats(Hm.data_ptr(), kt.data_ptr(), B, M, H, W, D, 0.25, 20.0, configuration, out)
