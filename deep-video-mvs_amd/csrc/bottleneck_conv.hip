@@ -47,7 +47,8 @@ __host__ __device__ inline int bottleneck_splits(int B, int C_out, int C_in, int
   return groups;
 }
 
-template <int H_IN, int W_IN, int STRIDE>
+// CH: groups of 16 input channels whose weights are requested together; the split's group count is a multiple of it
+template <int H_IN, int W_IN, int STRIDE, int CH>
 __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(BottleneckConvArgs a) {
   constexpr int PW = W_IN + 2, PLANE = (H_IN + 2) * PW;
   constexpr int W_OUT = W_IN / STRIDE, H_OUT = H_IN / STRIDE, P = H_OUT * W_OUT, PG = P / kBcPixels;
@@ -86,28 +87,31 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
   const int groups = a.cs / 16;
   const float4v DVMVS_GLOBAL* wp = reinterpret_cast<const float4v DVMVS_GLOBAL*>(as_global(a.packed)) +
                                    (static_cast<size_t>(n_tile) * (a.C_in / 16) + c0 / 16) * (9 * 64) + lane;
-  float4v cur[9], nxt[9];
+  // Weights of CH groups of 16 input channels (9 float4 each) are requested in one straight-line burst and consumed group by group,
+  // so the wave waits once per burst for the first nine loads only (the compiler counts the newer ones: s_waitcnt vmcnt(9 * (CH - 1)))
+  // while the rest arrive behind 180 MFMAs per group.  The ConvLSTM layer has CH = 4 = all of a wave's weights (36 KB) in flight at
+  // once.  (Round 4, first form: a double buffer filled across loop iterations -- the compiler waits for ALL outstanding loads at a
+  // loop head, 42.8 us for the ConvLSTM layer = 45 % of the MFMA rate.)
+  for (int g0 = 0; g0 < groups; g0 += CH) {
+    float4v w[CH][9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) cur[t] = wp[t * 64];
-  for (int g = 0; g < groups; ++g) {
-    if (g + 1 < groups) {   // the next 16 input channels' weights are in flight while these are multiplied
+    for (int c = 0; c < CH; ++c)
 #pragma unroll
-      for (int t = 0; t < 9; ++t) nxt[t] = wp[(g + 1) * (9 * 64) + t * 64];
-    }
-    const float* xc = xs + g * 16 * PLANE;
+      for (int t = 0; t < 9; ++t) w[c][t] = wp[(g0 + c) * (9 * 64) + t * 64];
+    __builtin_amdgcn_sched_barrier(0);   // the requests stay in front of the MFMAs (the scheduler otherwise sinks each next to its use)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int toff = (t / 3) * PW + (t % 3);
+    for (int c = 0; c < CH; ++c) {
+      const float* xc = xs + (g0 + c) * 16 * PLANE;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int t = 0; t < 9; ++t) {
+        const int toff = (t / 3) * PW + (t % 3);
 #pragma unroll
-        for (int pt = 0; pt < kBcPT; ++pt)
-          acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[t][j], xc[j * 4 * PLANE + pix[pt] + toff], acc[pt], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int pt = 0; pt < kBcPT; ++pt)
+            acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c][t][j], xc[j * 4 * PLANE + pix[pt] + toff], acc[pt], 0, 0, 0);
+        }
       }
-    }
-    if (g + 1 < groups) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) cur[t] = nxt[t];
     }
   }
 
@@ -143,8 +147,17 @@ __global__ __launch_bounds__(256) void partial_sums_bias_act_kernel(const float*
                                                                     long long dst_batch_stride, const float* __restrict__ bias, int B, int C, int HW) {
   const long long per_split = static_cast<long long>(B) * C * HW;
   for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < per_split; i += static_cast<long long>(gridDim.x) * 256) {
-    float v = partials[i];
-    for (int s = 1; s < n_partials; ++s) v += partials[s * per_split + i];
+    // eight splits' loads in flight at a time (a plain `v += partials[s]` loop waits for every load before it issues the next:
+    // 11 us for 32 splits of a 512 x 80 map); the additions keep the ascending order
+    float v = 0.0f;
+    for (int s0 = 0; s0 < n_partials; s0 += 8) {
+      float part[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) part[k] = s0 + k < n_partials ? partials[(s0 + k) * per_split + i] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (s0 + k < n_partials) v = (s0 + k == 0) ? part[k] : v + part[k];
+    }
     const int plane = static_cast<int>(i / HW), b = plane / C, c = plane - b * C;
     v += bias ? bias[c] : 0.0f;
     if (ACT == 1) v = fmaxf(v, 0.0f);
@@ -157,8 +170,11 @@ int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
   constexpr int P = (H_IN / STRIDE) * (W_IN / STRIDE), PLANE = (H_IN + 2) * (W_IN + 2);
   const size_t lds = sizeof(float) * static_cast<size_t>(a.cs) * PLANE;
   if (lds > 64 * 1024) return DVMVS_EUNSUPPORTED;
-  const dim3 grid((a.n_tiles + kBcWaves - 1) / kBcWaves, a.splits, a.B * (P / kBcPixels));
-  hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE>), grid, dim3(kBcWaves * 64), lds, stream, a);
+  const dim3 grid((a.n_tiles + kBcWaves - 1) / kBcWaves, a.splits, a.B * (P / kBcPixels)), block(kBcWaves * 64);
+  const int groups = a.cs / 16;
+  if (groups % 4 == 0) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 4>), grid, block, lds, stream, a);
+  else if (groups % 2 == 0) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 2>), grid, block, lds, stream, a);
+  else hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1>), grid, block, lds, stream, a);
   return launch_status();
 }
 

@@ -201,7 +201,7 @@ extern "C" int dvmvs_sweep_plan_stats(const float* Hm_host, const float* kt_host
                                       double min_depth, double max_depth, int configuration, long long* stats) {
   if (!Hm_host || !kt_host || !stats || B <= 0 || M <= 0 || H <= 0 || W <= 0 || D <= 0) return DVMVS_EINVAL;
   if (M > DVMVS_MAX_MEASUREMENTS || D > DVMVS_MAX_DEPTH_LEVELS) return DVMVS_EUNSUPPORTED;
-  if (!(min_depth > 0.0) || !(max_depth > 0.0) || (configuration != 0 && configuration != 1)) return DVMVS_EINVAL;
+  if (!(min_depth > 0.0) || !(max_depth > 0.0) || configuration < 0 || configuration > 3) return DVMVS_EINVAL;
   const double inv_base = 1.0 / max_depth, inv_step = D > 1 ? (1.0 / min_depth - 1.0 / max_depth) / (D - 1) : 0.0;
   dvmvs::sweep_plan_stats_host(configuration, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, stats);
   return 0;

@@ -1207,6 +1207,8 @@ int sweep_work_list_host(int configuration, const float* Hm, const float* kt, in
 void sweep_plan_stats_host(int configuration, const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,
                            long long* stats) {
   if (configuration == 1) host_plan_stats<SweepWide>(Hm, kt, B, M, H, W, D, inv_base, inv_step, stats);
+  else if (configuration == 2) host_plan_stats<SweepConfig<32, 8, 8, 8, 1024, 1>>(Hm, kt, B, M, H, W, D, inv_base, inv_step, stats);      // (exploration)
+  else if (configuration == 3) host_plan_stats<SweepConfig<32, 8, 8, 8, 1536, 1, 4, 2, 2, true, true, 2>>(Hm, kt, B, M, H, W, D, inv_base, inv_step, stats);
   else host_plan_stats<SweepDefault>(Hm, kt, B, M, H, W, D, inv_base, inv_step, stats);
 }
 

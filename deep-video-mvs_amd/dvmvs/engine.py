@@ -328,7 +328,7 @@ class DepthEngine:
             for sub in ([] if m is None else m.modules()):
                 if isinstance(sub, FusedConv2d):
                     sub.bottleneck = self.bottleneck_convs
-        self._lstm_packed, self._lstm_partials = None, None
+        self._lstm_packed, self._lstm_partials, self._lstm_combined = None, None, None
         if lstm_channels_last and self.lstm is not None and not channels_last:
             # the ConvLSTM convolution (1024 -> 2048 channels on an 8x10 map, 75 MB of weights) is weight-bandwidth bound;
             # MIOpen's NHWC kernel for it takes 56 us against 88 us for NCHW, which more than pays for the two small layout
@@ -591,13 +591,23 @@ class DepthEngine:
                 return False
             self._lstm_packed = _ops.bottleneck_conv_pack(conv.weight.detach())
             self._lstm_partials = torch.empty(splits * x.shape[0] * k[0] * x.shape[2] * x.shape[3], device=x.device, dtype=torch.float32)
+            self._lstm_combined = torch.empty(x.shape[0], k[0], x.shape[2], x.shape[3], device=x.device, dtype=torch.float32)
         return True
 
     def _frame_body_direct(self, n_meas, has_previous, sweep_variant=0):
+        self._reference_features_direct()
+        self._after_features_direct(n_meas, has_previous, sweep_variant)
+
+    def _reference_features_direct(self, image=None, enc_cat=None):
+        """MnasNet taps -> FPN of the reference image, each used output into the front of its encoder concatenation buffer."""
+        s, d = self._static, self._direct_buffers
+        enc_cat = d["enc_cat"] if enc_cat is None else enc_cat
+        self._fpn_direct(self.fe(s["image"] if image is None else image), [c[:, :32] for c in enc_cat])
+
+    def _after_features_direct(self, n_meas, has_previous, sweep_variant=0):
+        """Everything of a frame behind the feature extraction: sweep, encoder, re-projection, ConvLSTM, decoder."""
         s, d = self._static, self._direct_buffers
         enc_cat, dec_cat = d["enc_cat"], d["dec_cat"]
-        # features: MnasNet taps -> FPN, each used output into the front of its encoder concatenation buffer
-        self._fpn_direct(self.fe(s["image"]), [c[:, :32] for c in enc_cat])
         Hm, kt = self._sweep_views(n_meas)
         if self.pose_algebra == "exact":
             Hm, kt = _ops.sweep_matrices(s["pose"], s["meas_pose"][:n_meas], s["half_K"])
@@ -632,9 +642,12 @@ class DepthEngine:
                 d["lstm_cat"][:, 512:].copy_(s["h"])      # first frame of a sequence: the (zero) state as it is, no warp (convlstm.py:29)
             if self._lstm_bottleneck(d["lstm_cat"]):
                 # the 1024 -> 2048-channel convolution as K-split partial sums (75 MB of weights streamed once through the MFMA
-                # pipe), added up in a fixed order by the gates kernel itself
+                # pipe), added up in a fixed order by a chip-wide reduction (the gates kernel can add them itself --
+                # lstm_gates_partials_into -- but its 32 workgroups take 30 us over 16 splits; reduction + gates: 5.6 + 5.3 us)
                 splits = _ops.bottleneck_conv_into(d["lstm_cat"], self._lstm_packed, cell.conv.weight.shape[0], 1, self._lstm_partials)
-                _ops.lstm_gates_partials_into(self._lstm_partials, splits, s["c"], s["h"])
+                _ops.partial_sums_bias_act_into(self._lstm_partials, splits, self._lstm_combined, None, _ops.ACTIVATIONS["none"],
+                                                tuple(self._lstm_combined.shape))
+                _ops.lstm_gates_into(self._lstm_combined, s["c"], s["h"])
             else:
                 combined = cell.conv(d["lstm_cat"])
                 if not combined.is_contiguous():       # channels-last convolution (lstm_channels_last): back to the gates' NCHW rows
