@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-feature-cache", action="store_true", help="recompute measurement features every frame like the reference")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-lstm-channels-last", action="store_true")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="do not hand the engine the next keyframe's image (no feature look-ahead: every frame's features on the frame's own stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-reps", type=int, default=10)
@@ -578,8 +580,10 @@ def main():
     def run_frame(k):
         ids = [k - 1 - i for i in range(M)]
         meas_images = None if not args.no_feature_cache else [images[i % n_images] for i in ids]
+        lookahead = not args.no_lookahead and not args.no_feature_cache
         return engine.step(images[k % n_images], seq[k][0], meas_images, seq[k][1], full_K,
-                           frame_id=k if not args.no_feature_cache else None, measurement_ids=ids if not args.no_feature_cache else None)
+                           frame_id=k if not args.no_feature_cache else None, measurement_ids=ids if not args.no_feature_cache else None,
+                           next_reference_image=images[(k + 1) % n_images] if lookahead else None, next_frame_id=k + 1 if lookahead else None)
 
     with torch.no_grad():
         # buffer fill: the first M keyframes only contribute features (reference: keyframe-buffer response 0 / short lists)
@@ -651,6 +655,7 @@ def main():
                        "sequences_per_gpu": 1, "hip_graphs": not args.no_graphs, "bn_folded": not args.no_fold_bn,
                        "feature_cache": not args.no_feature_cache, "full_resolution_only": True,
                        "miopen_solver_search": bool(torch.backends.cudnn.benchmark),
+                       "feature_lookahead": 0 if (args.no_lookahead or args.no_feature_cache) else 1,
                        "conv_epilogues_inside_miopen": (lambda rep: f"{sum(1 for r in rep if r[2])} of {len(rep)} dense convolution problems "
                                                         "(bit-identical to convolution + epilogue AND faster at warm-up)")(engine.conv_plan_report()),
                        "weights": "seeded (tests/synthetic.py) + published FPN checkpoint",

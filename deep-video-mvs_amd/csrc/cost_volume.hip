@@ -6,15 +6,11 @@
 // Semantics: /root/reference/dvmvs/utils.py:45-107 (see oracle/dvmvs_oracle.py for the CPU restatement).
 #include "plane_sweep.h"
 
-// coefficients of dvmvs::sweep_model_us (us; per-workgroup statistics), fitted by tools/sweep_select_fit.py
-#define SWEEP_MODEL_BASE_DEFAULT 14.0
-#define SWEEP_MODEL_RUN_DEFAULT 2.2
-#define SWEEP_MODEL_RECORD_DEFAULT 0.004
-#define SWEEP_MODEL_SPILL_DEFAULT 60.0
-#define SWEEP_MODEL_BASE_WIDE 22.0
-#define SWEEP_MODEL_RUN_WIDE 2.2
-#define SWEEP_MODEL_RECORD_WIDE 0.004
-#define SWEEP_MODEL_SPILL_WIDE 60.0
+// coefficients of dvmvs::sweep_model_us (us), least squares over the 285 keyframe pairs of the sample scene, launches with the
+// host-planned work list (tools/sweep_select_fit.py on tools/cv_microbench.py --lines all --variants 2,3 --work-list;
+// profiles/r04_sweep_select_fit.md): rms residual 3.2 us (default) / 2.3 us (wide)
+#define SWEEP_MODEL_DEFAULT {22.7145, 1.1898, 20.3308, 0.7128, 0.01731, 2.163e-05}
+#define SWEEP_MODEL_WIDE {23.8151, 3.9715, 20.3800, 0.8606, 0.01036, 2.050e-05}
 
 namespace dvmvs {
 
@@ -118,17 +114,17 @@ void sweep_plan_stats_host(int configuration, const float* Hm, const float* kt, 
                            long long* stats);
 int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream);
 
-// predicted duration (us) of the sweep + second pass in one configuration from its plan statistics; coefficients: see
-// dvmvs_sweep_select_variant.  Work is counted per workgroup slot of the chip so that the model carries over to other shapes.
+// Predicted duration (us) of the sweep + second pass in one configuration from its plan statistics (dvmvs_sweep_plan_stats):
+// base + staged runs of the longest work item (the work list cuts chains to <= 3) + a fixed cost when the second pass is not empty
+// (its chain of dependent gathers: ~20 us however few units) + queued planes of the worst workgroup + all queued planes + all staged
+// records.  Fitted on the 128x160x64 shape; it only ranks the two configurations, so other shapes reuse it as it is.
 inline double sweep_model_us(int configuration, const long long* st, int B, int H, int W, int D) {
-  static const double kBase[2] = {SWEEP_MODEL_BASE_DEFAULT, SWEEP_MODEL_BASE_WIDE};
-  static const double kPerRun[2] = {SWEEP_MODEL_RUN_DEFAULT, SWEEP_MODEL_RUN_WIDE};
-  static const double kPerRecord[2] = {SWEEP_MODEL_RECORD_DEFAULT, SWEEP_MODEL_RECORD_WIDE};
-  static const double kPerSpilledPlane[2] = {SWEEP_MODEL_SPILL_DEFAULT, SWEEP_MODEL_SPILL_WIDE};
-  const double scale = 1.0 / 640.0;   // statistics per workgroup of the 128x160x64 shape the model was fitted on
+  static const double kCoef[2][6] = {SWEEP_MODEL_DEFAULT, SWEEP_MODEL_WIDE};
+  const double* c = kCoef[configuration];
   (void)B; (void)H; (void)W; (void)D;
-  return kBase[configuration] + scale * (kPerRun[configuration] * static_cast<double>(st[0]) + kPerRecord[configuration] * static_cast<double>(st[1]) +
-                                         kPerSpilledPlane[configuration] * static_cast<double>(st[4]));
+  const double longest = st[6] < 3 ? static_cast<double>(st[6]) : 3.0;
+  return c[0] + c[1] * longest + (st[4] > 0 ? c[2] : 0.0) + c[3] * static_cast<double>(st[7]) + c[4] * static_cast<double>(st[4]) +
+         c[5] * static_cast<double>(st[1]);
 }
 
 }  // namespace dvmvs
@@ -182,6 +178,7 @@ extern "C" int dvmvs_cost_volume_planned_fwd(const float* image1, const float* c
   if (variant >= 32) {
     // tuning configurations for tools/cv_microbench.py; not part of the stable interface
     if (!dot_product) return DVMVS_EUNSUPPORTED;
+    if (work_list != nullptr && a.spill != nullptr) a.items = work_list;
     return launch_sweep_tuning(variant - 32, a, s);
   }
   // the tiled sweep addresses the maps through 32-bit buffer offsets: one batch item of one map must stay below 2 GiB
@@ -201,7 +198,7 @@ extern "C" int dvmvs_sweep_plan_stats(const float* Hm_host, const float* kt_host
                                       double min_depth, double max_depth, int configuration, long long* stats) {
   if (!Hm_host || !kt_host || !stats || B <= 0 || M <= 0 || H <= 0 || W <= 0 || D <= 0) return DVMVS_EINVAL;
   if (M > DVMVS_MAX_MEASUREMENTS || D > DVMVS_MAX_DEPTH_LEVELS) return DVMVS_EUNSUPPORTED;
-  if (!(min_depth > 0.0) || !(max_depth > 0.0) || configuration < 0 || configuration > 3) return DVMVS_EINVAL;
+  if (!(min_depth > 0.0) || !(max_depth > 0.0) || (configuration != 0 && configuration != 1)) return DVMVS_EINVAL;
   const double inv_base = 1.0 / max_depth, inv_step = D > 1 ? (1.0 / min_depth - 1.0 / max_depth) / (D - 1) : 0.0;
   dvmvs::sweep_plan_stats_host(configuration, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, stats);
   return 0;

@@ -902,12 +902,16 @@ __global__ __launch_bounds__(Cfg::NPIX) void sweep_spill_kernel(CostVolumeArgs a
     }
     if (touched) *out = value;
   }
-  // leave the header as the next call expects it (nothing to do for an empty list): every workgroup has read word 0 by
-  // the time it takes a ticket, and the last one to finish clears both words
+  // Leave the header as the next call expects it (nothing to do for an empty list).  Only the workgroups that HAD a unit take a
+  // ticket, and the last of them clears both words: a workgroup without one (blockIdx >= units) has read word 0 before it got here
+  // and never reads it again, and one that starts so late that it already sees the cleared header finds units == 0 -- it would not
+  // have had a unit anyway.  (Round 3 let all 1024 workgroups of the grid take a ticket: 1024 atomics on one address, serialised in
+  // L2 -- the fixed ~20 us a non-empty second pass cost however few units it had, tools/sweep_select_fit.py.)
   __syncthreads();
-  if (tid == 0 && units != 0) {
+  if (tid == 0 && blockIdx.x < units) {
+    const unsigned int participants = units < gridDim.x ? units : gridDim.x;
     const unsigned int ticket = atomicAdd(a.spill + 1, 1u);
-    if (ticket == gridDim.x - 1) {
+    if (ticket == participants - 1) {
       spill[0] = 0u;
       spill[1] = 0u;
     }
@@ -1207,8 +1211,6 @@ int sweep_work_list_host(int configuration, const float* Hm, const float* kt, in
 void sweep_plan_stats_host(int configuration, const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,
                            long long* stats) {
   if (configuration == 1) host_plan_stats<SweepWide>(Hm, kt, B, M, H, W, D, inv_base, inv_step, stats);
-  else if (configuration == 2) host_plan_stats<SweepConfig<32, 8, 8, 8, 1024, 1>>(Hm, kt, B, M, H, W, D, inv_base, inv_step, stats);      // (exploration)
-  else if (configuration == 3) host_plan_stats<SweepConfig<32, 8, 8, 8, 1536, 1, 4, 2, 2, true, true, 2>>(Hm, kt, B, M, H, W, D, inv_base, inv_step, stats);
   else host_plan_stats<SweepDefault>(Hm, kt, B, M, H, W, D, inv_base, inv_step, stats);
 }
 

@@ -355,6 +355,8 @@ class DepthEngine:
         self._static = None
         self._direct_buffers = {}
         self._warm = set()
+        self._parity, self._prefetched = 0, None      # buffer set of the next frame; (frame_id, buffer set) whose reference features are ready
+        self._side_stream = torch.cuda.Stream(device=self.device)
         self.sweep_variant_counts = {}     # frames per sweep configuration (dvmvs_cost_volume_fwd's variant) since construction
         # host-planned work list for the sweep: only where the matrices exist on the host, and one plan per launch (one sequence)
         self.sweep_work_list = bool(_utils.SWEEP_WORK_LIST and self.pose_algebra == "reference" and _utils.COST_VOLUME_VARIANT in (0, 2, 3))
@@ -420,6 +422,7 @@ class DepthEngine:
         (the cache is keyed by the caller's frame ids, which restart with every sequence)."""
         self.reset()
         self.clear_feature_cache()
+        self._prefetched = None      # (frame ids restart with the sequence)
 
     # ---- pieces -----------------------------------------------------------------------------------------------------
     def _features(self, image):
@@ -469,6 +472,12 @@ class DepthEngine:
                                        z(1, 2 * hc + 1, H // 2, W // 2)],
                               full_in=z(1, hc + 1 + 3, H, W), lstm_cat=z(1, 32 * hc, H // 32, W // 32), zbuffer=z(1, H // 2, W // 2),
                               estimate=z(1, 1, H // 32, W // 32), depth_store=z(1, H, W))
+            if self.direct:
+                # feature look-ahead (step(next_reference_image=...)): the NEXT frame's image and FPN outputs need a home while this
+                # frame's encoder / decoder read their own -- a second set of the buffers the feature extraction writes and of the
+                # buffer that holds the image; frames alternate between the two sets
+                direct["sets"] = [dict(enc_cat=direct["enc_cat"], full_in=direct["full_in"]),
+                                  dict(enc_cat=[torch.zeros_like(c) for c in direct["enc_cat"]], full_in=torch.zeros_like(direct["full_in"]))]
             self._direct_buffers = direct
             image = direct["full_in"][:, 33:36] if self.direct else z(S, 3, H, W)      # the decoder's last concatenation ends with the image
             depth = direct["depth_store"] if self.direct else z(S, H, W)
@@ -594,24 +603,41 @@ class DepthEngine:
             self._lstm_combined = torch.empty(x.shape[0], k[0], x.shape[2], x.shape[3], device=x.device, dtype=torch.float32)
         return True
 
-    def _frame_body_direct(self, n_meas, has_previous, sweep_variant=0):
-        self._reference_features_direct()
-        self._after_features_direct(n_meas, has_previous, sweep_variant)
+    def _frame_body_direct(self, n_meas, has_previous, sweep_variant=0, parity=0, prefetched=False, prefetch=False):
+        """One frame on buffer set ``parity``.  ``prefetched``: its reference features are already there (the previous step computed
+        them); ``prefetch``: the NEXT frame's reference features (image in the other set) are computed as well -- when this frame's own
+        are prefetched, on a second stream, concurrently with this frame's sweep .. decoder: at batch 1 most kernels of a frame leave
+        most of the chip idle, and the next frame's feature extraction depends on nothing this frame computes (measured:
+        tools/frame_stage_probe.py, 1603 -> 1278 us per frame)."""
+        sets = self._direct_buffers["sets"]
+        if not prefetched:
+            self._reference_features_direct(sets[parity])
+        if prefetch and not prefetched:
+            # (both on one stream: the feature extractor's modules are not run concurrently with themselves)
+            self._reference_features_direct(sets[1 - parity])
+            prefetch = False
+        if prefetch:
+            main = torch.cuda.current_stream(self.device)
+            self._side_stream.wait_stream(main)
+            with torch.cuda.stream(self._side_stream):
+                self._reference_features_direct(sets[1 - parity])
+        self._after_features_direct(n_meas, has_previous, sweep_variant, sets[parity])
+        if prefetch:
+            main.wait_stream(self._side_stream)
 
-    def _reference_features_direct(self, image=None, enc_cat=None):
-        """MnasNet taps -> FPN of the reference image, each used output into the front of its encoder concatenation buffer."""
-        s, d = self._static, self._direct_buffers
-        enc_cat = d["enc_cat"] if enc_cat is None else enc_cat
-        self._fpn_direct(self.fe(s["image"] if image is None else image), [c[:, :32] for c in enc_cat])
+    def _reference_features_direct(self, buffers):
+        """MnasNet taps -> FPN of the reference image of a buffer set, each used output into the front of its encoder concatenation buffer."""
+        self._fpn_direct(self.fe(buffers["full_in"][:, 33:36]), [c[:, :32] for c in buffers["enc_cat"]])
 
-    def _after_features_direct(self, n_meas, has_previous, sweep_variant=0):
+    def _after_features_direct(self, n_meas, has_previous, sweep_variant=0, buffers=None):
         """Everything of a frame behind the feature extraction: sweep, encoder, re-projection, ConvLSTM, decoder."""
         s, d = self._static, self._direct_buffers
-        enc_cat, dec_cat = d["enc_cat"], d["dec_cat"]
+        buffers = d["sets"][0] if buffers is None else buffers
+        enc_cat, dec_cat = buffers["enc_cat"], d["dec_cat"]
         Hm, kt = self._sweep_views(n_meas)
         if self.pose_algebra == "exact":
             Hm, kt = _ops.sweep_matrices(s["pose"], s["meas_pose"][:n_meas], s["half_K"])
-        _ops.cost_volume_into(s["ref_half"], s["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, enc_cat[0][:, 32:], sweep_variant,
+        _ops.cost_volume_into(enc_cat[0][:, :32], s["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, enc_cat[0][:, 32:], sweep_variant,
                               self._sweep_items())
         # encoder: aggregator output = skip connection, written where the decoder will read it
         enc, dec = self.enc, self.dec
@@ -658,7 +684,7 @@ class DepthEngine:
         d2 = self._decoder_block_direct(dec.decoder_block2, d1, dec_cat[1], dec.depth_layer_one_sixteen, d1)
         d3 = self._decoder_block_direct(dec.decoder_block3, d2, dec_cat[2], dec.depth_layer_one_eight, d2)
         d4 = self._decoder_block_direct(dec.decoder_block4, d3, dec_cat[3], dec.depth_layer_quarter, d3)
-        full_in = d["full_in"]
+        full_in = buffers["full_in"]
         _ops.upsample2x_into(d4, full_in[:, :32])
         self._upsampled_depth_head(dec.depth_layer_half, d4, full_in[:, 32:33])
         refined = dec.refine[1][0](dec.refine[0][0](full_in))
@@ -666,10 +692,10 @@ class DepthEngine:
         dec.depth_layer_full[0](refined, out=s["prev_depth"], activation=_ops.ACTIVATION_SIGMOID_TO_DEPTH,
                                 p0=dec.inverse_depth_multiplier, p1=dec.inverse_depth_base)
 
-    def _frame_body(self, n_meas, has_previous, sweep_variant=0):
+    def _frame_body(self, n_meas, has_previous, sweep_variant=0, parity=0, prefetched=False, prefetch=False):
         """The per-frame computation on the static buffers (this is what gets captured into a hipGraph)."""
         if self.direct:
-            return self._frame_body_direct(n_meas, has_previous, sweep_variant)
+            return self._frame_body_direct(n_meas, has_previous, sweep_variant, parity, prefetched, prefetch)
         s = self._static
         feats = self._features(s["image"])
         ref_half = feats[0].contiguous()
@@ -701,13 +727,19 @@ class DepthEngine:
     # ---- public -----------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, reference_image, reference_pose, measurement_images, measurement_poses, full_K, frame_id=None,
-             measurement_ids=None):
+             measurement_ids=None, next_reference_image=None, next_frame_id=None):
         """One keyframe (of each of the S sequences).  Images [S,3,H,W] normalised, on the GPU; poses [S,4,4] cam-to-world and
         ``full_K`` [S,3,3] preferably as HOST tensors (that is where they come from, and where the frame's small matrices are
         evaluated; device tensors are copied back, which synchronises).  With S > 1 the sequences advance in lockstep:
         ``frame_id`` / ``measurement_ids`` name the step for all of them and a cached feature entry holds all S maps.
 
         ``measurement_images[i]`` may be ``None`` when ``measurement_ids[i]`` is in the feature cache.
+
+        Feature look-ahead (one sequence per engine): ``next_reference_image`` / ``next_frame_id`` = the reference image of the NEXT
+        call and its ``frame_id``, when the caller already has it (a pre-computed keyframe index, a camera that is a frame ahead).
+        Its MnasNet + FPN features are then computed during THIS call on a second stream, concurrently with this frame's sweep,
+        encoder, ConvLSTM and decoder, and the next call (same ``frame_id``) finds them ready.  Results are bit-identical to the
+        calls without look-ahead (same kernels, same inputs); a next call with another ``frame_id`` simply recomputes.
         Returns the full-resolution depth [S,H,W] (a static buffer that the next call overwrites: clone to keep).
         """
         n_meas = len(measurement_poses)
@@ -735,12 +767,26 @@ class DepthEngine:
             s["meas_feat"][i].copy_(half)
         for mid, half in fresh:
             self._remember(mid, half)
-        s["image"].copy_(reference_image)
+        # buffer set of this frame; feature look-ahead (one sequence, destination-passing body)
+        parity = self._parity if self.direct else 0
+        prefetched = bool(self.direct and frame_id is not None and self._prefetched == (frame_id, parity))
+        prefetch = bool(self.direct and next_reference_image is not None)
+        sets = self._direct_buffers.get("sets")
+        if self.direct:
+            if not prefetched:
+                sets[parity]["full_in"][:, 33:36].copy_(reference_image)
+            if prefetch:
+                if tuple(next_reference_image.shape) != tuple(reference_image.shape):
+                    raise ValueError("next_reference_image must have the reference image's shape")
+                sets[1 - parity]["full_in"][:, 33:36].copy_(next_reference_image)
+            s["image"], s["ref_half"] = sets[parity]["full_in"][:, 33:36], sets[parity]["enc_cat"][0][:, :32]
+        else:
+            s["image"].copy_(reference_image)
         committed_pose, sweep_variant = self._upload_frame_parameters(n_meas, reference_pose, measurement_poses, full_K)
 
         # S > 1: always the previous-state path (see the class docstring); S == 1: the reference's two frame kinds
         kind = (n_meas, (self.has_previous or self.sequences > 1) and self.is_fusionnet)
-        key = kind + (sweep_variant,)
+        key = kind + (sweep_variant, parity, prefetched, prefetch)
         self.sweep_variant_counts[sweep_variant] = self.sweep_variant_counts.get(sweep_variant, 0) + 1
         if not self.use_graphs:
             self._frame_body(*key)
@@ -751,16 +797,25 @@ class DepthEngine:
             self._warm.add(kind)
         else:
             if key not in self._graphs:
-                # one graph per sweep configuration, both captured the first time the kind is replayed (capture records launches, it
-                # executes nothing): a later frame whose geometry asks for the other configuration finds its graph ready
+                # Capture records launches, it executes nothing -- so everything this kind of frame may need later is captured now,
+                # while the caller is still warming up: both sweep configurations, both buffer sets and, with look-ahead, the
+                # steady-state pattern (own features prefetched, next frame's being prefetched).  A later frame whose geometry asks
+                # for the other configuration finds its graph ready instead of paying ~0.1 s of capture in the middle of a run.
                 variants = {sweep_variant} | ({2, 3} if sweep_variant in (2, 3) else set())
+                patterns = {(prefetched, prefetch)} | ({(True, True)} if prefetch else set())
                 for v in sorted(variants):
-                    if kind + (v,) not in self._graphs:
-                        self._graphs[kind + (v,)] = self._capture(kind + (v,))
+                    for par in ((0, 1) if self.direct else (0,)):
+                        for pattern in sorted(patterns):
+                            k = kind + (v, par) + pattern
+                            if k not in self._graphs:
+                                self._graphs[k] = self._capture(k)
             self._graphs[key].replay()
         self._prev_pose_host = committed_pose
         self._no_previous[:] = False
         self.has_previous = True
+        if self.direct:
+            self._prefetched = (next_frame_id, 1 - parity) if prefetch and next_frame_id is not None else None
+            self._parity = 1 - parity
         if self.cache_features and frame_id is not None:
             self._remember(frame_id, s["ref_half"].clone())
         return s["depth"]

@@ -48,10 +48,22 @@ def _preprocessor(scene, raw_image):
                            perform_crop=Config.test_perform_crop)
 
 
-def _run_frame(engine, scene, timer, device, reference_index, measurement_indices, evaluate, images=None):
+def _run_frame(engine, scene, timer, device, reference_index, measurement_indices, evaluate, images=None, next_reference_index=None,
+               prepared=None):
+    """``next_reference_index``: the reference frame of the NEXT call when it is known (offline runs): its image is pre-processed now and
+    handed to the engine as look-ahead (DepthEngine.step: its features are computed concurrently with this frame); ``prepared``
+    (a dict) carries the pre-processed device image to that next call."""
     raw = images[reference_index] if images is not None and reference_index in images else scene.image(reference_index)
     pre = _preprocessor(scene, raw)
-    ref_image = _to_device(pre.apply_rgb(raw, SCALE_RGB, MEAN_RGB, STD_RGB), device)
+    ref_image = prepared.pop(reference_index, None) if prepared is not None else None
+    if ref_image is None:
+        ref_image = _to_device(pre.apply_rgb(raw, SCALE_RGB, MEAN_RGB, STD_RGB), device)
+    next_image = None
+    if next_reference_index is not None and prepared is not None:
+        raw_next = images[next_reference_index] if images is not None and next_reference_index in images else scene.image(next_reference_index)
+        next_image = _to_device(_preprocessor(scene, raw_next).apply_rgb(raw_next, SCALE_RGB, MEAN_RGB, STD_RGB), device)
+        prepared.clear()
+        prepared[next_reference_index] = next_image
     ref_pose = torch.from_numpy(scene.poses[reference_index]).float().unsqueeze(0)   # poses / K stay on the host (engine.step)
     full_K = torch.from_numpy(pre.get_updated_intrinsics()).float().unsqueeze(0)
     meas_images, meas_poses = [], []
@@ -64,7 +76,8 @@ def _run_frame(engine, scene, timer, device, reference_index, measurement_indice
         meas_poses.append(torch.from_numpy(scene.poses[m]).float().unsqueeze(0))
     timer.record_start_time()
     depth = engine.step(ref_image, ref_pose, meas_images, meas_poses, full_K, frame_id=reference_index,
-                        measurement_ids=list(measurement_indices))
+                        measurement_ids=list(measurement_indices), next_reference_image=next_image,
+                        next_frame_id=next_reference_index if next_image is not None else None)
     timer.record_end_time_and_elapsed_time()
     prediction = depth.cpu().numpy().squeeze()
     reference_depth = pre.apply_depth(scene.depth(reference_index)) if evaluate and scene.depth_names else None
@@ -80,15 +93,19 @@ def predict_offline(engine: DepthEngine, scene_folder, keyframe_index_file, eval
     timer = InferenceTimer()
     predictions, reference_depths = [], []
     engine.new_sequence()
-    lines = [l.strip() for l in open(keyframe_index_file) if l.strip()]
-    for line in lines[:max_frames]:
+    lines = [l.strip() for l in open(keyframe_index_file) if l.strip()][:max_frames]
+    prepared = {}      # the next keyframe's pre-processed image (the index file says which frame that is: feature look-ahead)
+    for n, line in enumerate(lines):
         if frame_log is not None:
             frame_log.append(line)
         if line == "TRACKING LOST":
             engine.reset()
             continue
         indices = [position[name] for name in line.split(" ")]
-        prediction, reference_depth = _run_frame(engine, scene, timer, device, indices[0], indices[1:], evaluate)
+        upcoming = next((l for l in lines[n + 1:] if l != "TRACKING LOST"), None)
+        next_reference = position[upcoming.split(" ")[0]] if upcoming is not None else None
+        prediction, reference_depth = _run_frame(engine, scene, timer, device, indices[0], indices[1:], evaluate,
+                                                 next_reference_index=next_reference, prepared=prepared)
         predictions.append(prediction)
         reference_depths.append(reference_depth)
     return predictions, (reference_depths if evaluate and scene.depth_names else None), timer

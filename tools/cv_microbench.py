@@ -85,8 +85,8 @@ def main():
         if args.work_list:
             from dvmvs.hip import ops as _ops
             for v in variants:
-                if v in (0, 2, 3):
-                    lists[v] = _ops.sweep_work_list_host(host[0], host[1], H, W, D, 0.25, 20.0, v).to(dev)
+                if v in (0, 2, 3) or v >= 32:      # (tuning variants use the 32x8x8 tiling of the default configuration)
+                    lists[v] = _ops.sweep_work_list_host(host[0], host[1], H, W, D, 0.25, 20.0, v if v < 32 else 2).to(dev)
 
         def launch(variant, dst, layout):
             meas = feats_cl if layout == "nhwc" else feats[1:]

@@ -2,7 +2,7 @@
 
     python tools/sweep_select_fit.py --stats                      # plan statistics of both configurations on all keyframe pairs (CPU only)
     python tools/sweep_select_fit.py --timings gpurun_out/x.json   # + least-squares fit to per-pair timings of variants 2 and 3
-                                                                   #   (tools/cv_microbench.py --variants 2,3 --lines all --out x.json)
+                                                                   #   (tools/cv_microbench.py --variants 2,3 --lines all --work-list --out x.json)
 
 The statistics come from the library's HOST-side plan model (dvmvs_sweep_plan_stats: no GPU needed); the timings from an MI355X.
 """
@@ -44,30 +44,34 @@ def main():
     lines = syn.keyframe_index_lines(2)
     poses = torch.from_numpy(syn.sample_poses()).float()
     K = syn.scaled_K(syn.full_K(), 2.0)
-    rows = []
+    rows, sel = [], []
     for li, (r, ms) in enumerate(lines):
         Hm, kt = pose_algebra.sweep_matrices_host(poses[r:r + 1], [poses[m:m + 1] for m in ms], K)
         rows.append((plan_stats(Hm, kt, 0), plan_stats(Hm, kt, 1)))
-        sel = _capi.lib().dvmvs_sweep_select_variant(Hm.contiguous().data_ptr(), kt.contiguous().data_ptr(), 1, 2, H, W, D, 0.25, 20.0)
+        sel.append(_capi.lib().dvmvs_sweep_select_variant(Hm.contiguous().data_ptr(), kt.contiguous().data_ptr(), 1, 2, H, W, D, 0.25, 20.0))
         if args.stats:
-            print(f"line {li:3d}: default {rows[-1][0]}  wide {rows[-1][1]}  -> variant {sel}")
+            print(f"line {li:3d}: default {rows[-1][0]}  wide {rows[-1][1]}  -> variant {sel[-1]}")
     if not args.timings:
         return
     t = json.load(open(args.timings))
     us = {v: np.array([t[f"{li}/nchw/{v}"]["us"] for li in range(len(lines))]) for v in (2, 3)}
     for cfg, v in ((0, 2), (1, 3)):
-        st = np.array([r[cfg] for r in rows], dtype=np.float64) / 640.0
-        A = np.stack([np.ones(len(st)), st[:, 0], st[:, 1], st[:, 4]], 1)
+        st = np.array([r[cfg] for r in rows], dtype=np.float64)
+        # the model of csrc/cost_volume.hip: sweep_model_us (launches WITH the work list: chains are cut to <= 3 staged runs)
+        A = np.stack([np.ones(len(st)), np.minimum(st[:, 6], 3), (st[:, 4] > 0) * 1.0, st[:, 7], st[:, 4], st[:, 1]], 1)
         coef, *_ = np.linalg.lstsq(A, us[v], rcond=None)
         pred = A @ coef
-        print(f"variant {v}: base {coef[0]:.3f} us, per run {coef[1]:.3f}, per record {coef[2]:.5f}, per spilled plane {coef[3]:.3f};  "
+        print(f"variant {v}: base {coef[0]:.4f} us, per staged run of the longest work item (<= 3) {coef[1]:.4f}, non-empty second pass {coef[2]:.4f}, "
+              f"per queued plane of the worst workgroup {coef[3]:.4f}, per queued plane {coef[4]:.5f}, per staged record {coef[5]:.3e};  "
               f"rms residual {np.sqrt(np.mean((pred - us[v]) ** 2)):.2f} us, max {np.abs(pred - us[v]).max():.1f}")
         us[f"pred{v}"] = pred
     best = np.minimum(us[2], us[3])
     chosen = np.where(us["pred2"] <= us["pred3"], us[2], us[3])
-    print(f"mean us: default everywhere {us[2].mean():.2f}, wide everywhere {us[3].mean():.2f}, oracle choice {best.mean():.2f}, "
-          f"model choice {chosen.mean():.2f} (wide on {int((us['pred2'] > us['pred3']).sum())} of {len(lines)} pairs); worst: default {us[2].max():.1f}, "
-          f"model choice {chosen.max():.1f}")
+    print(f"mean us over {len(lines)} keyframe pairs: default everywhere {us[2].mean():.2f} (worst {us[2].max():.1f}), wide everywhere {us[3].mean():.2f} "
+          f"(worst {us[3].max():.1f}), the faster of the two {best.mean():.2f}, model's choice {chosen.mean():.2f} (worst {chosen.max():.1f}; wide on "
+          f"{int((us['pred2'] > us['pred3']).sum())} pairs)")
+    lib_choice = np.array([us[2][i] if sel[i] == 2 else us[3][i] for i in range(len(lines))])
+    print(f"the library's current dvmvs_sweep_select_variant on these timings: mean {lib_choice.mean():.2f}, worst {lib_choice.max():.1f}, wide on {sel.count(3)} pairs")
 
 
 if __name__ == "__main__":
