@@ -4,10 +4,12 @@ The reference builds its FeatureExtractor from ``torchvision.models.mnasnet1_0(p
 FeatureShrinker from ``torchvision.ops.FeaturePyramidNetwork`` (/root/reference/dvmvs/fusionnet/model.py:122-164).
 torchvision is not part of this stack, so the two architectures are restated here with the module nesting that
 yields identical parameter names (``layers.{0,1,3,4,6,7}``, ``inner_blocks.N``, ``layer_blocks.N``), which lets
-the published checkpoints load unchanged.  All convolutions are plain ``torch.nn.Conv2d`` and run on MIOpen.
+the published checkpoints load unchanged.  All dense convolutions are plain ``torch.nn.Conv2d`` and run on MIOpen; the depthwise layers are
+``DepthwiseConv2d`` (an ``nn.Conv2d`` whose GPU forward / backward are HIP kernels).
 """
 from collections import OrderedDict
 
+import torch
 import torch.nn.functional as F
 from torch import nn
 
@@ -25,6 +27,22 @@ MNASNET_STACKS = (
 )
 
 
+class DepthwiseConv2d(nn.Conv2d):
+    """nn.Conv2d for the depthwise layers of MnasNet (groups == channels, k in {3, 5}, padding k // 2, no bias): same parameters and
+    state-dict keys; on the GPU in float32 the forward and both gradients are HIP kernels (dvmvs::depthwise_conv_train) -- MIOpen runs
+    these layers through its naive reference kernels, ~10 ms of a training step.  (At inference the frame engine replaces the layer
+    together with its BatchNorm + ReLU by dvmvs::depthwise_conv.)"""
+
+    def forward(self, x):
+        k = self.kernel_size
+        if (x.is_cuda and x.dtype == torch.float32 and self.bias is None and self.groups == self.in_channels == self.out_channels and
+                k[0] == k[1] and k[0] in (3, 5) and tuple(self.padding) == (k[0] // 2, k[0] // 2) and tuple(self.dilation) == (1, 1) and
+                self.stride[0] == self.stride[1] and self.stride[0] in (1, 2) and self.padding_mode == "zeros"):
+            from dvmvs.hip import ops as _ops
+            return _ops.depthwise_conv_train(x, self.weight, self.stride[0])
+        return super().forward(x)
+
+
 def _bn(channels):
     return nn.BatchNorm2d(channels, momentum=MNASNET_BN_MOMENTUM)
 
@@ -38,7 +56,7 @@ class InvertedResidual(nn.Module):
         self.apply_residual = cin == cout and stride == 1
         self.layers = nn.Sequential(
             nn.Conv2d(cin, mid, 1, bias=False), _bn(mid), nn.ReLU(inplace=True),
-            nn.Conv2d(mid, mid, kernel, padding=kernel // 2, stride=stride, groups=mid, bias=False), _bn(mid),
+            DepthwiseConv2d(mid, mid, kernel, padding=kernel // 2, stride=stride, groups=mid, bias=False), _bn(mid),
             nn.ReLU(inplace=True),
             nn.Conv2d(mid, cout, 1, bias=False), _bn(cout))
 
@@ -66,7 +84,7 @@ def mnasnet1_0_trunk_layers():
     """
     layers = [
         nn.Conv2d(3, 32, 3, padding=1, stride=2, bias=False), _bn(32), nn.ReLU(inplace=True),
-        nn.Conv2d(32, 32, 3, padding=1, stride=1, groups=32, bias=False), _bn(32), nn.ReLU(inplace=True),
+        DepthwiseConv2d(32, 32, 3, padding=1, stride=1, groups=32, bias=False), _bn(32), nn.ReLU(inplace=True),
         nn.Conv2d(32, 16, 1, padding=0, stride=1, bias=False), _bn(16),
     ]
     layers += [_stack(*spec) for spec in MNASNET_STACKS]

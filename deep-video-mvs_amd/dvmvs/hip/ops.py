@@ -473,6 +473,91 @@ def _(x):
     _no_cpu("upsample2x")
 
 
+@torch.library.custom_op("dvmvs::upsample2x_bwd", mutates_args=(), device_types="cuda")
+def upsample2x_bwd(grad_out: Tensor) -> Tensor:
+    """Adjoint of ``upsample2x`` as a gather (no atomics: bit-reproducible), dvmvs_upsample2x_bwd."""
+    _dev_f32("upsample2x_bwd", grad_out)
+    grad_out = grad_out.contiguous()
+    B, C, OH, OW = grad_out.shape
+    grad_in = torch.empty((B, C, OH // 2, OW // 2), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        rc = _capi.lib().dvmvs_upsample2x_bwd(_ptr(grad_out), _ptr(grad_in), B, C, OH // 2, OW // 2, _stream(grad_out))
+    _capi.check(rc, "dvmvs_upsample2x_bwd")
+    return grad_in
+
+
+@upsample2x_bwd.register_fake
+def _(grad_out):
+    B, C, OH, OW = grad_out.shape
+    return grad_out.new_empty((B, C, OH // 2, OW // 2))
+
+
+torch.library.register_autograd("dvmvs::upsample2x", lambda ctx, grad: upsample2x_bwd(grad), setup_context=lambda ctx, inputs, output: None)
+
+
+@torch.library.custom_op("dvmvs::depthwise_conv_train", mutates_args=(), device_types="cuda")
+def depthwise_conv_train(x: Tensor, weight: Tensor, stride: int) -> Tensor:
+    """Depthwise k x k convolution (weight [C,1,k,k], padding k//2, no bias) with gradients: the training-time form of
+    ``depthwise_conv`` (MIOpen runs these MnasNet layers, forward and backward, through its naive reference kernels)."""
+    _dev_f32("depthwise_conv_train", x, weight)
+    x, weight = x.contiguous(), weight.contiguous()
+    B, C, H, W = x.shape
+    k = weight.shape[-1]
+    if tuple(weight.shape) != (C, 1, k, k):
+        raise ValueError(f"dvmvs::depthwise_conv_train: weight {tuple(weight.shape)} is not depthwise for {C} channels")
+    pad = k // 2
+    out = torch.empty((B, C, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().dvmvs_depthwise_conv_fwd(_ptr(x), _ptr(weight), None, None, 0, _ptr(out), B, C, H, W, k, int(stride), 0, _stream(x))
+    _capi.check(rc, "dvmvs_depthwise_conv_fwd")
+    return out
+
+
+@depthwise_conv_train.register_fake
+def _(x, weight, stride):
+    B, C, H, W = x.shape
+    k = weight.shape[-1]
+    pad = k // 2
+    return x.new_empty((B, C, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1))
+
+
+@torch.library.custom_op("dvmvs::depthwise_conv_bwd", mutates_args=(), device_types="cuda")
+def depthwise_conv_bwd(grad_out: Tensor, x: Tensor, weight: Tensor, stride: int, need_input: bool, need_weight: bool) -> Tuple[Tensor, Tensor]:
+    """(grad_x, grad_weight) of ``depthwise_conv_train`` (gathers / a fixed-order reduction: no atomics); an unneeded one is empty."""
+    _dev_f32("depthwise_conv_bwd", grad_out, x, weight)
+    grad_out, x, weight = grad_out.contiguous(), x.contiguous(), weight.contiguous()
+    B, C, H, W = x.shape
+    k = weight.shape[-1]
+    gx = torch.empty_like(x) if need_input else x.new_empty(0)
+    gw = torch.empty_like(weight) if need_weight else x.new_empty(0)
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().dvmvs_depthwise_conv_bwd(_ptr(grad_out), _ptr(x), _ptr(weight), _ptr(gx) if need_input else None,
+                                                  _ptr(gw) if need_weight else None, B, C, H, W, k, int(stride), _stream(x))
+    _capi.check(rc, "dvmvs_depthwise_conv_bwd")
+    return gx, gw
+
+
+@depthwise_conv_bwd.register_fake
+def _(grad_out, x, weight, stride, need_input, need_weight):
+    return (torch.empty_like(x) if need_input else x.new_empty(0)), (torch.empty_like(weight) if need_weight else x.new_empty(0))
+
+
+def _depthwise_train_setup(ctx, inputs, output):
+    x, weight, stride = inputs
+    ctx.stride = stride
+    ctx.save_for_backward(x, weight)
+
+
+def _depthwise_train_backward(ctx, grad):
+    x, weight = ctx.saved_tensors
+    need_input, need_weight = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    gx, gw = depthwise_conv_bwd(grad, x, weight, ctx.stride, need_input, need_weight)
+    return (gx if need_input else None), (gw if need_weight else None), None
+
+
+torch.library.register_autograd("dvmvs::depthwise_conv_train", _depthwise_train_backward, setup_context=_depthwise_train_setup)
+
+
 @torch.library.custom_op("dvmvs::depthwise_conv", mutates_args=(), device_types="cuda")
 def depthwise_conv(x: Tensor, weight: Tensor, bias: Tensor, stride: int, activation: int, pre_bias: Tensor, pre_relu: bool) -> Tensor:
     """Depthwise k x k convolution (weight [C,1,k,k], padding k//2) + bias (numel 0 = none) + activation, one HIP launch.  With

@@ -23,9 +23,9 @@ hyper_channels = 32
 
 
 def _upsample2(x):
-    """x2 bilinear up-sampling, align_corners=True.  On the GPU at inference this is the HIP kernel
-    (dvmvs_upsample2x_fwd, same interpolation formula); with autograd enabled or on the CPU it is ATen's."""
-    if x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad):
+    """x2 bilinear up-sampling, align_corners=True.  On the GPU this is the HIP kernel (dvmvs_upsample2x_fwd, same interpolation
+    formula; with autograd its adjoint dvmvs_upsample2x_bwd, a gather without atomics); on the CPU it is ATen's."""
+    if x.is_cuda and x.dtype == torch.float32:
         from dvmvs.hip import ops as _ops
         return _ops.upsample2x(x)
     return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)

@@ -200,6 +200,18 @@ int dvmvs_lstm_gates_bwd(const float* grad_h, const float* grad_c, const float* 
                          int B, int hidden, int H, int W, dvmvs_stream_t stream);
 
 /*
+ * Gradients of two frame-path ops for training (BASELINE.json configs[4]); both are gathers / fixed-order reductions without
+ * atomics, i.e. bit-reproducible (csrc/train_ops.hip).
+ *   dvmvs_upsample2x_bwd      adjoint of dvmvs_upsample2x_fwd (x2 bilinear, align_corners; /root/reference/dvmvs/fusionnet/model.py:59,114):
+ *                             grad_out [B,C,2H,2W] -> grad_in [B,C,H,W]
+ *   dvmvs_depthwise_conv_bwd  depthwise k x k (3 or 5), padding k/2, stride 1 or 2 (the MnasNet layers): grad_out [B,C,OH,OW], in [B,C,H,W],
+ *                             weight [C,1,k,k] -> grad_in [B,C,H,W] and / or grad_weight [C,1,k,k] (either pointer may be NULL)
+ */
+int dvmvs_upsample2x_bwd(const float* grad_out, float* grad_in, int B, int C, int H, int W, dvmvs_stream_t stream);
+int dvmvs_depthwise_conv_bwd(const float* grad_out, const float* in, const float* weight, float* grad_in, float* grad_weight,
+                             int B, int C, int H, int W, int kernel_size, int stride, dvmvs_stream_t stream);
+
+/*
  * 3x3, padding-1 convolutions on the bottleneck maps of a 320x256 frame (8x10, and 16x20 with stride 1 or 2) as a weight-streaming
  * fp32 MFMA GEMM with a DETERMINISTIC split-K (csrc/bottleneck_conv.hip).  Replaces, for those shapes only, the nn.Conv2d of the
  * ConvLSTM cell (/root/reference/dvmvs/convlstm.py:43-44: 1024 -> 2048 channels) and the 256 / 512-channel layers around it

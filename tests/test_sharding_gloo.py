@@ -58,12 +58,20 @@ class _StubEngine:
 
     def new_sequence(self):
         self.sequences += 1
+        self.announced = None
 
     def reset(self):
         self.resets += 1
 
-    def step(self, image, pose, measurement_images, measurement_poses, full_K, frame_id=None, measurement_ids=None):
+    announced = None
+
+    def step(self, image, pose, measurement_images, measurement_poses, full_K, frame_id=None, measurement_ids=None,
+             next_reference_image=None, next_frame_id=None):
         assert tuple(image.shape) == (1, 3, 256, 320) and len(measurement_images) == len(measurement_poses) == 2
+        # feature look-ahead of the offline runner: the frame announced by the previous call is the one that comes, with its image
+        if self.announced is not None:
+            assert self.announced[0] == frame_id and torch.equal(self.announced[1], image)
+        self.announced = None if next_reference_image is None else (next_frame_id, next_reference_image.clone())
         return torch.full((1, 256, 320), 1.0 + self.rank + 0.01 * frame_id)
 
 
