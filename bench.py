@@ -48,8 +48,9 @@ def parse():
     ap.add_argument("--no-feature-cache", action="store_true", help="recompute measurement features every frame like the reference")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-lstm-channels-last", action="store_true")
-    ap.add_argument("--no-lookahead", action="store_true",
-                    help="do not hand the engine the next keyframe's image (no feature look-ahead: every frame's features on the frame's own stream)")
+    ap.add_argument("--lookahead", type=int, default=2, choices=[0, 1, 2],
+                    help="what the engine is told about the NEXT keyframe: 0 nothing (every stage of a frame on the frame's own stream), 1 its "
+                         "image (feature extraction a frame ahead, on a second stream), 2 also its poses (plane sweep + encoder a frame ahead as well)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-reps", type=int, default=10)
@@ -498,9 +499,10 @@ def train_mode(args, world, rank, device):
     import synthetic as syn
     from dvmvs.config import Config
     from dvmvs.training import BucketedGradientReducer, train_step
-    # no exhaustive MIOpen search here: a training step has ~300 distinct forward / backward-data / backward-weight problems
-    # and searching them all takes many minutes on a fresh box
-    torch.backends.cudnn.benchmark = False
+    # MIOpen's immediate mode by default: a training step has ~300 distinct forward / backward-data / backward-weight problems and
+    # searching them all (the reference trains with cudnn.benchmark = True, run-training.py:115) takes minutes on a fresh box.
+    # DVMVS_TRAIN_CUDNN_BENCHMARK=1 searches (point MIOPEN_USER_DB_PATH at a kept directory to pay for it once).
+    torch.backends.cudnn.benchmark = os.environ.get("DVMVS_TRAIN_CUDNN_BENCHMARK", "0") != "0"
     model = [m.to(device).train() for m in build_modules()]
     params = [p for m in model for p in m.parameters()]
     reducer = BucketedGradientReducer(params)
@@ -528,6 +530,7 @@ def train_mode(args, world, rank, device):
             "unit": "subsequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"fusionnet training step, subseq_len={T}, batch={B}/GPU, Adam, L1-inv loss (BASELINE.json configs[4])",
+                       "miopen_solver_search": bool(torch.backends.cudnn.benchmark),
                        "grad_buckets": len(reducer.buckets), "grad_bytes": sum(f.numel() * 4 for f in reducer.flat),
                        "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce overlapped with backward"},
             "final_loss": float(loss)}))
@@ -580,10 +583,14 @@ def main():
     def run_frame(k):
         ids = [k - 1 - i for i in range(M)]
         meas_images = None if not args.no_feature_cache else [images[i % n_images] for i in ids]
-        lookahead = not args.no_lookahead and not args.no_feature_cache
+        level = 0 if args.no_feature_cache else args.lookahead
+        ahead = {}
+        if level >= 1:      # the sequence is known in advance (as with a pre-computed keyframe index): announce the next keyframe
+            ahead = dict(next_reference_image=images[(k + 1) % n_images], next_frame_id=k + 1)
+        if level >= 2:
+            ahead.update(next_reference_pose=seq[k + 1][0], next_measurement_poses=seq[k + 1][1], next_measurement_ids=[k - i for i in range(M)])
         return engine.step(images[k % n_images], seq[k][0], meas_images, seq[k][1], full_K,
-                           frame_id=k if not args.no_feature_cache else None, measurement_ids=ids if not args.no_feature_cache else None,
-                           next_reference_image=images[(k + 1) % n_images] if lookahead else None, next_frame_id=k + 1 if lookahead else None)
+                           frame_id=k if not args.no_feature_cache else None, measurement_ids=ids if not args.no_feature_cache else None, **ahead)
 
     with torch.no_grad():
         # buffer fill: the first M keyframes only contribute features (reference: keyframe-buffer response 0 / short lists)
@@ -655,7 +662,9 @@ def main():
                        "sequences_per_gpu": 1, "hip_graphs": not args.no_graphs, "bn_folded": not args.no_fold_bn,
                        "feature_cache": not args.no_feature_cache, "full_resolution_only": True,
                        "miopen_solver_search": bool(torch.backends.cudnn.benchmark),
-                       "feature_lookahead": 0 if (args.no_lookahead or args.no_feature_cache) else 1,
+                       "lookahead": {0: "none", 1: "next keyframe's feature extraction on a second stream",
+                                     2: "next keyframe's feature extraction + plane sweep + encoder on a second stream, concurrently with this "
+                                        "keyframe's ConvLSTM + decoder (bit-identical results)"}[0 if args.no_feature_cache else args.lookahead],
                        "conv_epilogues_inside_miopen": (lambda rep: f"{sum(1 for r in rep if r[2])} of {len(rep)} dense convolution problems "
                                                         "(bit-identical to convolution + epilogue AND faster at warm-up)")(engine.conv_plan_report()),
                        "weights": "seeded (tests/synthetic.py) + published FPN checkpoint",

@@ -8,9 +8,9 @@
 
 // coefficients of dvmvs::sweep_model_us (us), least squares over the 285 keyframe pairs of the sample scene, launches with the
 // host-planned work list (tools/sweep_select_fit.py on tools/cv_microbench.py --lines all --variants 2,3 --work-list;
-// profiles/r04_sweep_select_fit.md): rms residual 3.2 us (default) / 2.3 us (wide)
-#define SWEEP_MODEL_DEFAULT {22.7145, 1.1898, 20.3308, 0.7128, 0.01731, 2.163e-05}
-#define SWEEP_MODEL_WIDE {23.8151, 3.9715, 20.3800, 0.8606, 0.01036, 2.050e-05}
+// profiles/r04_sweep_select_fit.md): rms residual 3.2 us (default) / 2.4 us (wide)
+#define SWEEP_MODEL_DEFAULT {22.7412, 1.2906, 10.4202, 0.8341, 0.02711, 2.140e-05}
+#define SWEEP_MODEL_WIDE {24.9001, 3.8563, 8.7854, 1.1609, 0.02185, 1.917e-05}
 
 namespace dvmvs {
 
@@ -116,7 +116,7 @@ int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream);
 
 // Predicted duration (us) of the sweep + second pass in one configuration from its plan statistics (dvmvs_sweep_plan_stats):
 // base + staged runs of the longest work item (the work list cuts chains to <= 3) + a fixed cost when the second pass is not empty
-// (its chain of dependent gathers: ~20 us however few units) + queued planes of the worst workgroup + all queued planes + all staged
+// (its chain of dependent loads and gathers: ~10 us however few units) + queued planes of the worst workgroup + all queued planes + all staged
 // records.  Fitted on the 128x160x64 shape; it only ranks the two configurations, so other shapes reuse it as it is.
 inline double sweep_model_us(int configuration, const long long* st, int B, int H, int W, int D) {
   static const double kCoef[2][6] = {SWEEP_MODEL_DEFAULT, SWEEP_MODEL_WIDE};

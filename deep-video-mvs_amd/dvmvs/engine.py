@@ -450,11 +450,14 @@ class DepthEngine:
         if self._static is None:
             # the frame's small matrices: one device buffer (one upload per frame), fixed offsets so that captured graphs keep
             # pointing at the right place; Hm / kt are sized for the ABI's maximum number of measurement frames
+            items = _ops.sweep_work_list_words(S, H // 2, W // 2, self.n_depth_levels)
             sizes = [("Hm", S * _MAX_MEAS * 9), ("kt", S * _MAX_MEAS * 3), ("reproject_T", S * 16), ("lstm_T", S * 16),
                      ("full_K", S * 9), ("half_K", S * 9), ("lstm_K", S * 9), ("pose", S * 16), ("prev_pose", S * 16),
                      ("meas_pose", _MAX_MEAS * S * 16),
                      # the sweep's work list (32-bit words, planned on the host per frame: dvmvs_sweep_work_list) rides in the same upload
-                     ("sweep_items", _ops.sweep_work_list_words(S, H // 2, W // 2, self.n_depth_levels))]
+                     ("sweep_items", items),
+                     # the sweep parameters of the OTHER buffer set (look-ahead: the next frame's sweep runs during this frame)
+                     ("Hm1", S * _MAX_MEAS * 9), ("kt1", S * _MAX_MEAS * 3), ("sweep_items1", items)]
             self._param_offsets, total = {}, 0
             for name, n in sizes:
                 self._param_offsets[name] = (total, n)
@@ -476,8 +479,11 @@ class DepthEngine:
                 # feature look-ahead (step(next_reference_image=...)): the NEXT frame's image and FPN outputs need a home while this
                 # frame's encoder / decoder read their own -- a second set of the buffers the feature extraction writes and of the
                 # buffer that holds the image; frames alternate between the two sets
-                direct["sets"] = [dict(enc_cat=direct["enc_cat"], full_in=direct["full_in"]),
-                                  dict(enc_cat=[torch.zeros_like(c) for c in direct["enc_cat"]], full_in=torch.zeros_like(direct["full_in"]))]
+                # and, for the deeper look-ahead (the next frame's sweep + encoder as well), of everything the encoder writes
+                keys = ("enc_cat", "dec_cat", "full_in", "lstm_cat")
+                clone = lambda v: [torch.zeros_like(t) for t in v] if isinstance(v, list) else torch.zeros_like(v)
+                direct["sets"] = [dict({k: direct[k] for k in keys}, index=0, meas_feat=[]),
+                                  dict({k: clone(direct[k]) for k in keys}, index=1, meas_feat=[])]
             self._direct_buffers = direct
             image = direct["full_in"][:, 33:36] if self.direct else z(S, 3, H, W)      # the decoder's last concatenation ends with the image
             depth = direct["depth_store"] if self.direct else z(S, H, W)
@@ -491,26 +497,41 @@ class DepthEngine:
                                 prev_depth=depth.view(S, 1, H, W) if self.direct else z(S, 1, H, W), h=z(S, 512, H // 32, W // 32),
                                 c=z(S, 512, H // 32, W // 32), meas_feat=[], ref_half=ref_half, depth=depth)
             self._ring = [(torch.zeros(total, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(_STAGING_SLOTS)]
+            self._param_host = torch.zeros(total, dtype=torch.float32)      # host mirror of the block: a step rewrites only its own regions
         while len(self._static["meas_feat"]) < n_meas:
             self._static["meas_feat"].append(z(S, 32, H // 2, W // 2))
+        if self.direct:
+            sets = self._direct_buffers["sets"]
+            sets[0]["meas_feat"] = self._static["meas_feat"]
+            while len(sets[1]["meas_feat"]) < n_meas:
+                sets[1]["meas_feat"].append(z(S, 32, H // 2, W // 2))
 
-    def _sweep_views(self, n_meas):
-        """Hm [S,n_meas,9] and kt [S,n_meas,3] views of the parameter buffer (contiguous prefixes of their regions)."""
+    def _sweep_views(self, n_meas, index=0):
+        """Hm [S,n_meas,9] and kt [S,n_meas,3] views of the parameter buffer (contiguous prefixes of their regions) of buffer set ``index``."""
         S, p = self.sequences, self._static["params"]
-        o_h, o_k = self._param_offsets["Hm"][0], self._param_offsets["kt"][0]
+        suffix = "1" if index else ""
+        o_h, o_k = self._param_offsets["Hm" + suffix][0], self._param_offsets["kt" + suffix][0]
         return p[o_h:o_h + S * n_meas * 9].view(S, n_meas, 9), p[o_k:o_k + S * n_meas * 3].view(S, n_meas, 3)
 
-    def _sweep_items(self):
-        """The device copy of this frame's work list (a fixed region of the parameter buffer: captured graphs keep pointing at it)."""
+    def _sweep_items(self, index=0):
+        """The device copy of a frame's work list (a fixed region of the parameter buffer per buffer set: captured graphs keep pointing at it)."""
         if not self.sweep_work_list:
             return None
-        o, n = self._param_offsets["sweep_items"]
+        o, n = self._param_offsets["sweep_items1" if index else "sweep_items"]
         return self._static["params"].view(torch.int32)[o:o + n]
 
-    def _upload_frame_parameters(self, n_meas, pose, measurement_poses, full_K):
+    def _upload_frame_parameters(self, n_meas, pose, measurement_poses, full_K, index=0, own_sweep=True, next_frame=None):
         """Evaluates the frame's small matrices on the host (reference mode) and sends them, the intrinsics and the poses to
         the device with ONE asynchronous copy out of a pinned staging slot.  The slot's previous copy (issued _STAGING_SLOTS
-        frames ago) must have executed before it is overwritten: its event is waited for, which never blocks in practice."""
+        frames ago) must have executed before it is overwritten: its event is waited for, which never blocks in practice.
+
+        ``index``: the buffer set of this frame (its sweep parameters live in that set's region); ``own_sweep`` False: this frame's
+        sweep already ran (look-ahead), its region is left as it is; ``next_frame`` = (pose, measurement poses) of the NEXT frame whose
+        sweep runs during this one: its matrices / work list go into the other set's region.  Regions a step does not rewrite keep
+        their contents through the host mirror of the block.
+        Returns (the host pose that becomes "the previous pose" -- committed by step() only after the frame was launched, so that a
+        frame that raises leaves (h, c, previous depth, previous pose) those of one frame --, this frame's sweep configuration or
+        None, the next frame's or None)."""
         S = self.sequences
         host = _pose_algebra.to_host
         pose, full_K = host(pose).reshape(S, 4, 4), host(full_K).reshape(S, 3, 3)
@@ -522,26 +543,34 @@ class DepthEngine:
         # relative pose: its previous depth is all zero, and under the identity every zero-depth point stays at z = 0, which the
         # splat never writes -- an exactly empty depth estimate, as on the reference's first-frame path.
         previous = torch.where(self._no_previous.view(S, 1, 1), pose, self._prev_pose_host)
-        staging, event = self._ring[self._ring_pos]
-        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
-        event.synchronize()
+        mirror = self._param_host
 
         def put(name, tensor):
             o, n = self._param_offsets[name]
             flat = tensor.reshape(-1)
-            staging[o:o + flat.numel()].copy_(flat)
+            mirror[o:o + flat.numel()].copy_(flat)
 
-        sweep_variant = _utils.COST_VOLUME_VARIANT
-        if self.pose_algebra == "reference":
-            Hm, kt = _pose_algebra.sweep_matrices_host(pose, measurement_poses, half_K)
-            put("Hm", Hm)
-            put("kt", kt)
+        def put_sweep(region, ref_pose, meas_poses):
+            """Sweep matrices, configuration and work list of one frame into buffer set ``region``'s part of the block."""
+            suffix = "1" if region else ""
+            Hm, kt = _pose_algebra.sweep_matrices_host(ref_pose, meas_poses, half_K)
+            put("Hm" + suffix, Hm)
+            put("kt" + suffix, kt)
             # which sweep configuration suits this keyframe geometry: decided here, on the host copies (one graph per configuration)
-            sweep_variant = _utils.sweep_variant((Hm, kt), self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth)
+            variant = _utils.sweep_variant((Hm, kt), self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth)
             if self.sweep_work_list:
-                o, n = self._param_offsets["sweep_items"]
-                _ops.sweep_work_list_host(Hm, kt, self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth, sweep_variant,
-                                          out=staging.view(torch.int32)[o:o + n])
+                o, n = self._param_offsets["sweep_items" + suffix]
+                _ops.sweep_work_list_host(Hm, kt, self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth, variant,
+                                          out=mirror.view(torch.int32)[o:o + n])
+            return variant
+
+        sweep_variant = _utils.COST_VOLUME_VARIANT if own_sweep else None
+        next_variant = None
+        if self.pose_algebra == "reference":
+            if own_sweep:
+                sweep_variant = put_sweep(index, pose, measurement_poses)
+            if next_frame is not None:
+                next_variant = put_sweep(1 - index, host(next_frame[0]).reshape(S, 4, 4), [host(p).reshape(S, 4, 4) for p in next_frame[1]])
             if self.is_fusionnet:
                 eye = torch.eye(4).expand(S, 4, 4)
                 if bool(self._no_previous.all()):      # nothing to relate to: the identity, exactly (see above)
@@ -558,10 +587,14 @@ class DepthEngine:
         put("pose", pose)
         put("prev_pose", previous)
         put("meas_pose", torch.stack(measurement_poses))
+        staging, event = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        event.synchronize()
+        staging.copy_(mirror)
         with torch.cuda.device(self.device):     # the ring guard must be recorded on the engine's device, whichever is current
             self._static["params"].copy_(staging, non_blocking=True)
             event.record(torch.cuda.current_stream(self.device))
-        return pose.clone(), sweep_variant      # step() commits the pose as the previous one once the frame has been launched
+        return pose.clone(), sweep_variant, next_variant
 
     # ---- destination-passing frame body (one sequence) ------------------------------------------------------------------
     def _fpn_direct(self, taps, outs):
@@ -603,26 +636,42 @@ class DepthEngine:
             self._lstm_combined = torch.empty(x.shape[0], k[0], x.shape[2], x.shape[3], device=x.device, dtype=torch.float32)
         return True
 
-    def _frame_body_direct(self, n_meas, has_previous, sweep_variant=0, parity=0, prefetched=False, prefetch=False):
-        """One frame on buffer set ``parity``.  ``prefetched``: its reference features are already there (the previous step computed
-        them); ``prefetch``: the NEXT frame's reference features (image in the other set) are computed as well -- when this frame's own
-        are prefetched, on a second stream, concurrently with this frame's sweep .. decoder: at batch 1 most kernels of a frame leave
-        most of the chip idle, and the next frame's feature extraction depends on nothing this frame computes (measured:
-        tools/frame_stage_probe.py, 1603 -> 1278 us per frame)."""
+    def _frame_body_direct(self, n_meas, has_previous, sweep_variant=0, parity=0, have=0, give=0, n_meas_next=0, next_variant=0):
+        """One frame on buffer set ``parity``.  ``have``: how much of it the previous step already computed (0 nothing, 1 its reference
+        features, 2 also its sweep + encoder); ``give``: how much of the NEXT frame (other buffer set) this step computes (0 / 1 / 2).
+        When this frame's own share does not include a stage the next frame's share includes, the next frame's work runs on a second
+        stream, concurrently with this frame's remaining stages: at batch 1 most kernels of a frame leave most of the chip idle, and
+        the next frame's feature extraction, sweep and encoder depend on nothing this frame computes -- only the ConvLSTM and the
+        decoder carry state (measured: tools/frame_stage_probe.py).  Same kernels on the same inputs either way: results are
+        bit-identical to the one-stream frame."""
         sets = self._direct_buffers["sets"]
-        if not prefetched:
-            self._reference_features_direct(sets[parity])
-        if prefetch and not prefetched:
-            # (both on one stream: the feature extractor's modules are not run concurrently with themselves)
-            self._reference_features_direct(sets[1 - parity])
-            prefetch = False
-        if prefetch:
+        cur, nxt = sets[parity], sets[1 - parity]
+
+        def own():
+            if have < 1:
+                self._reference_features_direct(cur)
+            if have < 2:
+                self._sweep_encoder_direct(cur, n_meas, sweep_variant)
+            self._lstm_decoder_direct(cur, has_previous)
+
+        def ahead():
+            if give >= 1:
+                self._reference_features_direct(nxt)
+            if give >= 2:
+                self._sweep_encoder_direct(nxt, n_meas_next, next_variant)
+
+        if give == 0:
+            own()
+        elif have < give:
+            # (one stream: a stage's modules and scratch buffers are not run concurrently with themselves)
+            own()
+            ahead()
+        else:
             main = torch.cuda.current_stream(self.device)
             self._side_stream.wait_stream(main)
             with torch.cuda.stream(self._side_stream):
-                self._reference_features_direct(sets[1 - parity])
-        self._after_features_direct(n_meas, has_previous, sweep_variant, sets[parity])
-        if prefetch:
+                ahead()
+            own()
             main.wait_stream(self._side_stream)
 
     def _reference_features_direct(self, buffers):
@@ -631,14 +680,21 @@ class DepthEngine:
 
     def _after_features_direct(self, n_meas, has_previous, sweep_variant=0, buffers=None):
         """Everything of a frame behind the feature extraction: sweep, encoder, re-projection, ConvLSTM, decoder."""
-        s, d = self._static, self._direct_buffers
-        buffers = d["sets"][0] if buffers is None else buffers
-        enc_cat, dec_cat = buffers["enc_cat"], d["dec_cat"]
-        Hm, kt = self._sweep_views(n_meas)
+        buffers = self._direct_buffers["sets"][0] if buffers is None else buffers
+        self._sweep_encoder_direct(buffers, n_meas, sweep_variant)
+        self._lstm_decoder_direct(buffers, has_previous)
+
+    def _sweep_encoder_direct(self, buffers, n_meas, sweep_variant=0):
+        """Plane sweep + cost-volume encoder of the frame whose features are in ``buffers``: reads that set's measurement features and
+        sweep parameters, writes its skip connections (into the decoder's concatenation buffers) and its bottleneck map.  Depends on
+        nothing the PREVIOUS frame computes -- no recurrent state, no previous depth -- which is what lets it run a frame ahead."""
+        s = self._static
+        enc_cat, dec_cat = buffers["enc_cat"], buffers["dec_cat"]
+        Hm, kt = self._sweep_views(n_meas, buffers["index"])
         if self.pose_algebra == "exact":
             Hm, kt = _ops.sweep_matrices(s["pose"], s["meas_pose"][:n_meas], s["half_K"])
-        _ops.cost_volume_into(enc_cat[0][:, :32], s["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, enc_cat[0][:, 32:], sweep_variant,
-                              self._sweep_items())
+        _ops.cost_volume_into(enc_cat[0][:, :32], buffers["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, enc_cat[0][:, 32:], sweep_variant,
+                              self._sweep_items(buffers["index"]))
         # encoder: aggregator output = skip connection, written where the decoder will read it
         enc, dec = self.enc, self.dec
         x = None
@@ -652,10 +708,16 @@ class DepthEngine:
             if level < 3:
                 block.standard_convolution.conv2[0](x, out=enc_cat[level + 1][:, 32:])
             elif self.is_fusionnet:
-                x = block.standard_convolution.conv2[0](x, out=d["lstm_cat"][:, :512])
+                x = block.standard_convolution.conv2[0](x, out=buffers["lstm_cat"][:, :512])
             else:
-                x = block.standard_convolution.conv2[0](x)
-        bottom = x
+                x = block.standard_convolution.conv2[0](x, out=buffers["lstm_cat"][:, :512])      # (pairnet: the buffer is just the bottleneck's home)
+
+    def _lstm_decoder_direct(self, buffers, has_previous):
+        """Re-projection of the previous depth, ConvLSTM and decoder of the frame whose encoder outputs are in ``buffers``: the part of a
+        frame that carries the recurrent state."""
+        s, d = self._static, self._direct_buffers
+        dec, dec_cat, lstm_cat = self.dec, buffers["dec_cat"], buffers["lstm_cat"]
+        bottom = lstm_cat[:, :512]
         if self.is_fusionnet:
             cell = self.lstm.lstm_cell
             if has_previous:
@@ -663,19 +725,19 @@ class DepthEngine:
                 reproject_T = _ops.relative_pose(s["pose"], s["prev_pose"]) if exact else s["reproject_T"]
                 lstm_T = _ops.relative_pose(s["prev_pose"], s["pose"]) if exact else s["lstm_T"]
                 _ops.depth_reproject_lowres_into(reproject_T, s["prev_depth"], s["full_K"], s["half_K"], d["zbuffer"], d["estimate"], 16)
-                _ops.hidden_warp_into(s["h"], d["estimate"], lstm_T, s["lstm_K"], True, d["lstm_cat"][:, 512:])
+                _ops.hidden_warp_into(s["h"], d["estimate"], lstm_T, s["lstm_K"], True, lstm_cat[:, 512:])
             else:
-                d["lstm_cat"][:, 512:].copy_(s["h"])      # first frame of a sequence: the (zero) state as it is, no warp (convlstm.py:29)
-            if self._lstm_bottleneck(d["lstm_cat"]):
+                lstm_cat[:, 512:].copy_(s["h"])      # first frame of a sequence: the (zero) state as it is, no warp (convlstm.py:29)
+            if self._lstm_bottleneck(lstm_cat):
                 # the 1024 -> 2048-channel convolution as K-split partial sums (75 MB of weights streamed once through the MFMA
                 # pipe), added up in a fixed order by a chip-wide reduction (the gates kernel can add them itself --
                 # lstm_gates_partials_into -- but its 32 workgroups take 30 us over 16 splits; reduction + gates: 5.6 + 5.3 us)
-                splits = _ops.bottleneck_conv_into(d["lstm_cat"], self._lstm_packed, cell.conv.weight.shape[0], 1, self._lstm_partials)
+                splits = _ops.bottleneck_conv_into(lstm_cat, self._lstm_packed, cell.conv.weight.shape[0], 1, self._lstm_partials)
                 _ops.partial_sums_bias_act_into(self._lstm_partials, splits, self._lstm_combined, None, _ops.ACTIVATIONS["none"],
                                                 tuple(self._lstm_combined.shape))
                 _ops.lstm_gates_into(self._lstm_combined, s["c"], s["h"])
             else:
-                combined = cell.conv(d["lstm_cat"])
+                combined = cell.conv(lstm_cat)
                 if not combined.is_contiguous():       # channels-last convolution (lstm_channels_last): back to the gates' NCHW rows
                     combined = combined.contiguous()
                 _ops.lstm_gates_into(combined, s["c"], s["h"])
@@ -692,10 +754,10 @@ class DepthEngine:
         dec.depth_layer_full[0](refined, out=s["prev_depth"], activation=_ops.ACTIVATION_SIGMOID_TO_DEPTH,
                                 p0=dec.inverse_depth_multiplier, p1=dec.inverse_depth_base)
 
-    def _frame_body(self, n_meas, has_previous, sweep_variant=0, parity=0, prefetched=False, prefetch=False):
+    def _frame_body(self, n_meas, has_previous, sweep_variant=0, parity=0, have=0, give=0, n_meas_next=0, next_variant=0):
         """The per-frame computation on the static buffers (this is what gets captured into a hipGraph)."""
         if self.direct:
-            return self._frame_body_direct(n_meas, has_previous, sweep_variant, parity, prefetched, prefetch)
+            return self._frame_body_direct(n_meas, has_previous, sweep_variant, parity, have, give, n_meas_next, next_variant)
         s = self._static
         feats = self._features(s["image"])
         ref_half = feats[0].contiguous()
@@ -727,7 +789,8 @@ class DepthEngine:
     # ---- public -----------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, reference_image, reference_pose, measurement_images, measurement_poses, full_K, frame_id=None,
-             measurement_ids=None, next_reference_image=None, next_frame_id=None):
+             measurement_ids=None, next_reference_image=None, next_frame_id=None, next_reference_pose=None,
+             next_measurement_poses=None, next_measurement_ids=None):
         """One keyframe (of each of the S sequences).  Images [S,3,H,W] normalised, on the GPU; poses [S,4,4] cam-to-world and
         ``full_K`` [S,3,3] preferably as HOST tensors (that is where they come from, and where the frame's small matrices are
         evaluated; device tensors are copied back, which synchronises).  With S > 1 the sequences advance in lockstep:
@@ -735,11 +798,14 @@ class DepthEngine:
 
         ``measurement_images[i]`` may be ``None`` when ``measurement_ids[i]`` is in the feature cache.
 
-        Feature look-ahead (one sequence per engine): ``next_reference_image`` / ``next_frame_id`` = the reference image of the NEXT
-        call and its ``frame_id``, when the caller already has it (a pre-computed keyframe index, a camera that is a frame ahead).
-        Its MnasNet + FPN features are then computed during THIS call on a second stream, concurrently with this frame's sweep,
-        encoder, ConvLSTM and decoder, and the next call (same ``frame_id``) finds them ready.  Results are bit-identical to the
-        calls without look-ahead (same kernels, same inputs); a next call with another ``frame_id`` simply recomputes.
+        Look-ahead (one sequence per engine), for callers that already know the NEXT call's frame -- a pre-computed keyframe index, a
+        camera that is a frame ahead.  The stages of a frame that carry no recurrent state are computed for the next frame during
+        THIS call, on a second stream, concurrently with this frame's ConvLSTM and decoder:
+        * ``next_reference_image`` + ``next_frame_id``: its MnasNet + FPN features;
+        * additionally ``next_reference_pose``, ``next_measurement_poses`` and ``next_measurement_ids`` (every one of them this call's
+          ``frame_id`` or a cached keyframe): its plane sweep and cost-volume encoder as well.
+        The next call (same ``frame_id``; same poses / measurement ids for the second level) finds them ready; anything else is simply
+        recomputed.  Same kernels on the same inputs: results are bit-identical to calls without look-ahead.
         Returns the full-resolution depth [S,H,W] (a static buffer that the next call overwrites: clone to keep).
         """
         n_meas = len(measurement_poses)
@@ -750,73 +816,121 @@ class DepthEngine:
         s = self._static
         if tuple(reference_image.shape) != (self.sequences, 3, self.height, self.width):
             raise ValueError(f"image must be [{self.sequences},3,{self.height},{self.width}], got {tuple(reference_image.shape)}")
-        # resolve every measurement frame BEFORE anything is inserted into the cache: an insertion may evict the least
-        # recently used entry, which could be a frame this very call still needs
-        fresh = []
-        for i in range(n_meas):
-            img = measurement_images[i] if measurement_images is not None else None
-            mid = measurement_ids[i]
-            if self.cache_features and mid is not None and mid in self._feature_cache:
-                self._feature_cache.move_to_end(mid)
-                half = self._feature_cache[mid]
-            elif img is None:
-                raise ValueError(f"measurement frame {mid} is not cached and no image was given")
-            else:
-                half = self._features(img)[0].contiguous()
-                fresh.append((mid, half))
-            s["meas_feat"][i].copy_(half)
-        for mid, half in fresh:
-            self._remember(mid, half)
-        # buffer set of this frame; feature look-ahead (one sequence, destination-passing body)
         parity = self._parity if self.direct else 0
-        prefetched = bool(self.direct and frame_id is not None and self._prefetched == (frame_id, parity))
-        prefetch = bool(self.direct and next_reference_image is not None)
         sets = self._direct_buffers.get("sets")
+        cur = sets[parity] if self.direct else None
+
+        # ---- what the previous call prepared for this frame: 0 nothing, 1 its reference features, 2 also its sweep + encoder ----
+        have, ready = 0, self._prefetched
+        if self.direct and frame_id is not None and ready is not None and ready["frame_id"] == frame_id and ready["parity"] == parity:
+            have = 1
+            if ready["level"] == 2 and ready["measurement_ids"] == list(measurement_ids) and len(ready["measurement_poses"]) == n_meas and \
+                    torch.equal(ready["pose"], _pose_algebra.to_host(reference_pose).reshape(-1, 4, 4)) and \
+                    all(torch.equal(a, _pose_algebra.to_host(b).reshape(-1, 4, 4)) for a, b in zip(ready["measurement_poses"], measurement_poses)):
+                have = 2
+        if have >= 1 and self.cache_features:
+            self._remember(frame_id, cur["enc_cat"][0][:, :32].clone())     # (the next frame may use this one as a measurement frame)
+
+        # ---- this frame's measurement features (not needed when its sweep already ran) ----
+        if have < 2:
+            # resolve every measurement frame BEFORE anything is inserted into the cache: an insertion may evict the least
+            # recently used entry, which could be a frame this very call still needs
+            fresh, target = [], (cur["meas_feat"] if self.direct else s["meas_feat"])
+            for i in range(n_meas):
+                img = measurement_images[i] if measurement_images is not None else None
+                mid = measurement_ids[i]
+                if self.cache_features and mid is not None and mid in self._feature_cache:
+                    self._feature_cache.move_to_end(mid)
+                    half = self._feature_cache[mid]
+                elif img is None:
+                    raise ValueError(f"measurement frame {mid} is not cached and no image was given")
+                else:
+                    half = self._features(img)[0].contiguous()
+                    fresh.append((mid, half))
+                target[i].copy_(half)
+            for mid, half in fresh:
+                self._remember(mid, half)
+
+        # ---- how much of the next frame this call computes ----
+        give, next_frame, n_meas_next = 0, None, 0
+        if self.direct and next_reference_image is not None:
+            if tuple(next_reference_image.shape) != tuple(reference_image.shape):
+                raise ValueError("next_reference_image must have the reference image's shape")
+            give = 1
+            if next_reference_pose is not None and next_measurement_poses is not None and next_measurement_ids is not None and \
+                    next_frame_id is not None and self.pose_algebra == "reference" and self.cache_features and \
+                    1 <= len(next_measurement_poses) <= _MAX_MEAS and len(next_measurement_ids) == len(next_measurement_poses) and \
+                    all(m is not None and (m in self._feature_cache or (m == frame_id and have >= 1)) for m in next_measurement_ids):
+                give, n_meas_next = 2, len(next_measurement_poses)
+                self._allocate_static(n_meas_next)
+                next_frame = (next_reference_pose, list(next_measurement_poses))
+                for i, mid in enumerate(next_measurement_ids):
+                    sets[1 - parity]["meas_feat"][i].copy_(self._feature_cache[mid])
         if self.direct:
-            if not prefetched:
-                sets[parity]["full_in"][:, 33:36].copy_(reference_image)
-            if prefetch:
-                if tuple(next_reference_image.shape) != tuple(reference_image.shape):
-                    raise ValueError("next_reference_image must have the reference image's shape")
+            if have < 1:
+                cur["full_in"][:, 33:36].copy_(reference_image)
+            if give >= 1:
                 sets[1 - parity]["full_in"][:, 33:36].copy_(next_reference_image)
-            s["image"], s["ref_half"] = sets[parity]["full_in"][:, 33:36], sets[parity]["enc_cat"][0][:, :32]
+            s["image"], s["ref_half"] = cur["full_in"][:, 33:36], cur["enc_cat"][0][:, :32]
         else:
             s["image"].copy_(reference_image)
-        committed_pose, sweep_variant = self._upload_frame_parameters(n_meas, reference_pose, measurement_poses, full_K)
+        committed_pose, sweep_variant, next_variant = self._upload_frame_parameters(n_meas, reference_pose, measurement_poses, full_K, index=parity,
+                                                                                    own_sweep=have < 2, next_frame=next_frame)
+        if have == 2:
+            sweep_variant = ready["sweep_variant"]
+        self.sweep_variant_counts[sweep_variant] = self.sweep_variant_counts.get(sweep_variant, 0) + 1
 
         # S > 1: always the previous-state path (see the class docstring); S == 1: the reference's two frame kinds
         kind = (n_meas, (self.has_previous or self.sequences > 1) and self.is_fusionnet)
-        key = kind + (sweep_variant, parity, prefetched, prefetch)
-        self.sweep_variant_counts[sweep_variant] = self.sweep_variant_counts.get(sweep_variant, 0) + 1
+
+        def graph_key(par, hv, gv, variant, variant_next):
+            # (stages that do not run in this graph do not tell graphs apart)
+            return (n_meas if hv < 2 else 0, kind[1], variant if hv < 2 else 0, par, hv, gv, n_meas_next if gv == 2 else 0, variant_next if gv == 2 else 0)
+
+        key = graph_key(parity, have, give, sweep_variant, next_variant)
+        body = (n_meas, kind[1], sweep_variant, parity, have, give, n_meas_next, next_variant or 0)
         if not self.use_graphs:
-            self._frame_body(*key)
+            self._frame_body(*body)
         elif kind not in self._warm:
             # first occurrence of this kind of frame: run eagerly (lets MIOpen pick its solvers, times the fusion plans); state
             # buffers are updated by the body, so this is a real frame, not a throw-away
-            self._frame_body(*key)
+            self._frame_body(*body)
             self._warm.add(kind)
         else:
             if key not in self._graphs:
-                # Capture records launches, it executes nothing -- so everything this kind of frame may need later is captured now,
-                # while the caller is still warming up: both sweep configurations, both buffer sets and, with look-ahead, the
-                # steady-state pattern (own features prefetched, next frame's being prefetched).  A later frame whose geometry asks
-                # for the other configuration finds its graph ready instead of paying ~0.1 s of capture in the middle of a run.
-                variants = {sweep_variant} | ({2, 3} if sweep_variant in (2, 3) else set())
-                patterns = {(prefetched, prefetch)} | ({(True, True)} if prefetch else set())
-                for v in sorted(variants):
+                # Capture records launches, it executes nothing -- so what this kind of frame will need later is captured now, while the
+                # caller is still warming up: with look-ahead the steady-state pattern (this frame's share prefetched, the next frame's
+                # being prefetched) for both buffer sets and both sweep configurations, without it both configurations.  A later frame
+                # whose geometry asks for the other configuration finds its graph ready instead of paying ~0.1 s of capture mid-run.
+                self._graphs[key] = self._capture(body)
+                if give:
+                    choices = (2, 3) if next_variant in (2, 3) or sweep_variant in (2, 3) else (sweep_variant,)
+                    for par in (0, 1):
+                        for v in (choices if give < 2 else (0,)):
+                            for vn in (choices if give == 2 else (0,)):
+                                k = graph_key(par, give, give, v, vn)
+                                if k not in self._graphs:
+                                    self._graphs[k] = self._capture((n_meas, kind[1], v, par, give, give, n_meas_next, vn))
+                elif sweep_variant in (2, 3) and have < 2:
                     for par in ((0, 1) if self.direct else (0,)):
-                        for pattern in sorted(patterns):
-                            k = kind + (v, par) + pattern
+                        for v in (2, 3):
+                            k = graph_key(par, have, 0, v, 0)
                             if k not in self._graphs:
-                                self._graphs[k] = self._capture(k)
+                                self._graphs[k] = self._capture((n_meas, kind[1], v, par, have, 0, 0, 0))
             self._graphs[key].replay()
         self._prev_pose_host = committed_pose
         self._no_previous[:] = False
         self.has_previous = True
         if self.direct:
-            self._prefetched = (next_frame_id, 1 - parity) if prefetch and next_frame_id is not None else None
+            self._prefetched = None
+            if give >= 1 and next_frame_id is not None:
+                self._prefetched = dict(frame_id=next_frame_id, parity=1 - parity, level=give, sweep_variant=next_variant)
+                if give == 2:
+                    to_host = _pose_algebra.to_host
+                    self._prefetched.update(pose=to_host(next_reference_pose).reshape(-1, 4, 4).clone(), measurement_ids=list(next_measurement_ids),
+                                            measurement_poses=[to_host(p).reshape(-1, 4, 4).clone() for p in next_measurement_poses])
             self._parity = 1 - parity
-        if self.cache_features and frame_id is not None:
+        if self.cache_features and frame_id is not None and have < 1:
             self._remember(frame_id, s["ref_half"].clone())
         return s["depth"]
 

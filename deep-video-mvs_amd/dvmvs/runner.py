@@ -49,7 +49,7 @@ def _preprocessor(scene, raw_image):
 
 
 def _run_frame(engine, scene, timer, device, reference_index, measurement_indices, evaluate, images=None, next_reference_index=None,
-               prepared=None):
+               prepared=None, next_measurement_indices=None):
     """``next_reference_index``: the reference frame of the NEXT call when it is known (offline runs): its image is pre-processed now and
     handed to the engine as look-ahead (DepthEngine.step: its features are computed concurrently with this frame); ``prepared``
     (a dict) carries the pre-processed device image to that next call."""
@@ -75,9 +75,15 @@ def _run_frame(engine, scene, timer, device, reference_index, measurement_indice
             meas_images.append(_to_device(pre.apply_rgb(raw_m, SCALE_RGB, MEAN_RGB, STD_RGB), device))
         meas_poses.append(torch.from_numpy(scene.poses[m]).float().unsqueeze(0))
     timer.record_start_time()
+    ahead = {}
+    if next_image is not None:
+        ahead = dict(next_reference_image=next_image, next_frame_id=next_reference_index)
+        if next_measurement_indices is not None:      # ... and its poses: the engine then also runs its sweep + encoder a frame ahead
+            ahead.update(next_reference_pose=torch.from_numpy(scene.poses[next_reference_index]).float().unsqueeze(0),
+                         next_measurement_poses=[torch.from_numpy(scene.poses[m]).float().unsqueeze(0) for m in next_measurement_indices],
+                         next_measurement_ids=list(next_measurement_indices))
     depth = engine.step(ref_image, ref_pose, meas_images, meas_poses, full_K, frame_id=reference_index,
-                        measurement_ids=list(measurement_indices), next_reference_image=next_image,
-                        next_frame_id=next_reference_index if next_image is not None else None)
+                        measurement_ids=list(measurement_indices), **ahead)
     timer.record_end_time_and_elapsed_time()
     prediction = depth.cpu().numpy().squeeze()
     reference_depth = pre.apply_depth(scene.depth(reference_index)) if evaluate and scene.depth_names else None
@@ -103,9 +109,10 @@ def predict_offline(engine: DepthEngine, scene_folder, keyframe_index_file, eval
             continue
         indices = [position[name] for name in line.split(" ")]
         upcoming = next((l for l in lines[n + 1:] if l != "TRACKING LOST"), None)
-        next_reference = position[upcoming.split(" ")[0]] if upcoming is not None else None
+        next_indices = [position[name] for name in upcoming.split(" ")] if upcoming is not None else None
         prediction, reference_depth = _run_frame(engine, scene, timer, device, indices[0], indices[1:], evaluate,
-                                                 next_reference_index=next_reference, prepared=prepared)
+                                                 next_reference_index=next_indices[0] if next_indices else None, prepared=prepared,
+                                                 next_measurement_indices=next_indices[1:] if next_indices else None)
         predictions.append(prediction)
         reference_depths.append(reference_depth)
     return predictions, (reference_depths if evaluate and scene.depth_names else None), timer

@@ -343,39 +343,50 @@ def test_lockstep_sequences_equal_single_sequence_runs(hip_device):
             fresh[s] = False
 
 
-def test_feature_lookahead_is_bit_identical(hip_device):
-    """DepthEngine.step(next_reference_image=...): the next keyframe's MnasNet + FPN features are computed during the current step on a
-    second stream, concurrently with the current frame's sweep .. decoder (tools/frame_stage_probe.py: 20 % less time per frame).
-    Same kernels on the same inputs: every depth map must equal, bit for bit, the one an engine without look-ahead produces --
-    through eager frames and replayed graphs, both buffer sets, a tracking loss, and an announced next frame that does not come."""
+def test_lookahead_is_bit_identical(hip_device):
+    """DepthEngine.step(next_reference_image=..., [next_reference_pose=..., next_measurement_poses=..., next_measurement_ids=...]): the
+    next keyframe's MnasNet + FPN features -- and, with its poses, its plane sweep and encoder -- are computed during the current step
+    on a second stream, concurrently with the current frame's ConvLSTM and decoder (tools/frame_stage_probe.py).  Same kernels on the
+    same inputs: every depth map and the recurrent state must equal, bit for bit, what an engine without look-ahead produces --
+    through eager frames and replayed graphs, both buffer sets, both sweep configurations, a tracking loss, and an announced next
+    frame that does not come."""
     dev = hip_device
-    mods, ahead = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
+    mods, shallow = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
+    _, deep = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
     _, plain = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
     fullK = syn.full_K()
     lines = syn.keyframe_index_lines(2)
-    # (index line or None = tracking loss, announce the next frame?, does the announced frame actually come next?)
+    # (index line or None = tracking loss, announce the next frame?: True, False, or "wrong" = another frame than the one that comes)
     schedule = [(0, True), (1, True), (2, True), (3, True), (4, False), (5, True), (None, None), (117, True), (118, True), (119, "wrong"),
-                (200, True), (201, True), (202, True), (203, False)]
+                (200, True), (201, True), (202, True), (203, True), (204, False)]
     frames = [(None if i is None else lines[i], flag) for i, flag in schedule]
-    used = 0
+    used = {"shallow": 0, "deep": 0}
     for n, (item, announce) in enumerate(frames):
         if item is None:
-            ahead.reset()
-            plain.reset()
+            for e in (shallow, deep, plain):
+                e.reset()
             continue
         r, ms = item
         args = (syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK)
         upcoming = next((f[0] for f in frames[n + 1:] if f[0] is not None), None)
-        kw = {}
+        kw1, kw2 = {}, {}
         if announce and upcoming is not None:
-            nxt = upcoming[0] if announce is True else upcoming[0] + 1          # "wrong": another frame is announced than the one that comes
-            kw = dict(next_reference_image=syn.e2e_image(nxt).to(dev), next_frame_id=nxt)
-        was_ready = ahead._prefetched == (r, ahead._parity)
-        a = ahead.step(*args, frame_id=r, measurement_ids=list(ms), **kw).clone()
-        b = plain.step(*args, frame_id=r, measurement_ids=list(ms)).clone()
-        used += was_ready
-        print(f"step {n} (reference frame {r}): features prefetched {was_ready}, look-ahead requested {bool(kw)}, identical {torch.equal(a, b)}")
-        assert torch.equal(a, b), n
-        assert torch.equal(ahead._static["h"], plain._static["h"]) and torch.equal(ahead._static["c"], plain._static["c"]), n
-    assert used >= 7          # the prefetched features were actually used
-    assert any(k[5] and k[4] for k in ahead._graphs)      # ... through replayed graphs of the steady-state pattern
+            nr, nms = upcoming
+            nxt = nr if announce is True else nr + 1
+            kw1 = dict(next_reference_image=syn.e2e_image(nxt).to(dev), next_frame_id=nxt)
+            kw2 = dict(kw1, next_reference_pose=syn.pose(nxt), next_measurement_poses=[syn.pose(i) for i in nms], next_measurement_ids=list(nms))
+        ready = {name: (e._prefetched["level"] if e._prefetched and e._prefetched["frame_id"] == r else 0) for name, e in (("shallow", shallow), ("deep", deep))}
+        a = shallow.step(*args, frame_id=r, measurement_ids=list(ms), **kw1).clone()
+        b = deep.step(*args, frame_id=r, measurement_ids=list(ms), **kw2).clone()
+        c = plain.step(*args, frame_id=r, measurement_ids=list(ms)).clone()
+        for name in used:
+            used[name] += ready[name] > 0
+        print(f"step {n} (reference frame {r}): prepared by the previous step: shallow {ready['shallow']}, deep {ready['deep']}; "
+              f"identical to the engine without look-ahead: {torch.equal(a, c)}, {torch.equal(b, c)}")
+        assert torch.equal(a, c) and torch.equal(b, c), n
+        for e in (shallow, deep):
+            assert torch.equal(e._static["h"], plain._static["h"]) and torch.equal(e._static["c"], plain._static["c"]), n
+    assert used["shallow"] >= 8 and used["deep"] >= 8          # the prepared stages were actually used ...
+    assert any(k[4] == 1 and k[5] == 1 for k in shallow._graphs)      # ... through replayed graphs of the steady-state patterns
+    assert any(k[4] == 2 and k[5] == 2 for k in deep._graphs)
+    assert deep.sweep_variant_counts == plain.sweep_variant_counts

@@ -66,7 +66,7 @@ class _StubEngine:
     announced = None
 
     def step(self, image, pose, measurement_images, measurement_poses, full_K, frame_id=None, measurement_ids=None,
-             next_reference_image=None, next_frame_id=None):
+             next_reference_image=None, next_frame_id=None, next_reference_pose=None, next_measurement_poses=None, next_measurement_ids=None):
         assert tuple(image.shape) == (1, 3, 256, 320) and len(measurement_images) == len(measurement_poses) == 2
         # feature look-ahead of the offline runner: the frame announced by the previous call is the one that comes, with its image
         if self.announced is not None:

@@ -42,7 +42,13 @@ def main():
         d = engine._direct_buffers
         cur, alt = d["sets"][0], d["sets"][1]
         alt["full_in"][:, 33:36].copy_(syn.e2e_image(12).to(dev))
-        key = (2, True, 2)
+        # the other buffer set gets a copy of this frame's sweep parameters and measurement features (timing only)
+        params, off = engine._static["params"], engine._param_offsets
+        for name in ("Hm", "kt", "sweep_items"):
+            (o0, n), (o1, _) = off[name], off[name + "1"]
+            params[o1:o1 + n].copy_(params[o0:o0 + n])
+        for a, b in zip(alt["meas_feat"], cur["meas_feat"]):
+            a.copy_(b)
 
         def capture(fn):
             g = torch.cuda.CUDAGraph()
@@ -52,33 +58,35 @@ def main():
 
         side = torch.cuda.Stream()
 
-        def both():
-            main_stream = torch.cuda.current_stream()
-            side.wait_stream(main_stream)
-            with torch.cuda.stream(side):
-                engine._reference_features_direct(alt)
-            engine._after_features_direct(*key, cur)
-            main_stream.wait_stream(side)
+        def overlapped(ahead, own):
+            def body():
+                main_stream = torch.cuda.current_stream()
+                side.wait_stream(main_stream)
+                with torch.cuda.stream(side):
+                    ahead()
+                own()
+                main_stream.wait_stream(side)
+            return body
 
-        g_feat = capture(lambda: engine._reference_features_direct(alt))
-        g_rest = capture(lambda: engine._after_features_direct(*key, cur))
-        g_whole = capture(lambda: engine._frame_body_direct(*key))
-        g_both = capture(both)
-        t_feat, t_rest, t_whole, t_both = timed(g_feat), timed(g_rest), timed(g_whole), timed(g_both)
-        print(f"feature extraction (MnasNet + FPN): {t_feat:8.1f} us")
-        print(f"sweep .. decoder:                   {t_rest:8.1f} us")
-        print(f"whole frame, one stream:            {t_whole:8.1f} us   (sum of the halves {t_feat + t_rest:.1f})")
-        print(f"next frame's features on a 2nd stream, concurrently with sweep .. decoder: {t_both:8.1f} us   "
-              f"({100 * (1 - t_both / t_whole):.1f} % less than the one-stream frame)")
-        # sanity: the concurrent features equal the serial ones
-        g_feat.replay()
-        torch.cuda.synchronize()
-        serial = [c[:, :32].clone() for c in alt["enc_cat"]]
-        for c in alt["enc_cat"]:
-            c[:, :32].zero_()
-        g_both.replay()
-        torch.cuda.synchronize()
-        print("concurrent features bit-identical to serial:", all(torch.equal(a[:, :32], b) for a, b in zip(alt["enc_cat"], serial)))
+        feat = lambda b: (lambda: engine._reference_features_direct(b))
+        enc = lambda b: (lambda: engine._sweep_encoder_direct(b, 2, 2))
+        dec = lambda b: (lambda: engine._lstm_decoder_direct(b, True))
+        both = lambda f, g: (lambda: (f(), g()))
+        rows = [
+            ("A  feature extraction (MnasNet + FPN)", feat(alt)),
+            ("B  plane sweep + encoder", enc(alt)),
+            ("C  re-projection + ConvLSTM + decoder", dec(cur)),
+            ("A + B + C on one stream (the frame of rounds 1-3)", both(both(feat(cur), enc(cur)), dec(cur))),
+            ("look-ahead 1:  A(next) on a 2nd stream  ||  B + C", overlapped(feat(alt), both(enc(cur), dec(cur)))),
+            ("look-ahead 2:  A(next) + B(next) on a 2nd stream  ||  C", overlapped(both(feat(alt), enc(alt)), dec(cur))),
+        ]
+        times = {}
+        for name, fn in rows:
+            times[name] = timed(capture(fn))
+            print(f"{name:62s} {times[name]:8.1f} us")
+        whole = times[rows[3][0]]
+        for name in (rows[4][0], rows[5][0]):
+            print(f"{name}: {100 * (1 - times[name] / whole):.1f} % less than the one-stream frame")
 
 
 if __name__ == "__main__":
