@@ -580,7 +580,17 @@ def main():
     # poses and intrinsics stay on the host: that is where they come from and where the engine evaluates the frame's small
     # matrices (dvmvs.pose_algebra, "reference" mode) before its single per-frame upload
 
+    host_seconds = [0.0, 0]      # time the host spends inside engine.step (pose algebra, sweep plan, upload, graph launch), and calls
+
     def run_frame(k):
+        t_host = time.perf_counter()
+        try:
+            return run_frame_inner(k)
+        finally:
+            host_seconds[0] += time.perf_counter() - t_host
+            host_seconds[1] += 1
+
+    def run_frame_inner(k):
         ids = [k - 1 - i for i in range(M)]
         meas_images = None if not args.no_feature_cache else [images[i % n_images] for i in ids]
         level = 0 if args.no_feature_cache else args.lookahead
@@ -599,7 +609,14 @@ def main():
                 engine._half_features(k, images[k % n_images])
         marker = torch.ones(4096, device=device)
         mark = (lambda: (marker.cumsum(0), torch.cuda.synchronize())) if args.mark_region else None
-        elapsed = timed_region(lambda i: run_frame(M + i), args.warmup, args.steps, world, device, before=mark, after=mark)
+
+        def region_start():      # (host time is counted over the timed steps only: warm-up steps run eagerly and capture graphs)
+            host_seconds[0], host_seconds[1] = 0.0, 0
+            if mark is not None:
+                mark()
+
+        elapsed = timed_region(lambda i: run_frame(M + i), args.warmup, args.steps, world, device, before=region_start, after=mark)
+        host_ms = 1e3 * host_seconds[0] / max(host_seconds[1], 1)
     depth_mean = float(engine._static["depth"].mean())
     assert np.isfinite(depth_mean), "non-finite depth"
 
@@ -657,6 +674,8 @@ def main():
             "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            # host time per step inside engine.step (asynchronous to the GPU: it matters only where it exceeds ms_per_step)
+            "host_ms_per_step": host_ms,
             "config": {"workload": "fusionnet inference, one synthetic-image sequence per GPU on the sample scene's keyframe poses, "
                                    f"320x256, 64 planes, M={M} measurement frames, batch 1 (BASELINE.json configs[2]; configs[3] at N>1)",
                        "sequences_per_gpu": 1, "hip_graphs": not args.no_graphs, "bn_folded": not args.no_fold_bn,

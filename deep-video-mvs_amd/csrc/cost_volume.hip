@@ -109,7 +109,7 @@ int launch_sweep_default(const CostVolumeArgs& a, hipStream_t stream);
 int launch_sweep_wide(const CostVolumeArgs& a, hipStream_t stream);
 size_t sweep_work_list_words(int B, int H, int W, int D);
 int sweep_work_list_host(int configuration, const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,
-                         unsigned int* items, size_t capacity_words);
+                         unsigned int* items, size_t capacity_words, long long* stats);
 void sweep_plan_stats_host(int configuration, const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,
                            long long* stats);
 int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream);
@@ -154,7 +154,8 @@ extern "C" int dvmvs_sweep_work_list(const float* Hm_host, const float* kt_host,
   if (M > DVMVS_MAX_MEASUREMENTS || D > DVMVS_MAX_DEPTH_LEVELS) return DVMVS_EUNSUPPORTED;
   if (!(min_depth > 0.0) || !(max_depth > 0.0) || (configuration != 0 && configuration != 1)) return DVMVS_EINVAL;
   const double inv_base = 1.0 / max_depth, inv_step = D > 1 ? (1.0 / min_depth - 1.0 / max_depth) / (D - 1) : 0.0;
-  return dvmvs::sweep_work_list_host(configuration, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, work_list_host, work_list_bytes / sizeof(unsigned int));
+  return dvmvs::sweep_work_list_host(configuration, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, work_list_host, work_list_bytes / sizeof(unsigned int),
+                                     nullptr);
 }
 
 extern "C" int dvmvs_cost_volume_planned_fwd(const float* image1, const float* const* image2s, const float* Hm, const float* kt,
@@ -204,15 +205,45 @@ extern "C" int dvmvs_sweep_plan_stats(const float* Hm_host, const float* kt_host
   return 0;
 }
 
-// Which configuration of the LDS-tiled sweep for this keyframe pair: a linear cost model over the plan statistics of both
-// configurations, fitted to per-pair timings of both on all 286 keyframe pairs of the sample scene (tools/sweep_select_fit.py;
-// profiles/r04_sweep_select_fit.md).  Deterministic in the matrices (IEEE fp32 / integer arithmetic only).
+// Which configuration of the LDS-tiled sweep for this keyframe pair.  An easy geometry -- nothing queued for the second pass and no
+// workgroup with more than three staged runs in the default configuration, two thirds of the sample scene's pairs -- keeps the default
+// one (35 us against 41); otherwise a linear cost model over the plan statistics of both configurations decides, fitted to per-pair
+// timings of both on all 285 keyframe pairs of the sample scene (tools/sweep_select_fit.py; profiles/r04_sweep_select_fit.md).
+// Deterministic in the matrices (IEEE fp32 / integer arithmetic only).
+namespace dvmvs {
+inline bool sweep_is_easy(const long long* default_stats) { return default_stats[4] == 0 && default_stats[6] <= 3; }
+}
+
 extern "C" int dvmvs_sweep_select_variant(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
                                           double min_depth, double max_depth) {
   long long d[8], w[8];
   int rc = dvmvs_sweep_plan_stats(Hm_host, kt_host, B, M, H, W, D, min_depth, max_depth, 0, d);
   if (rc != 0) return rc;
+  if (dvmvs::sweep_is_easy(d)) return 2;
   rc = dvmvs_sweep_plan_stats(Hm_host, kt_host, B, M, H, W, D, min_depth, max_depth, 1, w);
   if (rc != 0) return rc;
   return dvmvs::sweep_model_us(0, d, B, H, W, D) <= dvmvs::sweep_model_us(1, w, B, H, W, D) ? 2 : 3;
+}
+
+// dvmvs_sweep_select_variant + dvmvs_sweep_work_list in ONE walk over the (tile, chunk) pairs (the per-frame host cost of the sweep
+// plan: ~0.15 ms for an easy pair, ~0.5 ms where both configurations have to be planned): decides the configuration (or takes
+// `variant` = 2 / 3 as given; 0 = decide), leaves that configuration's work list in `work_list_host` and returns the variant.
+extern "C" int dvmvs_sweep_plan(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
+                                int variant, unsigned int* work_list_host, size_t work_list_bytes) {
+  if (!Hm_host || !kt_host || !work_list_host || B <= 0 || M <= 0 || H <= 0 || W <= 0 || D <= 0) return DVMVS_EINVAL;
+  if (M > DVMVS_MAX_MEASUREMENTS || D > DVMVS_MAX_DEPTH_LEVELS) return DVMVS_EUNSUPPORTED;
+  if (!(min_depth > 0.0) || !(max_depth > 0.0) || (variant != 0 && variant != 2 && variant != 3)) return DVMVS_EINVAL;
+  const double inv_base = 1.0 / max_depth, inv_step = D > 1 ? (1.0 / min_depth - 1.0 / max_depth) / (D - 1) : 0.0;
+  const size_t words = work_list_bytes / sizeof(unsigned int);
+  long long d[8], w[8];
+  int rc = 0;
+  if (variant != 3) {
+    rc = dvmvs::sweep_work_list_host(0, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, work_list_host, words, d);
+    if (rc < 0) return rc;
+    if (variant == 2 || dvmvs::sweep_is_easy(d)) return 2;
+    dvmvs::sweep_plan_stats_host(1, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, w);
+    if (dvmvs::sweep_model_us(0, d, B, H, W, D) <= dvmvs::sweep_model_us(1, w, B, H, W, D)) return 2;
+  }
+  rc = dvmvs::sweep_work_list_host(1, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, work_list_host, words, nullptr);
+  return rc < 0 ? rc : 3;
 }

@@ -985,17 +985,29 @@ struct HostTilePlanner {
           int len = len0;
           for (int i = 0; i < candidate; ++i) len = (len + 1) / 2 > MINSEG ? (len + 1) / 2 : MINSEG;
           if (len > len0) len = len0;
-          float lo_x = 0, hi_x = 0, lo_y = 0, hi_y = 0, top[2][2] = {{0, 0}, {0, 0}};
-          bool finite = true;
+          // the eight corners (4 tile corners x first / last plane of the run) in array form: the loops below vectorise (the chain of
+          // dependent fp32 divisions of one corner after the other was most of the host cost of a plan)
+          float X[8], Y[8], den[8], ux[8], uy[8];
           for (int corner = 0; corner < 8; ++corner) {
             const float* k = ktd[m][(corner & 4) ? lo + len - 1 : lo];
-            float ux, uy, denom;
-            host_sweep_position(ray[m][corner & 3], k[0], k[1], k[2], sc, &ux, &uy, &denom);
-            finite = finite && (ux > -1e6f) && (ux < 1e6f) && (uy > -1e6f) && (uy < 1e6f) && (denom > 1e-6f);
-            if (corner < 2) { top[corner][0] = ux; top[corner][1] = uy; }
-            if (corner == 0) { lo_x = hi_x = ux; lo_y = hi_y = uy; }
-            else { lo_x = fminf(lo_x, ux); hi_x = fmaxf(hi_x, ux); lo_y = fminf(lo_y, uy); hi_y = fmaxf(hi_y, uy); }
+            const SweepRay& r = ray[m][corner & 3];
+            X[corner] = r.X0 + k[0];
+            Y[corner] = r.Y0 + k[1];
+            den[corner] = (r.Z0 + k[2]) + 1e-8f;
           }
+          for (int corner = 0; corner < 8; ++corner) {
+            const float u = X[corner] / den[corner], v = Y[corner] / den[corner];
+            ux[corner] = ((((u - sc.wn) / sc.wn) + 1.0f) * 0.5f) * sc.Wm1;
+            uy[corner] = ((((v - sc.hn) / sc.hn) + 1.0f) * 0.5f) * sc.Hm1;
+          }
+          float lo_x = ux[0], hi_x = ux[0], lo_y = uy[0], hi_y = uy[0];
+          bool finite = true;
+          for (int corner = 0; corner < 8; ++corner) {
+            finite = finite && (ux[corner] > -1e6f) && (ux[corner] < 1e6f) && (uy[corner] > -1e6f) && (uy[corner] < 1e6f) && (den[corner] > 1e-6f);
+            lo_x = fminf(lo_x, ux[corner]); hi_x = fmaxf(hi_x, ux[corner]);
+            lo_y = fminf(lo_y, uy[corner]); hi_y = fmaxf(hi_y, uy[corner]);
+          }
+          const float top[2][2] = {{ux[0], uy[0]}, {ux[1], uy[1]}};
           const bool outside = (hi_x + 0.05f <= -1.0f) || (lo_x - 0.05f >= sc.Wf) || (hi_y + 0.05f <= -1.0f) || (lo_y - 0.05f >= sc.Hf);
           int state = 0, records = 0;
           if (finite && outside) state = 2;
@@ -1058,9 +1070,10 @@ void host_plan_stats(const float* Hm, const float* kt, int B, int M, int H, int 
 // gives their (tile, chunk) -- XCD locality and the CU mix stay as decode_work arranges them --, the extra pieces follow.
 constexpr int kMaxRunsPerItem = 3;
 
+// `stats` (optional, 8 entries as host_plan_stats fills them): the plan statistics of the uncut (tile, chunk) pairs, gathered in the same walk
 template <class Cfg>
 int host_build_work_list(const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,
-                         unsigned int* items, size_t capacity_words) {
+                         unsigned int* items, size_t capacity_words, long long* stats = nullptr) {
   constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH, chunks = (D + DP - 1) / DP;
   const int tiles = tiles_x * tiles_y;
@@ -1073,6 +1086,8 @@ int host_build_work_list(const float* Hm, const float* kt, int B, int M, int H, 
   planner.set_shape(M, H, W);
   size_t extra = positions;      // next free position behind the statically numbered ones
   int cached_b = -1, cached_chunk = -1;
+  if (stats)
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
   for (size_t block = 0; block < positions; ++block) {
     const SweepWork work = decode_work<Cfg::ORDER>(static_cast<int>(block), tiles, chunks, B);
     unsigned int* item = items + kWorkListHeaderWords + 2 * block;
@@ -1088,10 +1103,19 @@ int host_build_work_list(const float* Hm, const float* kt, int B, int M, int H, 
     int piece_lo[DP], piece_hi[DP], n_pieces = 0;
     int stack_lo[2 * DP], stack_hi[2 * DP], top = 0;
     stack_lo[0] = 0; stack_hi[0] = planes; top = 1;
+    bool whole = true;
     while (top > 0) {
       --top;
       const int lo = stack_lo[top], hi = stack_hi[top];
-      const bool cut = hi - lo > Cfg::MINSEG && planner.plan(lo, hi).staged_runs > kMaxRunsPerItem && extra + n_pieces < capacity;
+      const HostRunCounts n = planner.plan(lo, hi);
+      if (whole && stats) {      // (the first range popped is the whole chunk: its plan is the static numbering's)
+        stats[0] += n.staged_runs; stats[1] += n.staged_records; stats[2] += n.empty_runs; stats[3] += n.queued_runs; stats[4] += n.queued_planes;
+        if (n.queued_runs > 0) ++stats[5];
+        if (n.staged_runs > stats[6]) stats[6] = n.staged_runs;
+        if (n.queued_planes > stats[7]) stats[7] = n.queued_planes;
+      }
+      whole = false;
+      const bool cut = hi - lo > Cfg::MINSEG && n.staged_runs > kMaxRunsPerItem && extra + n_pieces < capacity;
       if (cut) {
         const int mid = lo + (hi - lo + 1) / 2;
         stack_lo[top] = mid; stack_hi[top] = hi; ++top;     // (popped second: pieces come out in plane order)
@@ -1203,9 +1227,9 @@ size_t sweep_work_list_words(int B, int H, int W, int D) {
 }
 
 int sweep_work_list_host(int configuration, const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,
-                         unsigned int* items, size_t capacity_words) {
-  if (configuration == 1) return host_build_work_list<SweepWide>(Hm, kt, B, M, H, W, D, inv_base, inv_step, items, capacity_words);
-  return host_build_work_list<SweepDefault>(Hm, kt, B, M, H, W, D, inv_base, inv_step, items, capacity_words);
+                         unsigned int* items, size_t capacity_words, long long* stats) {
+  if (configuration == 1) return host_build_work_list<SweepWide>(Hm, kt, B, M, H, W, D, inv_base, inv_step, items, capacity_words, stats);
+  return host_build_work_list<SweepDefault>(Hm, kt, B, M, H, W, D, inv_base, inv_step, items, capacity_words, stats);
 }
 
 void sweep_plan_stats_host(int configuration, const float* Hm, const float* kt, int B, int M, int H, int W, int D, double inv_base, double inv_step,

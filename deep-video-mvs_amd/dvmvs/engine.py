@@ -556,12 +556,15 @@ class DepthEngine:
             Hm, kt = _pose_algebra.sweep_matrices_host(ref_pose, meas_poses, half_K)
             put("Hm" + suffix, Hm)
             put("kt" + suffix, kt)
-            # which sweep configuration suits this keyframe geometry: decided here, on the host copies (one graph per configuration)
-            variant = _utils.sweep_variant((Hm, kt), self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth)
+            # which sweep configuration suits this keyframe geometry and its work list: decided here, on the host copies, in one walk
+            # over the (tile, chunk) pairs (one graph per configuration)
+            variant = _utils.COST_VOLUME_VARIANT
             if self.sweep_work_list:
                 o, n = self._param_offsets["sweep_items" + suffix]
-                _ops.sweep_work_list_host(Hm, kt, self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth, variant,
-                                          out=mirror.view(torch.int32)[o:o + n])
+                variant = _ops.sweep_plan_host(Hm, kt, self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth,
+                                               variant if variant in (2, 3) else 0, mirror.view(torch.int32)[o:o + n])
+            elif variant == 0:
+                variant = _utils.sweep_variant((Hm, kt), self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth)
             return variant
 
         sweep_variant = _utils.COST_VOLUME_VARIANT if own_sweep else None

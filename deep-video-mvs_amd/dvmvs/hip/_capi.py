@@ -17,7 +17,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVMVS_HIP_LIB", os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libdvmvs_hip.so")))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_MEASUREMENTS = 8
 MAX_DEPTH_LEVELS = 256
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
@@ -43,6 +43,7 @@ SIGNATURES = {
     "dvmvs_sweep_select_variant": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _c_dbl]),
     "dvmvs_sweep_work_list_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int]),
     "dvmvs_sweep_work_list": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _c_dbl, _c_int, _c_fp, ctypes.c_size_t]),
+    "dvmvs_sweep_plan": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _c_dbl, _c_int, _c_fp, ctypes.c_size_t]),
     "dvmvs_cost_volume_planned_fwd": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fp, _c_fp,
                                                _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                                _c_dbl, _c_dbl, _c_int, _c_int, _c_int, _c_fp, ctypes.c_size_t, _c_fp, _c_stream]),

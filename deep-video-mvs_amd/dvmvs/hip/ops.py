@@ -106,6 +106,21 @@ def sweep_work_list_host(Hm: Tensor, kt: Tensor, H: int, W: int, D: int, min_dep
     return out
 
 
+def sweep_plan_host(Hm: Tensor, kt: Tensor, H: int, W: int, D: int, min_depth: float, max_depth: float, variant: int, out: Tensor) -> int:
+    """Configuration choice (``variant`` 0; or 2 / 3 as given) and work list in one walk (dvmvs_sweep_plan): fills ``out`` (an int32 host
+    tensor of ``sweep_work_list_words``) and returns the variant to launch with."""
+    Hm, kt = Hm.contiguous(), kt.contiguous()
+    if Hm.device.type != "cpu" or Hm.dtype != torch.float32 or kt.dtype != torch.float32:
+        raise ValueError("sweep_plan_host needs the float32 HOST copies of the sweep matrices")
+    if out.device.type != "cpu" or out.dtype != torch.int32 or not out.is_contiguous() or out.numel() < sweep_work_list_words(Hm.shape[0], H, W, D):
+        raise ValueError("work list buffer must be a contiguous int32 host tensor of sweep_work_list_words entries")
+    chosen = _capi.lib().dvmvs_sweep_plan(Hm.data_ptr(), kt.data_ptr(), Hm.shape[0], Hm.shape[1], int(H), int(W), int(D), float(min_depth),
+                                          float(max_depth), int(variant), out.data_ptr(), out.numel() * 4)
+    if chosen < 0:
+        _capi.check(chosen, "dvmvs_sweep_plan")
+    return chosen
+
+
 def _work_list_ptr(work_list, image1, B, H, W, D):
     if work_list is None:
         return None

@@ -6,7 +6,8 @@
  * INTEGRATION.md).  Each entry point names the reference interface it replaces.
  *
  * Conventions (all entry points)
- *   - every pointer is a DEVICE pointer to contiguous fp32 data unless the comment says "host array";
+ *   - every pointer is a DEVICE pointer to contiguous fp32 data unless the comment says "host array" or the parameter is named
+ *     *_host (the host-side sweep plan: those functions make no HIP call at all);
  *   - tensors are NCHW, batch-major, exactly as the reference lays them out;
  *   - the caller (PyTorch) allocates and owns every buffer including outputs and workspaces;
  *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no entry point synchronises,
@@ -24,7 +25,11 @@
 extern "C" {
 #endif
 
-#define DVMVS_ABI_VERSION 3
+/* ABI 4 (round 4) = ABI 3 + additions, no signature of ABI 3 changed: variant 3 of dvmvs_cost_volume_fwd, the host-side sweep plan
+ * (dvmvs_sweep_plan_stats / _select_variant / _work_list / dvmvs_sweep_plan, dvmvs_cost_volume_planned_fwd), the bottleneck convolution
+ * (dvmvs_bottleneck_conv_*, dvmvs_partial_sums_bias_act_fwd, dvmvs_lstm_gates_partials_fwd) and two training gradients
+ * (dvmvs_upsample2x_bwd, dvmvs_depthwise_conv_bwd). */
+#define DVMVS_ABI_VERSION 4
 #define DVMVS_MAX_MEASUREMENTS 8      /* measurement frames fused per launch */
 #define DVMVS_MAX_DEPTH_LEVELS 256    /* sweep planes per launch */
 
@@ -132,6 +137,10 @@ int dvmvs_sweep_select_variant(const float* Hm_host, const float* kt_host, int B
  * volume is bit-reproducible.
  */
 size_t dvmvs_sweep_work_list_bytes(int B, int H, int W, int D);
+/* dvmvs_sweep_select_variant + dvmvs_sweep_work_list in one walk (what a frame loop calls once per keyframe): `variant` 0 = decide,
+ * 2 / 3 = as given; leaves the chosen configuration's work list in work_list_host and returns the variant (negative on error). */
+int dvmvs_sweep_plan(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
+                     int variant, unsigned int* work_list_host, size_t work_list_bytes);
 int dvmvs_sweep_work_list(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
                           double min_depth, double max_depth, int configuration, unsigned int* work_list_host, size_t work_list_bytes);
 int dvmvs_cost_volume_planned_fwd(const float* image1, const float* const* image2s, const float* Hm, const float* kt,

@@ -200,3 +200,27 @@ def test_work_list_rejects_bad_arguments():
     lib = _capi.lib()
     assert lib.dvmvs_sweep_work_list(Hm.data_ptr(), kt.data_ptr(), 1, 2, H, W, D, 0.25, 20.0, 0, None, 0) == -1
     assert lib.dvmvs_sweep_work_list_bytes(0, H, W, D) == 0
+
+
+def test_one_walk_plan_equals_selection_plus_work_list():
+    """dvmvs_sweep_plan (what the frame engine calls once per keyframe) = dvmvs_sweep_select_variant + dvmvs_sweep_work_list of the
+    chosen configuration, on every keyframe pair of the sample scene; a forced variant is respected."""
+    from dvmvs.hip import ops
+    out = torch.zeros(ops.sweep_work_list_words(1, H, W, D), dtype=torch.int32)
+    chosen = []
+    for line in range(0, len(syn.keyframe_index_lines(2)), 3):
+        Hm, kt = matrices(line)
+        v = ops.sweep_plan_host(Hm, kt, H, W, D, 0.25, 20.0, 0, out)
+        assert v == pose_algebra.sweep_variant_host(Hm, kt, H, W, D, 0.25, 20.0)
+        ref = ops.sweep_work_list_host(Hm, kt, H, W, D, 0.25, 20.0, v)
+        used = 2 + 2 * int(ref[0])
+        assert int(out[0]) == int(ref[0]) and torch.equal(out[:used], ref[:used]), line
+        chosen.append(v)
+    assert set(chosen) == {2, 3}
+    Hm, kt = matrices(0)
+    for forced in (2, 3):
+        assert ops.sweep_plan_host(Hm, kt, H, W, D, 0.25, 20.0, forced, out) == forced
+        ref = ops.sweep_work_list_host(Hm, kt, H, W, D, 0.25, 20.0, forced)
+        assert torch.equal(out[:2 + 2 * int(ref[0])], ref[:2 + 2 * int(ref[0])])
+    with pytest.raises(RuntimeError):
+        ops.sweep_plan_host(Hm, kt, H, W, D, 0.25, 20.0, 1, out)
