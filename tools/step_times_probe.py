@@ -1,0 +1,49 @@
+"""Probe (MI355X): wall time of every engine step of a short run (host clock at each step's return + one device sync at the end of
+every step), to see what the first steps after the graph captures cost.   python tools/step_times_probe.py [lookahead]"""
+import os
+import sys
+import time
+
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, ROOT)
+for p in (os.path.join(ROOT, "deep-video-mvs_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    level = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    from dvmvs.engine import DepthEngine
+    dev = torch.device("cuda:0")
+    engine = DepthEngine(*bench.build_modules(), device=dev)
+    M, n_images, total = 2, 32, 70
+    images, seq, full_K = bench.synthetic_sequence(0, n_images, total + M + 2, M)
+    images = [im.to(dev) for im in images]
+    rows = []
+    with torch.no_grad():
+        for k in range(M):
+            engine._half_features(k, images[k % n_images])
+        torch.cuda.synchronize()
+        for i in range(total):
+            k = M + i
+            ahead = {}
+            if level >= 1:
+                ahead = dict(next_reference_image=images[(k + 1) % n_images], next_frame_id=k + 1)
+            if level >= 2:
+                ahead.update(next_reference_pose=seq[k + 1][0], next_measurement_poses=seq[k + 1][1], next_measurement_ids=[k - j for j in range(M)])
+            t0 = time.perf_counter()
+            engine.step(images[k % n_images], seq[k][0], None, seq[k][1], full_K, frame_id=k, measurement_ids=[k - 1 - j for j in range(M)], **ahead)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            rows.append((i, 1e3 * (t1 - t0), 1e3 * (t2 - t0)))
+    print(f"look-ahead {level}: step, host ms inside step(), ms until the device is idle (a sync after every step: no overlap between steps)")
+    for i, h, d in rows:
+        print(f"  {i:3d}  {h:8.3f}  {d:8.3f}")
+
+
+if __name__ == "__main__":
+    main()
