@@ -663,7 +663,7 @@ def main():
             pass
         try:     # ... and the count a rocprofv3 kernel trace of this command's timed region recorded (profiles/, per round)
             import glob
-            region = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_timed_region.csv")))[-1]
+            region = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_timed_region*.csv")))[-1]
             last = open(region).read().strip().splitlines()[-1].split(",")
             launches_per_frame = dict(launches_per_frame or {}, profiled=float(last[5]) / float(last[7]), profiled_source=os.path.relpath(region, ROOT))
         except Exception:

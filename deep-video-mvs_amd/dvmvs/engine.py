@@ -356,6 +356,7 @@ class DepthEngine:
         self._static = None
         self._direct_buffers = {}
         self._warm = set()
+        self.step_clock = None
         self._parity, self._prefetched = 0, None      # buffer set of the next frame; (frame_id, buffer set) whose reference features are ready
         self._side_stream = torch.cuda.Stream(device=self.device)
         self.sweep_variant_counts = {}     # frames per sweep configuration (dvmvs_cost_volume_fwd's variant) since construction
@@ -838,6 +839,14 @@ class DepthEngine:
         if n_meas < 1 or n_meas > _MAX_MEAS:
             raise ValueError(f"need between 1 and {_MAX_MEAS} measurement frames")
         measurement_ids = measurement_ids or [None] * n_meas
+        clock = self.step_clock      # None, or a list that receives this step's host checkpoints (tools/step_times_probe.py)
+        if clock is not None:
+            import time
+            marks = [("enter", time.perf_counter())]
+            clock.append(marks)
+            mark = lambda name: marks.append((name, time.perf_counter()))
+        else:
+            mark = lambda name: None
         self._allocate_static(n_meas)
         s = self._static
         if tuple(reference_image.shape) != (self.sequences, 3, self.height, self.width):
@@ -900,8 +909,10 @@ class DepthEngine:
             s["image"], s["ref_half"] = cur["full_in"][:, 33:36], cur["enc_cat"][0][:, :32]
         else:
             s["image"].copy_(reference_image)
+        mark("inputs copied")
         committed_pose, sweep_variant, next_variant = self._upload_frame_parameters(n_meas, reference_pose, measurement_poses, full_K, index=parity,
                                                                                     own_sweep=have < 2, next_frame=next_frame)
+        mark("parameters planned + uploaded")
         if have == 2:
             sweep_variant = ready["sweep_variant"]
         self.sweep_variant_counts[sweep_variant] = self.sweep_variant_counts.get(sweep_variant, 0) + 1
@@ -944,6 +955,7 @@ class DepthEngine:
                             if k not in self._graphs:
                                 self._graphs[k] = self._capture((n_meas, kind[1], v, par, have, 0, 0, 0))
             self._graphs[key].replay()
+        mark("frame launched")
         self._prev_pose_host = committed_pose
         self._no_previous[:] = False
         self.has_previous = True
@@ -958,6 +970,7 @@ class DepthEngine:
             self._parity = 1 - parity
         if self.cache_features and frame_id is not None and have < 1:
             self._remember(frame_id, s["ref_half"])
+        mark("done")
         return s["depth"]
 
     def _capture(self, key):

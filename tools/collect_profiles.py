@@ -32,7 +32,11 @@ def counters(summary_path):
 def main():
     src, rnd = sys.argv[1], sys.argv[2]
     dst = os.path.join(ROOT, "profiles")
-    for name in ("bench_timed_region.csv", "bench_kernel_stats_whole_run.csv", "bench_under_rocprof.json"):
+    names = ["bench_timed_region.csv", "bench_kernel_stats_whole_run.csv", "bench_under_rocprof.json", "sweep_timed_lines_kernel_stats.csv",
+             "sweep_timed_lines.log", "train_timed_region.csv", "train_under_rocprof.json"]
+    for tag in ("lookahead2", "lookahead0"):
+        names += [f"bench_timed_region_{tag}.csv", f"bench_kernel_stats_whole_run_{tag}.csv", f"bench_under_rocprof_{tag}.json"]
+    for name in names:
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
     per_line = {}
