@@ -18,6 +18,8 @@
 // float4 -- so a wave streams them with fully coalesced 1 KB loads, 9 per 16 input channels, double-buffered against 180 MFMAs.
 // Splits are summed by the consumer in a fixed order (dvmvs_lstm_gates_partials_fwd, dvmvs_partial_sums_bias_act_fwd): the result
 // is bit-reproducible.  An fp32 MFMA is an fmaf chain over k (cdna guide, "exact f32"): no reduced precision anywhere.
+#include <stdlib.h>
+
 #include "dvmvs_device.h"
 
 namespace dvmvs {
@@ -41,7 +43,11 @@ struct BottleneckConvArgs {
 __host__ __device__ inline int bottleneck_splits(int B, int C_out, int C_in, int P) {
   const int n_tiles = (C_out + kBcRows - 1) / kBcRows, groups = C_in / 16, pixel_groups = P / kBcPixels;
   const int per_split = n_tiles * pixel_groups * B;
-  const int wanted = (kBcTargetWaves + per_split - 1) / per_split;
+  int target = kBcTargetWaves;
+#if defined(DVMVS_SWEEP_TUNING) && !defined(__HIP_DEVICE_COMPILE__)      // tools-only build: DVMVS_BC_WAVES overrides the wave target
+  if (const char* w = getenv("DVMVS_BC_WAVES")) target = atoi(w);
+#endif
+  const int wanted = (target + per_split - 1) / per_split;
   for (int d = 1; d <= groups; ++d)
     if (groups % d == 0 && d >= wanted) return d;
   return groups;
@@ -87,11 +93,9 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
   const int groups = a.cs / 16;
   const float4v DVMVS_GLOBAL* wp = reinterpret_cast<const float4v DVMVS_GLOBAL*>(as_global(a.packed)) +
                                    (static_cast<size_t>(n_tile) * (a.C_in / 16) + c0 / 16) * (9 * 64) + lane;
-  // Weights of CH groups of 16 input channels (9 float4 each) are requested in one straight-line burst and consumed group by group,
-  // so the wave waits once per burst for the first nine loads only (the compiler counts the newer ones: s_waitcnt vmcnt(9 * (CH - 1)))
-  // while the rest arrive behind 180 MFMAs per group.  The ConvLSTM layer has CH = 4 = all of a wave's weights (36 KB) in flight at
-  // once.  (Round 4, first form: a double buffer filled across loop iterations -- the compiler waits for ALL outstanding loads at a
-  // loop head, 42.8 us for the ConvLSTM layer = 45 % of the MFMA rate.)
+  // Weights of CH groups of 16 input channels (9 float4 each) are requested in one straight-line burst and consumed group by group:
+  // the wave waits for the first nine loads only (the compiler counts the newer ones: s_waitcnt vmcnt(9 * (CH - 1))) while the rest
+  // arrive behind 180 MFMAs per group.  The product launches CH = 1 (see launch_bottleneck_conv for the measurement).
   for (int g0 = 0; g0 < groups; g0 += CH) {
     float4v w[CH][9];
 #pragma unroll
@@ -172,9 +176,22 @@ int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
   if (lds > 64 * 1024) return DVMVS_EUNSUPPORTED;
   const dim3 grid((a.n_tiles + kBcWaves - 1) / kBcWaves, a.splits, a.B * (P / kBcPixels)), block(kBcWaves * 64);
   const int groups = a.cs / 16;
-  if (groups % 4 == 0) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 4>), grid, block, lds, stream, a);
-  else if (groups % 2 == 0) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 2>), grid, block, lds, stream, a);
-  else hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1>), grid, block, lds, stream, a);
+#ifdef DVMVS_SWEEP_TUNING      // tools-only build: DVMVS_BC_CH=1|2|4 forces the request burst (tools/lstm_conv_probe.py)
+  if (const char* ch = getenv("DVMVS_BC_CH")) {
+    const int c = atoi(ch);
+    if (c == 1 || groups % c == 0) {
+      if (c == 1) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1>), grid, block, lds, stream, a);
+      else if (c == 2) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 2>), grid, block, lds, stream, a);
+      else hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 4>), grid, block, lds, stream, a);
+      return launch_status();
+    }
+  }
+#endif
+  // CH = 1: one group's nine requests per burst.  Measured on the ConvLSTM layer (tools/bc_tuning_probe.sh, MI355X): CH 1 / 2 / 4 =
+  // 39.8 / 40.8 / 43.7 us at 16 splits, 50-53 us at 8 splits, 43-44 us at 32 -- the kernel is not waiting for its weights (two waves
+  // per SIMD cover each other's requests); it runs at ~48 % of the fp32 MFMA rate whatever the burst (PMC: MFMA pipe busy 50 % of the
+  // kernel, LDS pipe 25 %, profiles/r04_bottleneck_conv_pmc.txt).
+  hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1>), grid, block, lds, stream, a);
   return launch_status();
 }
 
