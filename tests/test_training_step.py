@@ -164,7 +164,7 @@ def test_training_step_at_the_config5_size(hip_device):
     """BASELINE.json configs[4] at its stated size: sub-sequences of 8 frames, 4 per GPU, 256x256, 64 planes, batch-norm in
     training mode (fusionnet/run-training.py:184-284).  Too large for a CPU oracle run, so size-independent properties:
     finite loss, gradient reaching all five modules, the forward pass reproducible to 1e-6 and the backward pass (the atomic
-    scatter of the hidden-state gradient, MIOpen's weight-gradient kernels) to 2e-2, the reference-signature forward_pass agreeing
+    scatter of the hidden-state gradient, MIOpen's weight-gradient kernels) to 1e-2, the reference-signature forward_pass agreeing
     with the bare loss, one Adam step changing the weights -- and the measurement-gradient gather kernel of the cost
     volume checked against autograd through the CPU oracle at this feature size."""
     import dvmvs_oracle as orc
@@ -202,10 +202,14 @@ def test_training_step_at_the_config5_size(hip_device):
         assert all(np.isfinite(norms)) and sum(n > 0 for n in norms) >= 0.9 * len(norms), type(module).__name__
     loss2, grads2, _ = run()
     assert abs(loss2.item() - loss1.item()) <= 1e-6 * abs(loss1.item())
-    for a, b in zip(grads1, grads2):
-        # run-to-run noise of floating-point atomics (scatter kernels here, weight-gradient kernels in MIOpen), amplified on
-        # the way down to the first layers: measured 2e-4 (last buckets) to 3.4e-3 (feature extractor)
-        assert float((a - b).norm() / (a.norm() + 1e-30)) <= 2e-2
+    for n, (a, b) in enumerate(zip(grads1, grads2)):
+        # Run-to-run noise of the floating-point atomics that are LEFT in a training step: the scatter of the hidden-state warp's
+        # gradient (dvmvs_hidden_warp_bwd) and MIOpen's split-K weight-gradient kernels (igemm_wrw_*_gkgs), amplified on the way down
+        # to the first layers: measured 2e-4 (last bucket) to 3.4e-3 (feature extractor).  The cost-volume gradients (gathers since
+        # round 3), the up-sampler's and the depthwise layers' (round 4: gathers / fixed-order reductions) contribute nothing to it.
+        noise = float((a - b).norm() / (a.norm() + 1e-30))
+        print(f"gradient bucket {n}: run-to-run relative L2 difference {noise:.2e}")
+        assert noise <= 1e-2
     # the script-level forward pass (meters + loss, reference signature) computes the same loss
     meters_and_loss = forward_pass(images=images, depths=depths, poses=poses, K=K, model=model, is_training=True)
     assert abs(meters_and_loss[4].item() - loss1.item()) <= 1e-5 * abs(loss1.item())
