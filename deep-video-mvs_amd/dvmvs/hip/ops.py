@@ -130,11 +130,19 @@ def _work_list_ptr(work_list, image1, B, H, W, D):
     return work_list.data_ptr()
 
 
-@torch.library.custom_op("dvmvs::cost_volume", mutates_args=(), device_types="cuda")
-def cost_volume(image1: Tensor, image2s: Sequence[Tensor], Hm: Tensor, kt: Tensor,
-                min_depth: float, max_depth: float, n_depth_levels: int, dot_product: bool, variant: int, work_list: Optional[Tensor] = None) -> Tensor:
+def cost_volume(image1: Tensor, image2s: Sequence[Tensor], Hm: Tensor, kt: Tensor, min_depth: float, max_depth: float, n_depth_levels: int,
+                dot_product: bool, variant: int, work_list: Optional[Tensor] = None) -> Tensor:
     """``Hm`` [B,M,9] = K R K^-1 and ``kt`` [B,M,3] = K t per (batch item, measurement frame): dvmvs.pose_algebra.  ``work_list``: the
-    device copy of ``sweep_work_list_host``'s result for these matrices (optional; the tiled sweep then cuts long workgroups)."""
+    device copy of ``sweep_work_list_host``'s result for these matrices (optional; the tiled sweep then cuts long workgroups).
+    Differentiable in the feature maps (dot-product mode)."""
+    if work_list is None:      # (the registered op takes a tensor: an empty one = no list)
+        work_list = torch.empty(0, dtype=torch.int32, device=image1.device)
+    return _cost_volume_op(image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant, work_list)
+
+
+@torch.library.custom_op("dvmvs::cost_volume", mutates_args=(), device_types="cuda")
+def _cost_volume_op(image1: Tensor, image2s: Sequence[Tensor], Hm: Tensor, kt: Tensor,
+                    min_depth: float, max_depth: float, n_depth_levels: int, dot_product: bool, variant: int, work_list: Tensor) -> Tensor:
     _dev_f32("cost_volume", image1, Hm, kt, *image2s)
     M = len(image2s)
     if M == 0:
@@ -154,7 +162,7 @@ def cost_volume(image1: Tensor, image2s: Sequence[Tensor], Hm: Tensor, kt: Tenso
     out = torch.empty((B, n_depth_levels, H, W), dtype=torch.float32, device=image1.device)
     lib = _capi.lib()
     workspace, ws_bytes = sweep_workspace(image1.device, B, M, H, W, n_depth_levels) if COST_VOLUME_TWO_PASS else (None, 0)
-    items = _work_list_ptr(work_list, image1, B, H, W, n_depth_levels)
+    items = _work_list_ptr(work_list if work_list.numel() else None, image1, B, H, W, n_depth_levels)
     with torch.cuda.device(image1.device):
         rc = lib.dvmvs_cost_volume_planned_fwd(
             _ptr(image1), _capi.pointer_array([_ptr(t) for t in image2s]), _ptr(Hm), _ptr(kt), _ptr(out),
@@ -166,14 +174,14 @@ def cost_volume(image1: Tensor, image2s: Sequence[Tensor], Hm: Tensor, kt: Tenso
     return out
 
 
-@cost_volume.register_fake
-def _(image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant, work_list=None):
+@_cost_volume_op.register_fake
+def _(image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant, work_list):
     B, C, H, W = image1.shape
     return image1.new_empty((B, n_depth_levels, H, W))
 
 
-@cost_volume.register_kernel("cpu")
-def _(image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant, work_list=None):
+@_cost_volume_op.register_kernel("cpu")
+def _(image1, image2s, Hm, kt, min_depth, max_depth, n_depth_levels, dot_product, variant, work_list):
     _no_cpu("cost_volume")
 
 
