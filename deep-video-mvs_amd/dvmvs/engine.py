@@ -49,7 +49,11 @@ from dvmvs import utils as _utils
 os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC", "0")
 
 _MAX_MEAS = 8            # DVMVS_MAX_MEASUREMENTS of the C ABI
-_STAGING_SLOTS = 8       # pinned staging ring: the host may run this many frames ahead of the device
+# Pinned staging ring = how many frames the host may run ahead of the device (it waits for the slot's previous upload to have executed).
+# TWO: with 8 the host (0.7 ms per step) raced up to 8 graph launches ahead of the device (1.3 ms per frame) and every 10-20 frames one
+# frame took 2.5-5 ms instead of 1.3 on the device -- the deeper the queue of launched graphs, the more such stalls (2 / 3 / 8 / 64 slots:
+# 1 / 2 / 4 / 6 of them in 70 frames, tools/step_times_probe.py); with 2 the device runs a steady 1.28 ms per frame.
+_STAGING_SLOTS = int(os.environ.get("DVMVS_STAGING_SLOTS", "2"))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
