@@ -582,6 +582,8 @@ def main():
 
     host_seconds = [0.0, 0]      # time the host spends inside engine.step (pose algebra, sweep plan, upload, graph launch), and calls
 
+    step_events = []             # one device event after every timed step: per-step device times (diagnostic, short runs)
+
     def run_frame(k):
         t_host = time.perf_counter()
         try:
@@ -589,6 +591,9 @@ def main():
         finally:
             host_seconds[0] += time.perf_counter() - t_host
             host_seconds[1] += 1
+            if len(step_events) < 64:
+                step_events.append(torch.cuda.Event(enable_timing=True))
+                step_events[-1].record()
 
     def run_frame_inner(k):
         ids = [k - 1 - i for i in range(M)]
@@ -612,6 +617,7 @@ def main():
 
         def region_start():      # (host time is counted over the timed steps only: warm-up steps run eagerly and capture graphs)
             host_seconds[0], host_seconds[1] = 0.0, 0
+            step_events.clear()
             if mark is not None:
                 mark()
 
@@ -676,6 +682,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             # host time per step inside engine.step (asynchronous to the GPU: it matters only where it exceeds ms_per_step)
             "host_ms_per_step": host_ms,
+            "device_ms_between_step_ends": [round(step_events[i - 1].elapsed_time(step_events[i]), 3) for i in range(1, len(step_events))],
             "config": {"workload": "fusionnet inference, one synthetic-image sequence per GPU on the sample scene's keyframe poses, "
                                    f"320x256, 64 planes, M={M} measurement frames, batch 1 (BASELINE.json configs[2]; configs[3] at N>1)",
                        "sequences_per_gpu": 1, "hip_graphs": not args.no_graphs, "bn_folded": not args.no_fold_bn,
