@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--train-batch", type=int, default=4, help="sub-sequences per GPU per step (train mode)")
     ap.add_argument("--train-frames", type=int, default=8, help="frames per sub-sequence (train mode)")
     ap.add_argument("--mark-region", action="store_true",
-                    help="bracket the timed loop with a cumsum kernel so tools/summarize_trace.py can cut it out of a rocprofv3 trace")
+                    help="bracket the timed loop with the library's marker kernel so tools/summarize_trace.py can cut it out of a rocprofv3 trace")
     ap.add_argument("--no-roofline-leg", action="store_true", help="skip the dedicated cost-volume timing (profiling runs)")
     ap.add_argument("--no-rel-l1", action="store_true", help="skip the golden-frame parity check that fills the rel_l1 field")
     ap.add_argument("--sequences-per-gpu", type=int, default=8,
@@ -456,6 +456,19 @@ def cpu_baseline(args, modules, n_meas):
             "stage_ms": {k2: round(1e3 * v / frames, 2) for k2, v in pipe.stage_seconds.items()}}
 
 
+def region_marker(device):
+    """A callable that launches the library's empty, uniquely named marker kernel and synchronises: tools/summarize_trace.py cuts a
+    rocprofv3 kernel trace at the two marks bench.py sets around its timed loop."""
+    from dvmvs.hip import _capi
+
+    def mark():
+        with torch.cuda.device(device):
+            _capi.check(_capi.lib().dvmvs_trace_marker(torch.cuda.current_stream(device).cuda_stream), "dvmvs_trace_marker")
+        torch.cuda.synchronize(device)
+
+    return mark
+
+
 def timed_region(step_fn, warmup, steps, world, device, before=None, after=None):
     """The contract's timing harness, shared by the inference and training modes (and driven on CPU, with the gloo backend and
     a stub step, by tests/test_bench_harness.py): ``warmup`` untimed steps, then EXACTLY ``steps`` steps bracketed by a barrier +
@@ -520,8 +533,7 @@ def train_mode(args, world, rank, device):
     def step(_):
         last["loss"] = train_step(model, opt, reducer, images, depths, poses, K)
 
-    marker = torch.ones(4096, device=device)
-    mark = (lambda: (marker.cumsum(0), torch.cuda.synchronize())) if args.mark_region else None
+    mark = region_marker(device) if args.mark_region else None
     elapsed = timed_region(step, max(args.warmup, 1), args.steps, world, device, before=mark, after=mark)
     loss = last["loss"]
     if rank == 0:
@@ -612,8 +624,7 @@ def main():
         if not args.no_feature_cache:
             for k in range(M):
                 engine._half_features(k, images[k % n_images])
-        marker = torch.ones(4096, device=device)
-        mark = (lambda: (marker.cumsum(0), torch.cuda.synchronize())) if args.mark_region else None
+        mark = region_marker(device) if args.mark_region else None
 
         def region_start():      # (host time is counted over the timed steps only: warm-up steps run eagerly and capture graphs)
             host_seconds[0], host_seconds[1] = 0.0, 0

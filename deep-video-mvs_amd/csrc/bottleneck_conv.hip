@@ -39,8 +39,10 @@ struct BottleneckConvArgs {
   int B, C_in, C_out, n_tiles, cs, splits;
 };
 
-// split count: the smallest divisor of C_in / 16 that gives at least kBcTargetWaves waves (or all of them)
-__host__ __device__ inline int bottleneck_splits(int B, int C_out, int C_in, int P) {
+// split count: the smallest divisor of C_in / 16 that gives at least kBcTargetWaves waves (or all of them) AND whose slice of x
+// (C_in / splits channels x `plane` padded pixels) fits the 64 KB of LDS a workgroup stages it in
+constexpr size_t kBcLdsBytes = 64 * 1024;
+__host__ __device__ inline int bottleneck_splits(int B, int C_out, int C_in, int P, int plane) {
   const int n_tiles = (C_out + kBcRows - 1) / kBcRows, groups = C_in / 16, pixel_groups = P / kBcPixels;
   const int per_split = n_tiles * pixel_groups * B;
   int target = kBcTargetWaves;
@@ -49,7 +51,7 @@ __host__ __device__ inline int bottleneck_splits(int B, int C_out, int C_in, int
 #endif
   const int wanted = (target + per_split - 1) / per_split;
   for (int d = 1; d <= groups; ++d)
-    if (groups % d == 0 && d >= wanted) return d;
+    if (groups % d == 0 && d >= wanted && sizeof(float) * static_cast<size_t>(C_in / d) * plane <= kBcLdsBytes) return d;
   return groups;
 }
 
@@ -173,7 +175,7 @@ template <int H_IN, int W_IN, int STRIDE>
 int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
   constexpr int P = (H_IN / STRIDE) * (W_IN / STRIDE), PLANE = (H_IN + 2) * (W_IN + 2);
   const size_t lds = sizeof(float) * static_cast<size_t>(a.cs) * PLANE;
-  if (lds > 64 * 1024) return DVMVS_EUNSUPPORTED;
+  if (lds > kBcLdsBytes) return DVMVS_EUNSUPPORTED;
   const dim3 grid((a.n_tiles + kBcWaves - 1) / kBcWaves, a.splits, a.B * (P / kBcPixels)), block(kBcWaves * 64);
   const int groups = a.cs / 16;
 #ifdef DVMVS_SWEEP_TUNING      // tools-only build: DVMVS_BC_CH=1|2|4 forces the request burst (tools/lstm_conv_probe.py)
@@ -220,7 +222,7 @@ extern "C" int dvmvs_bottleneck_conv_pack(const float* weight, float* packed, in
 
 extern "C" int dvmvs_bottleneck_conv_splits(int B, int C_out, int C_in, int H_in, int W_in, int stride) {
   if (B <= 0 || !dvmvs::bottleneck_shape_ok(C_out, C_in, H_in, W_in, stride)) return DVMVS_EUNSUPPORTED;
-  return dvmvs::bottleneck_splits(B, C_out, C_in, (H_in / stride) * (W_in / stride));
+  return dvmvs::bottleneck_splits(B, C_out, C_in, (H_in / stride) * (W_in / stride), (H_in + 2) * (W_in + 2));
 }
 
 extern "C" int dvmvs_bottleneck_conv_fwd(const float* x, const float* packed, float* partials, int B, int C_in, int H_in, int W_in, int C_out,
@@ -232,7 +234,7 @@ extern "C" int dvmvs_bottleneck_conv_fwd(const float* x, const float* packed, fl
   a.x = x; a.packed = packed; a.partials = partials;
   a.B = B; a.C_in = C_in; a.C_out = C_out;
   a.n_tiles = (C_out + kBcRows - 1) / kBcRows;
-  a.splits = bottleneck_splits(B, C_out, C_in, (H_in / stride) * (W_in / stride));
+  a.splits = bottleneck_splits(B, C_out, C_in, (H_in / stride) * (W_in / stride), (H_in + 2) * (W_in + 2));
   a.cs = C_in / a.splits;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (H_in == 8 && W_in == 10) return launch_bottleneck_conv<8, 10, 1>(a, s);

@@ -46,6 +46,8 @@ typedef void* dvmvs_stream_t;         /* hipStream_t */
 int dvmvs_abi_version(void);
 const char* dvmvs_build_arch(void);   /* "gfx950" */
 const char* dvmvs_error_string(int code);
+/* Launches an empty kernel named dvmvs::trace_marker_kernel (profiling: brackets a region of a kernel trace). */
+int dvmvs_trace_marker(dvmvs_stream_t stream);
 
 /*
  * Small pose algebra: WHERE IT IS EVALUATED, AND WHY IT IS AN ARGUMENT (ABI 3).

@@ -29,8 +29,19 @@ def problem(C_in, C_out, H, W, B, seed):
     return x, w, bias
 
 
+def test_split_count_respects_the_lds_budget(ops):
+    """A large batch needs few splits for its wave count, but a split's slice of x must still fit the 64 KB a workgroup stages it in
+    (round 4, first form: batch 8 of the ConvLSTM layer asked for 2 splits = 512 channels x 120 padded pixels = 240 KB and the launch
+    was refused -- found by bench.py's 8-sequence leg)."""
+    for B in (1, 2, 4, 8, 16):
+        for (C_in, C_out, H, W, stride) in SHAPES:
+            S = ops.bottleneck_conv_splits(B, C_out, C_in, H, W, stride)
+            assert S >= 1 and (C_in // 16) % S == 0
+            assert (C_in // S) * (H + 2) * (W + 2) * 4 <= 64 * 1024, (B, C_in, S)
+
+
 @pytest.mark.parametrize("shape", SHAPES)
-@pytest.mark.parametrize("B", [1, 2])
+@pytest.mark.parametrize("B", [1, 2, 8])
 def test_partial_sums_add_up_to_the_convolution(ops, hip_device, shape, B):
     C_in, C_out, H, W, stride = shape
     dev = hip_device

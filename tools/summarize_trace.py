@@ -3,7 +3,7 @@
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python bench.py --mark-region ...
     python tools/summarize_trace.py /tmp/prof/bench_kernel_trace.csv profiles/r01_bench_timed_region.csv [steps]
 
-bench.py --mark-region brackets its timed loop with a cumulative-sum kernel that nothing else in the program launches;
+bench.py --mark-region brackets its timed loop with the library's empty marker kernel (dvmvs::trace_marker_kernel);
 everything outside the two markers (MIOpen solver search during warm-up, the roofline leg, the CPU baseline) is dropped.
 """
 import csv
@@ -17,7 +17,9 @@ def main():
     rows = list(csv.DictReader(open(src)))
     name_key = "Kernel_Name"
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "scan" in r[name_key].lower() or "cumsum" in r[name_key].lower()]
+    marks = [i for i, r in enumerate(rows) if "trace_marker_kernel" in r[name_key]]
+    if not marks:      # (traces taken before round 4 were marked with a cumulative-sum kernel)
+        marks = [i for i, r in enumerate(rows) if "scan" in r[name_key].lower() or "cumsum" in r[name_key].lower()]
     if len(marks) < 2:
         raise SystemExit(f"expected two marker kernels, found {len(marks)}")
     # a cumsum may be several kernels: region = after the last kernel of the first group .. before the first of the last
