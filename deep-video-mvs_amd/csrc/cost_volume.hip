@@ -164,8 +164,10 @@ extern "C" int dvmvs_cost_volume_planned_fwd(const float* image1, const float* c
                                              float* workspace, size_t workspace_bytes, const unsigned int* work_list, dvmvs_stream_t stream) {
   using namespace dvmvs;
   if (image2_layout != DVMVS_LAYOUT_NCHW && image2_layout != DVMVS_LAYOUT_NHWC) return DVMVS_EINVAL;
-  if (variant < 0 || (variant > 3 && variant < 32) || variant > 255) return DVMVS_EINVAL;
-  if ((variant == 2 || variant == 3) && !dot_product) return DVMVS_EUNSUPPORTED;
+  if (variant < 0 || (variant > 5 && variant < 32) || variant > 255) return DVMVS_EINVAL;
+  if (variant >= 2 && variant <= 5 && !dot_product) return DVMVS_EUNSUPPORTED;
+  const bool single_pass = variant == 4 || variant == 5;      // no second launch: the sweep gathers an unstageable run inline
+  if (single_pass) variant -= 2;
   CostVolumeArgs a;
   const int rc = fill_sweep_args(&a, image1, image2s, Hm, kt, cost_volume, B, M, C, H, W, D, min_depth, max_depth, true);
   if (rc != 0) return rc;
@@ -174,12 +176,12 @@ extern "C" int dvmvs_cost_volume_planned_fwd(const float* image1, const float* c
   if (a.image2_nhwc && (!dot_product || variant == 1 || C % 4 != 0 || H * W < 64 * 64)) return DVMVS_EUNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // a workspace large enough for the spill list switches the tiled sweep to its two-pass form
-  if (workspace != nullptr && workspace_bytes >= dvmvs_cost_volume_workspace_bytes(B, M, H, W, D))
+  if (!single_pass && workspace != nullptr && workspace_bytes >= dvmvs_cost_volume_workspace_bytes(B, M, H, W, D))
     a.spill = reinterpret_cast<unsigned int*>(workspace);
   if (variant >= 32) {
     // tuning configurations for tools/cv_microbench.py; not part of the stable interface
     if (!dot_product) return DVMVS_EUNSUPPORTED;
-    if (work_list != nullptr && a.spill != nullptr) a.items = work_list;
+    if (work_list != nullptr) a.items = work_list;
     return launch_sweep_tuning(variant - 32, a, s);
   }
   // the tiled sweep addresses the maps through 32-bit buffer offsets: one batch item of one map must stay below 2 GiB
@@ -187,8 +189,7 @@ extern "C" int dvmvs_cost_volume_planned_fwd(const float* image1, const float* c
   const bool tiled = dot_product && fits && (variant == 2 || variant == 3 || a.image2_nhwc || (variant == 0 && H * W >= 64 * 64));
   if ((variant == 2 || variant == 3) && !fits) return DVMVS_EUNSUPPORTED;
   if (a.image2_nhwc && !fits) return DVMVS_EUNSUPPORTED;
-  // the work list belongs to the tiled sweep's two-pass form (its items index the spill slots)
-  if (tiled && work_list != nullptr && a.spill != nullptr) a.items = work_list;
+  if (tiled && work_list != nullptr) a.items = work_list;
   if (tiled && variant == 3) return launch_sweep_wide(a, s);
   if (tiled) return launch_sweep_default(a, s);
   return launch_cost_volume_generic(a, dot_product != 0, s);
@@ -227,7 +228,9 @@ extern "C" int dvmvs_sweep_select_variant(const float* Hm_host, const float* kt_
 
 // dvmvs_sweep_select_variant + dvmvs_sweep_work_list in ONE walk over the (tile, chunk) pairs (the per-frame host cost of the sweep
 // plan: ~0.15 ms for an easy pair, ~0.5 ms where both configurations have to be planned): decides the configuration (or takes
-// `variant` = 2 / 3 as given; 0 = decide), leaves that configuration's work list in `work_list_host` and returns the variant.
+// `variant` = 2 / 3 as the configuration given; 0 = decide), leaves that configuration's work list in `work_list_host` and returns the
+// variant to launch with: 2 / 3 (two passes) or, when the plan queues nothing for the second pass, 4 / 5 (the same configurations as ONE
+// launch -- the empty second pass costs 3-4.5 us of every frame it is launched in, five frames of six on the sample scene).
 extern "C" int dvmvs_sweep_plan(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
                                 int variant, unsigned int* work_list_host, size_t work_list_bytes) {
   if (!Hm_host || !kt_host || !work_list_host || B <= 0 || M <= 0 || H <= 0 || W <= 0 || D <= 0) return DVMVS_EINVAL;
@@ -240,10 +243,13 @@ extern "C" int dvmvs_sweep_plan(const float* Hm_host, const float* kt_host, int 
   if (variant != 3) {
     rc = dvmvs::sweep_work_list_host(0, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, work_list_host, words, d);
     if (rc < 0) return rc;
-    if (variant == 2 || dvmvs::sweep_is_easy(d)) return 2;
+    // nothing queued for the second pass in this plan: the single-pass launch (no second kernel; should the kernel's own plan
+    // disagree, it gathers that run inline)
+    const int chosen = d[3] == 0 ? 4 : 2;
+    if (variant == 2 || dvmvs::sweep_is_easy(d)) return chosen;
     dvmvs::sweep_plan_stats_host(1, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, w);
-    if (dvmvs::sweep_model_us(0, d, B, H, W, D) <= dvmvs::sweep_model_us(1, w, B, H, W, D)) return 2;
+    if (dvmvs::sweep_model_us(0, d, B, H, W, D) <= dvmvs::sweep_model_us(1, w, B, H, W, D)) return chosen;
   }
-  rc = dvmvs::sweep_work_list_host(1, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, work_list_host, words, nullptr);
-  return rc < 0 ? rc : 3;
+  rc = dvmvs::sweep_work_list_host(1, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, work_list_host, words, w);
+  return rc < 0 ? rc : (w[3] == 0 ? 5 : 3);
 }

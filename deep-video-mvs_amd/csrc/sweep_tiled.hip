@@ -465,10 +465,11 @@ __host__ __device__ inline SweepWork decode_work(int block, int tiles, int chunk
   return w;
 }
 
-// GATHER: the caller gave no spill workspace, so runs of planes that cannot be staged are gathered inline (slow path,
-// compiled into its own instantiation so that the two-pass kernel carries none of its registers).
+// GATHER: there is no second pass (no spill workspace, or the single-pass variants 4 / 5 that the host's plan picks when it expects
+// nothing to be queued): runs of planes that cannot be staged are gathered inline -- slow, but then never taken; compiled into its own
+// instantiation so that the two-pass kernel carries none of its registers (162 VGPRs against 127-133: still three waves per SIMD).
 template <class Cfg, bool NHWC, bool GATHER>
-__global__ __launch_bounds__(Cfg::NT, GATHER ? 2 : Cfg::WAVES) void sweep_tiled_kernel(CostVolumeArgs a) {
+__global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_tiled_kernel(CostVolumeArgs a) {
   constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP, CCH = Cfg::CCH, CAP = Cfg::CAP, NT = Cfg::NT, REC = Cfg::REC;
   constexpr int NPIX = Cfg::NPIX, DPT = Cfg::DPT;
   constexpr int QPR = CCH / 4;   // 16-byte quads per record

@@ -5,7 +5,7 @@
 //     include it, weights recomputed with the forward's own fp32 expressions), so training can use the HIP forward;
 //   * depthwise k x k convolution (MnasNet): MIOpen falls back to naive_conv_ab_nonpacked_{fwd,bwd,wrw}_nchw (24-47 us per call,
 //     ~340 calls per step = 9.8 ms); the forward kernel exists (frame_ops.hip), here are the data gradient (gather over the k x k
-//     outputs that read an input pixel) and the weight gradient (one workgroup per channel, fixed-order reduction).
+//     outputs that read an input pixel) and the weight gradient (workgroups per channel x slice, fixed-order reductions).
 // No atomics anywhere: gradients are bit-reproducible.  Reference for the ops themselves: /root/reference/dvmvs/fusionnet/model.py:59,114
 // (F.interpolate(scale_factor=2, mode='bilinear', align_corners=True)) and torchvision's MnasNet depthwise layers.
 #include "dvmvs_device.h"
@@ -88,17 +88,22 @@ __global__ __launch_bounds__(256) void depthwise_bwd_data_kernel(const float* __
 }
 
 // grad_w[c, ky, kx] = sum_{b, oy, ox} grad_out[b, c, oy, ox] * in[b, c, oy * stride - K/2 + ky, ox * stride - K/2 + kx]
-// One workgroup per channel: every thread keeps K*K partial sums over its (b, pixel) share, then a fixed-order tree over LDS.
+// A workgroup = one channel x one slice of the (b, pixel) range: every thread keeps K*K partial sums over its share, a fixed-order tree
+// over LDS reduces the workgroup, and (when there is more than one slice) depthwise_bwd_weight_reduce_kernel adds the slices in order.
+// (Round 4, first form: one workgroup per channel -- 48 ... 576 workgroups of 256 threads for 65 536 products each: 58 us per call at
+// k = 3, no faster than MIOpen's naive kernel; sliced: the chip is full.)
 template <int K>
 __global__ __launch_bounds__(256) void depthwise_bwd_weight_kernel(const float* __restrict__ grad_out, const float* __restrict__ in,
-                                                                   float* __restrict__ grad_w, int B, int C, int H, int W, int OH, int OW, int stride) {
+                                                                   float* __restrict__ partial, int B, int C, int H, int W, int OH, int OW, int stride) {
   __shared__ float s_part[256];
-  const int c = blockIdx.x, tid = threadIdx.x;
+  const int c = blockIdx.x, slice = blockIdx.y, slices = gridDim.y, tid = threadIdx.x;
   float acc[K * K];
 #pragma unroll
   for (int k = 0; k < K * K; ++k) acc[k] = 0.0f;
-  const int per_image = OH * OW;
-  for (int i = tid; i < B * per_image; i += 256) {
+  const int per_image = OH * OW, total = B * per_image;
+  const int chunk = (total + slices - 1) / slices;
+  const int begin = slice * chunk, end = min(total, begin + chunk);
+  for (int i = begin + tid; i < end; i += 256) {
     const int b = i / per_image, p = i - b * per_image;
     const int oy = p / OW, ox = p - oy * OW;
     const float gv = grad_out[(static_cast<size_t>(b) * C + c) * per_image + p];
@@ -124,9 +129,17 @@ __global__ __launch_bounds__(256) void depthwise_bwd_weight_kernel(const float* 
       if (tid < off) s_part[tid] += s_part[tid + off];
       __syncthreads();
     }
-    if (tid == 0) grad_w[static_cast<size_t>(c) * K * K + k] = s_part[0];
+    if (tid == 0) partial[(static_cast<size_t>(slice) * C + c) * K * K + k] = s_part[0];
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(256) void depthwise_bwd_weight_reduce_kernel(const float* __restrict__ partial, float* __restrict__ grad_w, int n, int slices) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = partial[i];
+  for (int s = 1; s < slices; ++s) v += partial[static_cast<size_t>(s) * n + i];
+  grad_w[i] = v;
 }
 
 }  // namespace dvmvs
@@ -142,8 +155,24 @@ extern "C" int dvmvs_upsample2x_bwd(const float* grad_out, float* grad_in, int B
   return launch_status();
 }
 
+// slices of the (b, pixel) range per channel in the weight gradient: enough workgroups to fill the chip, at least 4096 products each
+static int depthwise_weight_slices(int B, int C, int OH, int OW) {
+  const long long total = static_cast<long long>(B) * OH * OW;
+  long long slices = (1024 + C - 1) / C;
+  if (slices > total / 4096) slices = total / 4096;
+  return static_cast<int>(slices < 1 ? 1 : (slices > 64 ? 64 : slices));
+}
+
+extern "C" size_t dvmvs_depthwise_conv_bwd_workspace_bytes(int B, int C, int H, int W, int kernel_size, int stride) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (kernel_size != 3 && kernel_size != 5) || (stride != 1 && stride != 2)) return 0;
+  const int pad = kernel_size / 2;
+  const int OH = (H + 2 * pad - kernel_size) / stride + 1, OW = (W + 2 * pad - kernel_size) / stride + 1;
+  const int slices = depthwise_weight_slices(B, C, OH, OW);
+  return slices > 1 ? sizeof(float) * static_cast<size_t>(slices) * C * kernel_size * kernel_size : 0;
+}
+
 extern "C" int dvmvs_depthwise_conv_bwd(const float* grad_out, const float* in, const float* weight, float* grad_in, float* grad_weight,
-                                        int B, int C, int H, int W, int kernel_size, int stride, dvmvs_stream_t stream) {
+                                        float* workspace, int B, int C, int H, int W, int kernel_size, int stride, dvmvs_stream_t stream) {
   using namespace dvmvs;
   if (!grad_out || !in || !weight || B <= 0 || C <= 0 || H <= 0 || W <= 0) return DVMVS_EINVAL;
   if ((kernel_size != 3 && kernel_size != 5) || (stride != 1 && stride != 2)) return DVMVS_EUNSUPPORTED;
@@ -159,8 +188,16 @@ extern "C" int dvmvs_depthwise_conv_bwd(const float* grad_out, const float* in, 
     if (rc != 0) return rc;
   }
   if (grad_weight) {
-    if (kernel_size == 3) hipLaunchKernelGGL(depthwise_bwd_weight_kernel<3>, dim3(C), dim3(256), 0, s, grad_out, in, grad_weight, B, C, H, W, OH, OW, stride);
-    else hipLaunchKernelGGL(depthwise_bwd_weight_kernel<5>, dim3(C), dim3(256), 0, s, grad_out, in, grad_weight, B, C, H, W, OH, OW, stride);
+    const int slices = depthwise_weight_slices(B, C, OH, OW);
+    if (slices > 1 && !workspace) return DVMVS_EINVAL;      // dvmvs_depthwise_conv_bwd_workspace_bytes() bytes of scratch
+    float* partial = slices > 1 ? workspace : grad_weight;
+    const dim3 grid(C, slices);
+    if (kernel_size == 3) hipLaunchKernelGGL(depthwise_bwd_weight_kernel<3>, grid, dim3(256), 0, s, grad_out, in, partial, B, C, H, W, OH, OW, stride);
+    else hipLaunchKernelGGL(depthwise_bwd_weight_kernel<5>, grid, dim3(256), 0, s, grad_out, in, partial, B, C, H, W, OH, OW, stride);
+    int rc = launch_status();
+    if (rc != 0 || slices == 1) return rc;
+    const int n = C * kernel_size * kernel_size;
+    hipLaunchKernelGGL(depthwise_bwd_weight_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, grad_weight, n, slices);
     return launch_status();
   }
   return 0;

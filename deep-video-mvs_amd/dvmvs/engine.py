@@ -365,7 +365,7 @@ class DepthEngine:
         self._side_stream = torch.cuda.Stream(device=self.device)
         self.sweep_variant_counts = {}     # frames per sweep configuration (dvmvs_cost_volume_fwd's variant) since construction
         # host-planned work list for the sweep: only where the matrices exist on the host, and one plan per launch (one sequence)
-        self.sweep_work_list = bool(_utils.SWEEP_WORK_LIST and self.pose_algebra == "reference" and _utils.COST_VOLUME_VARIANT in (0, 2, 3))
+        self.sweep_work_list = bool(_utils.SWEEP_WORK_LIST and self.pose_algebra == "reference" and _utils.COST_VOLUME_VARIANT in (0, 2, 3, 4, 5))
         self.reset()
 
     def conv_plan_report(self):
@@ -590,7 +590,7 @@ class DepthEngine:
             if self.sweep_work_list:
                 o, n = self._param_offsets["sweep_items" + suffix]
                 variant = _ops.sweep_plan_host(Hm, kt, self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth,
-                                               variant if variant in (2, 3) else 0, mirror.view(torch.int32)[o:o + n])
+                                               variant if variant in (2, 3, 4, 5) else 0, mirror.view(torch.int32)[o:o + n])
             elif variant == 0:
                 variant = _utils.sweep_variant((Hm, kt), self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth)
             return variant
@@ -945,16 +945,17 @@ class DepthEngine:
                 # whose geometry asks for the other configuration finds its graph ready instead of paying ~0.1 s of capture mid-run.
                 self._graphs[key] = self._capture(body)
                 if give:
-                    choices = (2, 3) if next_variant in (2, 3) or sweep_variant in (2, 3) else (sweep_variant,)
+                    tiled = (2, 3, 4, 5)      # the sweep's configurations x (two passes, one pass): whichever a later geometry asks for
+                    choices = tiled if next_variant in tiled or sweep_variant in tiled else (sweep_variant,)
                     for par in (0, 1):
                         for v in (choices if give < 2 else (0,)):
                             for vn in (choices if give == 2 else (0,)):
                                 k = graph_key(par, give, give, v, vn)
                                 if k not in self._graphs:
                                     self._graphs[k] = self._capture((n_meas, kind[1], v, par, give, give, n_meas_next, vn))
-                elif sweep_variant in (2, 3) and have < 2:
+                elif sweep_variant in (2, 3, 4, 5) and have < 2:
                     for par in ((0, 1) if self.direct else (0,)):
-                        for v in (2, 3):
+                        for v in (2, 3, 4, 5):
                             k = graph_key(par, have, 0, v, 0)
                             if k not in self._graphs:
                                 self._graphs[k] = self._capture((n_meas, kind[1], v, par, have, 0, 0, 0))

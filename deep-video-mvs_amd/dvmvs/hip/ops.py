@@ -100,7 +100,7 @@ def sweep_work_list_host(Hm: Tensor, kt: Tensor, H: int, W: int, D: int, min_dep
     if out.device.type != "cpu" or out.dtype != torch.int32 or out.numel() < words or not out.is_contiguous():
         raise ValueError(f"work list buffer must be a contiguous int32 host tensor of at least {words} words")
     used = _capi.lib().dvmvs_sweep_work_list(Hm.data_ptr(), kt.data_ptr(), B, M, int(H), int(W), int(D), float(min_depth), float(max_depth),
-                                             1 if variant == 3 else 0, out.data_ptr(), out.numel() * 4)
+                                             1 if variant in (3, 5) else 0, out.data_ptr(), out.numel() * 4)
     if used < 0:
         _capi.check(used, "dvmvs_sweep_work_list")
     return out
@@ -115,7 +115,7 @@ def sweep_plan_host(Hm: Tensor, kt: Tensor, H: int, W: int, D: int, min_depth: f
     if out.device.type != "cpu" or out.dtype != torch.int32 or not out.is_contiguous() or out.numel() < sweep_work_list_words(Hm.shape[0], H, W, D):
         raise ValueError("work list buffer must be a contiguous int32 host tensor of sweep_work_list_words entries")
     chosen = _capi.lib().dvmvs_sweep_plan(Hm.data_ptr(), kt.data_ptr(), Hm.shape[0], Hm.shape[1], int(H), int(W), int(D), float(min_depth),
-                                          float(max_depth), int(variant), out.data_ptr(), out.numel() * 4)
+                                          float(max_depth), {4: 2, 5: 3}.get(int(variant), int(variant)), out.data_ptr(), out.numel() * 4)
     if chosen < 0:
         _capi.check(chosen, "dvmvs_sweep_plan")
     return chosen
@@ -553,9 +553,13 @@ def depthwise_conv_bwd(grad_out: Tensor, x: Tensor, weight: Tensor, stride: int,
     k = weight.shape[-1]
     gx = torch.empty_like(x) if need_input else x.new_empty(0)
     gw = torch.empty_like(weight) if need_weight else x.new_empty(0)
+    lib = _capi.lib()
+    scratch = lib.dvmvs_depthwise_conv_bwd_workspace_bytes(B, C, H, W, k, int(stride)) if need_weight else 0
+    workspace = torch.empty(scratch // 4, dtype=torch.float32, device=x.device) if scratch else None
     with torch.cuda.device(x.device):
-        rc = _capi.lib().dvmvs_depthwise_conv_bwd(_ptr(grad_out), _ptr(x), _ptr(weight), _ptr(gx) if need_input else None,
-                                                  _ptr(gw) if need_weight else None, B, C, H, W, k, int(stride), _stream(x))
+        rc = lib.dvmvs_depthwise_conv_bwd(_ptr(grad_out), _ptr(x), _ptr(weight), _ptr(gx) if need_input else None,
+                                          _ptr(gw) if need_weight else None, _ptr(workspace) if workspace is not None else None,
+                                          B, C, H, W, k, int(stride), _stream(x))
     _capi.check(rc, "dvmvs_depthwise_conv_bwd")
     return gx, gw
 

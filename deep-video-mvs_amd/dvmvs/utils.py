@@ -33,7 +33,7 @@ from dvmvs import pose_algebra as _pose_algebra
 
 # kernel selector for the cost volume (include/dvmvs_hip.h): 0 = automatic (generic kernel for small maps / SAD, otherwise the
 # LDS-tiled sweep in the configuration the host-side plan model picks for the keyframe geometry), 1 = generic reference-order
-# kernel, 2 = LDS-tiled sweep, default configuration, 3 = LDS-tiled sweep, wide-baseline configuration
+# kernel, 2 = LDS-tiled sweep, default configuration, 3 = LDS-tiled sweep, wide-baseline configuration, 4 / 5 = 2 / 3 without a second pass
 COST_VOLUME_VARIANT = int(os.environ.get("DVMVS_COST_VOLUME_VARIANT", "0"))
 # host-planned work list for the tiled sweep (dvmvs_sweep_work_list); DVMVS_SWEEP_WORK_LIST=0: the static (tile, chunk) numbering
 SWEEP_WORK_LIST = os.environ.get("DVMVS_SWEEP_WORK_LIST", "1") != "0"
@@ -99,7 +99,7 @@ def cost_volume_fusion(image1, image2s, pose1, pose2s, K, warp_grid, min_depth, 
     H, W = image1.shape[2], image1.shape[3]
     variant = sweep_variant(host, H, W, n_depth_levels, min_depth, max_depth, dot_product)
     work_list = None
-    if host is not None and dot_product and variant in (0, 2, 3) and H * W >= 64 * 64 and SWEEP_WORK_LIST:
+    if host is not None and dot_product and variant in (0, 2, 3, 4, 5) and H * W >= 64 * 64 and SWEEP_WORK_LIST:
         # the tiled sweep's work list, planned on the host copies of the matrices (long workgroups cut into parallel pieces)
         work_list = _ops.sweep_work_list_host(host[0], host[1], H, W, n_depth_levels, min_depth, max_depth, variant).to(image1.device)
     return _ops.cost_volume(image1, image2s, Hm, kt, float(min_depth), float(max_depth), int(n_depth_levels), bool(dot_product), variant, work_list)

@@ -91,7 +91,9 @@ int dvmvs_sweep_matrices(const float* pose1, const float* const* pose2s, const f
  *               the vector L1); 2 = force the LDS-tiled sweep in its default configuration (dot_product only); 3 = the
  *               LDS-tiled sweep in its wide-baseline configuration (72 KB sample boxes, 512-thread workgroups: faster where
  *               the default one has to split or queue runs of planes, slower on easy pairs -- dvmvs_sweep_select_variant
- *               decides from the matrices).  Each configuration is bit-reproducible; the two differ in summation order.
+ *               decides from the matrices); 4 / 5 = configurations 2 / 3 as ONE launch: no second pass, a run that cannot be staged is
+ *               gathered inline by the sweep kernel (what dvmvs_sweep_plan returns when its plan queues nothing; also what a NULL
+ *               workspace gives).  Each is bit-reproducible; they differ in fp32 summation order.
  *   image2_layout DVMVS_LAYOUT_NCHW, or DVMVS_LAYOUT_NHWC when the MEASUREMENT maps are stored channels-last (a keyframe's
  *               features are reused as measurement features by later frames, so a runner converts them once per
  *               keyframe).  Supported by the LDS-tiled dot-product kernel (C % 4 == 0, H*W >= 4096); image1 and
@@ -140,7 +142,8 @@ int dvmvs_sweep_select_variant(const float* Hm_host, const float* kt_host, int B
  */
 size_t dvmvs_sweep_work_list_bytes(int B, int H, int W, int D);
 /* dvmvs_sweep_select_variant + dvmvs_sweep_work_list in one walk (what a frame loop calls once per keyframe): `variant` 0 = decide,
- * 2 / 3 = as given; leaves the chosen configuration's work list in work_list_host and returns the variant (negative on error). */
+ * 2 / 3 = that configuration; leaves the chosen configuration's work list in work_list_host and returns the variant to launch with
+ * (2 / 3, or 4 / 5 = the same configuration without a second pass when the plan queues nothing for it; negative on error). */
 int dvmvs_sweep_plan(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
                      int variant, unsigned int* work_list_host, size_t work_list_bytes);
 int dvmvs_sweep_work_list(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
@@ -216,11 +219,14 @@ int dvmvs_lstm_gates_bwd(const float* grad_h, const float* grad_c, const float* 
  *   dvmvs_upsample2x_bwd      adjoint of dvmvs_upsample2x_fwd (x2 bilinear, align_corners; /root/reference/dvmvs/fusionnet/model.py:59,114):
  *                             grad_out [B,C,2H,2W] -> grad_in [B,C,H,W]
  *   dvmvs_depthwise_conv_bwd  depthwise k x k (3 or 5), padding k/2, stride 1 or 2 (the MnasNet layers): grad_out [B,C,OH,OW], in [B,C,H,W],
- *                             weight [C,1,k,k] -> grad_in [B,C,H,W] and / or grad_weight [C,1,k,k] (either pointer may be NULL)
+ *                             weight [C,1,k,k] -> grad_in [B,C,H,W] and / or grad_weight [C,1,k,k] (either pointer may be NULL);
+ *                             workspace: dvmvs_depthwise_conv_bwd_workspace_bytes() bytes of caller-owned scratch for the weight
+ *                             gradient's slice sums (0 bytes -> may be NULL)
  */
 int dvmvs_upsample2x_bwd(const float* grad_out, float* grad_in, int B, int C, int H, int W, dvmvs_stream_t stream);
+size_t dvmvs_depthwise_conv_bwd_workspace_bytes(int B, int C, int H, int W, int kernel_size, int stride);
 int dvmvs_depthwise_conv_bwd(const float* grad_out, const float* in, const float* weight, float* grad_in, float* grad_weight,
-                             int B, int C, int H, int W, int kernel_size, int stride, dvmvs_stream_t stream);
+                             float* workspace, int B, int C, int H, int W, int kernel_size, int stride, dvmvs_stream_t stream);
 
 /*
  * 3x3, padding-1 convolutions on the bottleneck maps of a 320x256 frame (8x10, and 16x20 with stride 1 or 2) as a weight-streaming

@@ -204,23 +204,29 @@ def test_work_list_rejects_bad_arguments():
 
 def test_one_walk_plan_equals_selection_plus_work_list():
     """dvmvs_sweep_plan (what the frame engine calls once per keyframe) = dvmvs_sweep_select_variant + dvmvs_sweep_work_list of the
-    chosen configuration, on every keyframe pair of the sample scene; a forced variant is respected."""
+    chosen configuration, on every third keyframe pair of the sample scene; it returns the single-pass variant (4 / 5) exactly when
+    the chosen configuration's plan queues nothing for the second pass; a forced configuration is respected."""
     from dvmvs.hip import ops
     out = torch.zeros(ops.sweep_work_list_words(1, H, W, D), dtype=torch.int32)
     chosen = []
     for line in range(0, len(syn.keyframe_index_lines(2)), 3):
         Hm, kt = matrices(line)
         v = ops.sweep_plan_host(Hm, kt, H, W, D, 0.25, 20.0, 0, out)
-        assert v == pose_algebra.sweep_variant_host(Hm, kt, H, W, D, 0.25, 20.0)
+        configuration = {2: 2, 3: 3, 4: 2, 5: 3}[v]
+        assert configuration == pose_algebra.sweep_variant_host(Hm, kt, H, W, D, 0.25, 20.0)
+        queued_runs = lib_stats(Hm, kt, configuration - 2)[3]
+        assert (v >= 4) == (queued_runs == 0), (line, v, queued_runs)
         ref = ops.sweep_work_list_host(Hm, kt, H, W, D, 0.25, 20.0, v)
         used = 2 + 2 * int(ref[0])
         assert int(out[0]) == int(ref[0]) and torch.equal(out[:used], ref[:used]), line
         chosen.append(v)
-    assert set(chosen) == {2, 3}
+    assert {2, 4} <= set(chosen) and (3 in chosen or 5 in chosen)
     Hm, kt = matrices(0)
     for forced in (2, 3):
-        assert ops.sweep_plan_host(Hm, kt, H, W, D, 0.25, 20.0, forced, out) == forced
+        assert ops.sweep_plan_host(Hm, kt, H, W, D, 0.25, 20.0, forced, out) == forced + 2      # (line 0 queues nothing)
         ref = ops.sweep_work_list_host(Hm, kt, H, W, D, 0.25, 20.0, forced)
         assert torch.equal(out[:2 + 2 * int(ref[0])], ref[:2 + 2 * int(ref[0])])
+    Hm, kt = matrices(170)
+    assert ops.sweep_plan_host(Hm, kt, H, W, D, 0.25, 20.0, 2, out) == 2                           # (line 170 queues runs in both)
     with pytest.raises(RuntimeError):
         ops.sweep_plan_host(Hm, kt, H, W, D, 0.25, 20.0, 1, out)
