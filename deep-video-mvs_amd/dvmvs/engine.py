@@ -141,6 +141,12 @@ class FusedConv2d(nn.Module):
         self.bottleneck = False          # set by DepthEngine(bottleneck_convs=True)
         self._bottleneck_packed = None
         self._bottleneck_buffers = {}
+        # dense 3x3 / 5x5 layers on the larger maps and the one-channel depth heads: the direct MFMA convolution with bias + ReLU in
+        # its store path instead of MIOpen's Winograd / GEMM kernel + epilogue launch (csrc/direct_conv.hip);
+        # {input shape: output-channel tiles per wave the problem needs (0: not taken)}, {tiles: packed weights}
+        self.direct_conv = False         # set by DepthEngine(direct_convs=True)
+        self._direct_tiles = {}
+        self._direct_packed = {}
 
         k = conv.kernel_size
         self.depthwise = (conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1 and k[0] == k[1] and k[0] in (3, 5)
@@ -170,6 +176,10 @@ class FusedConv2d(nn.Module):
                 splits = _ops.bottleneck_conv_into(x, self._bottleneck_packed, shape[1], self.stride[0], buffers)
                 dst = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
                 return _ops.partial_sums_bias_act_into(buffers, splits, dst, self.bias, act, shape)
+        if self.direct_conv and residual is None and x.is_contiguous():
+            y = self._direct_forward(x, out, act, p0, p1, raw or self.defer_epilogue)
+            if y is not None:
+                return y
         if (self.plan_epilogue and residual is None and not raw and not self.defer_epilogue and self._plan_eligible(act)
                 and x.is_contiguous()):
             key = tuple(x.shape)
@@ -190,6 +200,37 @@ class FusedConv2d(nn.Module):
         if self.defer_epilogue or raw:
             return y
         return _ops.bias_act_into(y, y if out is None else out, self.bias, act, residual, residual_mode if residual is not None else 0, p0, p1)
+
+    def _direct_forward(self, x, out, act, p0, p1, raw):
+        """The layer through csrc/direct_conv.hip, or None when that kernel does not take the problem (then MIOpen as before).  ``raw``:
+        the convolution output without bias and activation (the consumer applies them)."""
+        k = self.weight.shape
+        if self.depthwise or self.groups != 1 or k[2] != k[3] or tuple(self.dilation) != (1, 1) or self.stride[0] != self.stride[1] or \
+                tuple(self.padding) != (k[2] // 2, k[2] // 2):
+            return None
+        B, _, H, W = x.shape
+        stride = self.stride[0]
+        bias = None if raw or self.bias is None else self.bias
+        if raw:
+            act = _ops.ACTIVATIONS["none"]
+        if k[0] == 1 and k[2] == 3 and stride == 1:      # depth head
+            dst = out if out is not None else torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
+            return _ops.conv_head_into(x, self.weight, bias, dst, act, p0, p1)
+        if act not in (_ops.ACTIVATIONS["none"], _ops.ACTIVATIONS["relu"]):
+            return None
+        key = tuple(x.shape)
+        tile = self._direct_tiles.get(key)
+        if tile is None:
+            tile = self._direct_tiles[key] = _ops.direct_conv_tile(B, k[1], H, W, k[0], k[2], stride)
+        if tile == 0:
+            return None
+        packed = self._direct_packed.get(tile)
+        if packed is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None      # (packed at the next eager call: the first frame of every kind runs eagerly)
+            packed = self._direct_packed[tile] = _ops.direct_conv_pack(self.weight.detach(), tile)
+        dst = out if out is not None else torch.empty((B, k[0], H // stride, W // stride), device=x.device, dtype=torch.float32)
+        return _ops.direct_conv_into(x, packed, tile, bias, dst, k[0], k[2], stride, act)
 
     def _bottleneck_for(self, x):
         """The partial-sum buffer for this input shape if the bottleneck kernel takes the problem (else None); packs the weights the
@@ -303,7 +344,7 @@ class DepthEngine:
     def __init__(self, feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder,
                  device="cuda", min_depth=0.25, max_depth=20.0, n_depth_levels=64, fold_bn=True, cache_features=True,
                  use_graphs=True, cache_size=None, channels_last=False, fuse=True, lstm_channels_last=True, sequences=1,
-                 pose_algebra=None, conv_plans=None, bottleneck_convs=None):
+                 pose_algebra=None, conv_plans=None, bottleneck_convs=None, direct_convs=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DepthEngine runs on an MI355X; there is no CPU execution path in this package")
@@ -332,6 +373,15 @@ class DepthEngine:
             for sub in ([] if m is None else m.modules()):
                 if isinstance(sub, FusedConv2d):
                     sub.bottleneck = self.bottleneck_convs
+        # the dense 3x3 / 5x5 layers of the 1/8 ... full-resolution maps and the depth heads through the direct MFMA convolution
+        # (csrc/direct_conv.hip; DVMVS_DIRECT_CONVS=0: MIOpen + epilogue launch as in rounds 1-3)
+        if direct_convs is None:
+            direct_convs = os.environ.get("DVMVS_DIRECT_CONVS", "1") != "0"
+        self.direct_convs = bool(direct_convs and fuse and not channels_last)
+        for m in mods:
+            for sub in ([] if m is None else m.modules()):
+                if isinstance(sub, FusedConv2d):
+                    sub.direct_conv = self.direct_convs
         self._lstm_packed, self._lstm_partials, self._lstm_combined = None, None, None
         if lstm_channels_last and self.lstm is not None and not channels_last:
             # the ConvLSTM convolution (1024 -> 2048 channels on an 8x10 map, 75 MB of weights) is weight-bandwidth bound;
@@ -864,6 +914,7 @@ class DepthEngine:
         if self.direct and frame_id is not None and ready is not None and ready["frame_id"] == frame_id and ready["parity"] == parity:
             have = 1
             if ready["level"] == 2 and ready["measurement_ids"] == list(measurement_ids) and len(ready["measurement_poses"]) == n_meas and \
+                    torch.equal(ready["full_K"], _pose_algebra.to_host(full_K).reshape(-1, 3, 3)) and \
                     torch.equal(ready["pose"], _pose_algebra.to_host(reference_pose).reshape(-1, 4, 4)) and \
                     all(torch.equal(a, _pose_algebra.to_host(b).reshape(-1, 4, 4)) for a, b in zip(ready["measurement_poses"], measurement_poses)):
                 have = 2
@@ -971,6 +1022,7 @@ class DepthEngine:
                 if give == 2:
                     to_host = _pose_algebra.to_host
                     self._prefetched.update(pose=to_host(next_reference_pose).reshape(-1, 4, 4).clone(), measurement_ids=list(next_measurement_ids),
+                                            full_K=to_host(full_K).reshape(-1, 3, 3).clone(),      # (the sweep ahead used THIS call's intrinsics)
                                             measurement_poses=[to_host(p).reshape(-1, 4, 4).clone() for p in next_measurement_poses])
             self._parity = 1 - parity
         if self.cache_features and frame_id is not None and have < 1:

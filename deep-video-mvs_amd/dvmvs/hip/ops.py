@@ -773,6 +773,60 @@ def partial_sums_bias_act_into(partials: Tensor, n_partials: int, dst: Tensor, b
     return dst
 
 
+# ---- dense 3x3 / 5x5 convolutions of the larger maps (csrc/direct_conv.hip): direct fp32 MFMA convolution, bias + ReLU fused ----
+def direct_conv_tile(B: int, C_in: int, H: int, W: int, C_out: int, kernel_size: int, stride: int) -> int:
+    """0 when dvmvs_direct_conv_fwd does not take the problem (the caller keeps its library convolution); else the number of
+    16-channel output tiles per wave (1 or 2) to pack the weights for."""
+    return _capi.lib().dvmvs_direct_conv_tile(int(B), int(C_in), int(H), int(W), int(C_out), int(kernel_size), int(stride))
+
+
+def direct_conv_pack(weight: Tensor, n_tile: int) -> Tensor:
+    """[C_out, C_in, k, k] convolution weights re-packed once into the MFMA B-operand order the kernel streams."""
+    _dev_f32("direct_conv_pack", weight)
+    C_out, C_in, kh, kw = weight.shape
+    nbytes = _capi.lib().dvmvs_direct_conv_packed_bytes(C_out, C_in, kh, int(n_tile)) if kh == kw else 0
+    if nbytes == 0:
+        raise ValueError(f"dvmvs::direct_conv_pack: need a 3x3 or 5x5 kernel and C_out % (16 * n_tile) == 0, got {tuple(weight.shape)}, n_tile {n_tile}")
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = _capi.lib().dvmvs_direct_conv_pack(_ptr(weight.contiguous()), _ptr(packed), C_out, C_in, kh, int(n_tile), _stream(weight))
+    _capi.check(rc, "dvmvs_direct_conv_pack")
+    return packed
+
+
+def direct_conv_into(x: Tensor, packed: Tensor, n_tile: int, bias, dst: Tensor, C_out: int, kernel_size: int, stride: int, activation: int) -> Tensor:
+    """dst = act(conv2d(x, W, padding = k // 2, stride) + bias) with ``direct_conv_pack``-ed weights; ``dst`` a dense [B,C_out,H/s,W/s]
+    tensor or a channel slice of a concatenation buffer; activation "none" or "relu"."""
+    _dev_f32("direct_conv_into", x, packed, dst)
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("dvmvs::direct_conv_into: expected a contiguous NCHW input")
+    B, C_in, H, W = x.shape
+    batch_stride = _slice_batch_stride("direct_conv_into", dst, B, int(C_out), H // stride, W // stride)
+    if bias is not None and bias.numel() not in (0, C_out):
+        raise ValueError(f"dvmvs::direct_conv_into: bias has {bias.numel()} entries for {C_out} channels")
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().dvmvs_direct_conv_fwd(_ptr(x), 0, _ptr(packed), int(n_tile), _ptr(bias) if bias is not None and bias.numel() else None,
+                                               _ptr(dst), batch_stride, B, C_in, H, W, int(C_out), int(kernel_size), int(stride), int(activation),
+                                               _stream(x))
+    _capi.check(rc, "dvmvs_direct_conv_fwd")
+    return dst
+
+
+def conv_head_into(x: Tensor, weight: Tensor, bias, dst: Tensor, activation: int = 0, p0: float = 0.0, p1: float = 0.0) -> Tensor:
+    """3x3, padding 1 convolution with ONE output channel (the decoder's depth heads): dst [B,1,H,W] = act(conv(x, weight) + bias);
+    bias None and activation 0: the raw convolution output (the consumer applies bias + activation)."""
+    _dev_f32("conv_head_into", x, weight, dst)
+    if x.dim() != 4 or not x.is_contiguous() or tuple(weight.shape) != (1, x.shape[1], 3, 3) or not weight.is_contiguous():
+        raise ValueError(f"dvmvs::conv_head_into: expected a contiguous NCHW input and a [1,{x.shape[1]},3,3] weight, got {tuple(x.shape)}, {tuple(weight.shape)}")
+    B, C_in, H, W = x.shape
+    batch_stride = _slice_batch_stride("conv_head_into", dst, B, 1, H, W)
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().dvmvs_conv_head_fwd(_ptr(x), 0, _ptr(weight), _ptr(bias) if bias is not None and bias.numel() else None, _ptr(dst),
+                                             batch_stride, B, C_in, H, W, int(activation), float(p0), float(p1), _stream(x))
+    _capi.check(rc, "dvmvs_conv_head_fwd")
+    return dst
+
+
 def lstm_gates_partials_into(conv_partials: Tensor, n_partials: int, c_state: Tensor, h_state: Tensor) -> None:
     """``lstm_gates_into`` on a convolution output that arrives as ``n_partials`` partial sums ([split][B][4*hidden][H*W])."""
     _dev_f32("lstm_gates_partials_into", conv_partials, c_state, h_state)

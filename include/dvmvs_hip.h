@@ -28,8 +28,9 @@ extern "C" {
 /* ABI 4 (round 4) = ABI 3 + additions, no signature of ABI 3 changed: variant 3 of dvmvs_cost_volume_fwd, the host-side sweep plan
  * (dvmvs_sweep_plan_stats / _select_variant / _work_list / dvmvs_sweep_plan, dvmvs_cost_volume_planned_fwd), the bottleneck convolution
  * (dvmvs_bottleneck_conv_*, dvmvs_partial_sums_bias_act_fwd, dvmvs_lstm_gates_partials_fwd) and two training gradients
- * (dvmvs_upsample2x_bwd, dvmvs_depthwise_conv_bwd). */
-#define DVMVS_ABI_VERSION 4
+ * (dvmvs_upsample2x_bwd, dvmvs_depthwise_conv_bwd).
+ * ABI 5 = ABI 4 + the direct convolution of the larger maps and the depth heads (dvmvs_direct_conv_*, dvmvs_conv_head_fwd). */
+#define DVMVS_ABI_VERSION 5
 #define DVMVS_MAX_MEASUREMENTS 8      /* measurement frames fused per launch */
 #define DVMVS_MAX_DEPTH_LEVELS 256    /* sweep planes per launch */
 
@@ -251,6 +252,31 @@ int dvmvs_partial_sums_bias_act_fwd(const float* partials, int n_partials, float
                                     int B, int C, int HW, int activation, dvmvs_stream_t stream);
 int dvmvs_lstm_gates_partials_fwd(const float* conv_partials, int n_partials, const float* c_cur, float* h_next, float* c_next,
                                   int B, int hidden, int H, int W, dvmvs_stream_t stream);
+
+/*
+ * Dense 3x3 / 5x5 convolutions ("same" padding k/2, stride 1 or 2) of the 1/8 ... full-resolution maps of a frame as a direct fp32-MFMA
+ * convolution with bias + ReLU in its store path, and the one-output-channel 3x3 depth heads (csrc/direct_conv.hip).  Replace, for the
+ * problems dvmvs_direct_conv_tile accepts, the nn.Conv2d + BatchNorm(folded) + ReLU of the cost-volume encoder / decoder, the FPN's
+ * smoothing layers and the stem (/root/reference/dvmvs/fusionnet/model.py:167-305, dvmvs/layers.py conv_layer) at inference; no
+ * gradient.  Deterministic: input-channel splits are added through LDS in a fixed order.
+ *   dvmvs_direct_conv_tile          0 when the kernel does not take the problem (output width not a multiple of 40, C_out % 16 != 0,
+ *                                   other kernel sizes / strides: the caller keeps its library convolution); else the number of
+ *                                   16-channel output tiles per wave (1 or 2) the weights have to be packed for
+ *   dvmvs_direct_conv_pack          weight [C_out,C_in,k,k] -> packed (dvmvs_direct_conv_packed_bytes), once per (layer, n_tile)
+ *   dvmvs_direct_conv_fwd           x [B,C_in,H,W] (batch item b at x + b*x_batch_stride, 0 = dense) -> dst [B,C_out,H/stride,W/stride]
+ *                                   (batch item b at dst + b*dst_batch_stride, 0 = dense: a channel slice of a concatenation buffer);
+ *                                   bias may be NULL; activation 0 none, 1 ReLU; DVMVS_EINVAL when n_tile is not the problem's
+ *   dvmvs_conv_head_fwd             3x3, padding 1, ONE output channel: weight [1,C_in,3,3]; dst [B,1,H,W]; bias may be NULL (raw
+ *                                   convolution output when also activation == 0); activation / p0 / p1 as dvmvs_bias_act_fwd
+ */
+int dvmvs_direct_conv_tile(int B, int C_in, int H, int W, int C_out, int kernel_size, int stride);
+size_t dvmvs_direct_conv_packed_bytes(int C_out, int C_in, int kernel_size, int n_tile);
+int dvmvs_direct_conv_pack(const float* weight, float* packed, int C_out, int C_in, int kernel_size, int n_tile, dvmvs_stream_t stream);
+int dvmvs_direct_conv_fwd(const float* x, long long x_batch_stride, const float* packed, int n_tile, const float* bias, float* dst,
+                          long long dst_batch_stride, int B, int C_in, int H, int W, int C_out, int kernel_size, int stride, int activation,
+                          dvmvs_stream_t stream);
+int dvmvs_conv_head_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias, float* dst,
+                        long long dst_batch_stride, int B, int C_in, int H, int W, int activation, float p0, float p1, dvmvs_stream_t stream);
 
 /*
  * Forward splat (z-buffer, farthest wins) of the previous full-resolution depth into the current view at half
