@@ -71,7 +71,11 @@ struct DirectConvConfig {
   static constexpr int PATCH = CIC * PH * PWD;
   static constexpr int XREGS = (PATCH + NT - 1) / NT;
   static constexpr int RED_FLOATS = (KS > 1) ? (KS / 2) * PW * MT * NTILE * 256 : 0;    // one round of the split tree
-  static constexpr int LDS_FLOATS = (CIC * CS > RED_FLOATS) ? CIC * CS : RED_FLOATS;
+  static constexpr int BUF = CIC * CS;                          // floats of one staged chunk
+  static constexpr bool PREFETCH = S == 1 && XREGS <= 28;       // the next chunk's patch waits in registers while this one is multiplied
+  static constexpr bool DOUBLE = PREFETCH && sizeof(float) * 2 * BUF <= 150 * 1024;    // two patch buffers: the next chunk is written while this one is read
+  static constexpr bool WHOLE = DOUBLE && K == 3 && NS * Q <= 6;           // a whole chunk's weights are requested one chunk ahead
+  static constexpr int LDS_FLOATS = ((DOUBLE ? 2 : 1) * BUF > RED_FLOATS) ? (DOUBLE ? 2 : 1) * BUF : RED_FLOATS;
   static_assert(MW == 16 || MW == 8, "tile shape");
   static_assert(NWAVES == 8 && NS >= 2 && (kDcGroupPad % (KS * G)) == 0 && (KS & (KS - 1)) == 0, "workgroup shape");
   static_assert(sizeof(float) * LDS_FLOATS <= 160 * 1024, "LDS");
@@ -93,23 +97,42 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
   const int HW = a.H * a.W;
   gcfloat_p xg = as_global(a.x) + static_cast<size_t>(b) * a.x_batch_stride;
 
-  // ---- patch staging: element e = tid + i * NT of the chunk's [CIC][PH][PWD] patch, zero outside the image / beyond C_in.  PREFETCH:
-  // the next chunk's elements wait in registers while this chunk is multiplied (stride-2 patches are too large for that: they are
-  // staged in pieces of eight elements per thread between the chunk's barriers) ----
-  constexpr bool PREFETCH = XREGS <= 28;
-  auto load_element = [&](int chunk, int i) __attribute__((always_inline)) -> float {
+  // ---- patch staging: element e = tid + i * NT of the chunk's [CIC][PH][PWD] patch, zero outside the image / beyond C_in.
+  // Raw buffer descriptor over this batch item's input: a load whose byte offset is >= num_records returns 0 without touching memory
+  // -- the zero padding ring costs no branch --, an element's offset inside a chunk never changes (computed once, up front) and the
+  // chunk's channel offset rides in the scalar offset operand: a staged element is one buffer_load_dword, no address arithmetic
+  // (per-element bounds branches + 64-bit address multiplies were ~600 instructions per chunk in front of 45 MFMAs).
+  // PREFETCH: the next chunk's elements wait in registers while this chunk is multiplied (stride-2 patches are too large for that:
+  // they are staged in pieces of eight elements per thread between the chunk's barriers) ----
+  constexpr bool PREFETCH = Cfg::PREFETCH, DOUBLE = Cfg::DOUBLE, WHOLE = Cfg::WHOLE;
+  constexpr int BUF = Cfg::BUF;
+  const __amdgpu_buffer_rsrc_t x_resource =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, static_cast<int>(sizeof(float) * static_cast<unsigned int>(a.C_in) * HW), 0x00020000);
+  constexpr unsigned int kOutOfRange = 0x80000000u;      // > any offset inside an input (inputs are < 2 GiB, checked on the host)
+  auto element_offset = [&](int i) __attribute__((always_inline)) -> unsigned int {
     const int e = tid + i * NT;
     const int ch = e / (PH * PWD), rem = e - ch * (PH * PWD);
     const int row = rem / PWD, col = rem - row * PWD;
-    const int c = chunk * CIC + ch, iy = iy0 + row, ix = ix0 + col;
-    const bool in = e < PATCH && c < a.C_in && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    return in ? xg[static_cast<size_t>(c) * HW + iy * a.W + ix] : 0.0f;
+    const int iy = iy0 + row, ix = ix0 + col;
+    const bool in = e < PATCH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    return in ? static_cast<unsigned int>(sizeof(float)) * static_cast<unsigned int>(ch * HW + iy * a.W + ix) : kOutOfRange;
   };
-  auto store_element = [&](int i, float v) __attribute__((always_inline)) {
+  unsigned int x_offset[PREFETCH ? XREGS : 1];
+  if (PREFETCH) {
+#pragma unroll
+    for (int i = 0; i < XREGS; ++i) x_offset[i] = element_offset(i);
+  }
+  auto load_element = [&](int chunk, int i) __attribute__((always_inline)) -> float {
+    const unsigned int offset = PREFETCH ? x_offset[i] : element_offset(i);
+    const bool live = chunk * CIC + (tid + i * NT) / (PH * PWD) < a.C_in;      // (a ragged last chunk, and the chunk behind the last)
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_resource, static_cast<int>(live ? offset : kOutOfRange),
+                                                                          static_cast<int>(sizeof(float) * static_cast<unsigned int>(chunk * CIC) * HW), 0));
+  };
+  auto store_element = [&](float* buffer, int i, float v) __attribute__((always_inline)) {
     const int e = tid + i * NT;
     const int ch = e / (PH * PWD), rem = e - ch * (PH * PWD);
     const int row = rem / PWD, col = rem - row * PWD;
-    if (e < PATCH) s_x[ch * CS + row * RS + col] = v;
+    if (e < PATCH) buffer[ch * CS + row * RS + col] = v;
   };
   float xr[PREFETCH ? XREGS : 1];
   auto load_patch = [&](int chunk) __attribute__((always_inline)) {
@@ -118,10 +141,10 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
       for (int i = 0; i < XREGS; ++i) xr[i] = load_element(chunk, i);
     }
   };
-  auto store_patch = [&](int chunk) __attribute__((always_inline)) {
+  auto store_patch = [&](int chunk, float* buffer) __attribute__((always_inline)) {
     if (PREFETCH) {
 #pragma unroll
-      for (int i = 0; i < XREGS; ++i) store_element(i, xr[i]);
+      for (int i = 0; i < XREGS; ++i) store_element(buffer, i, xr[i]);
     } else {
 #pragma unroll 1
       for (int i0 = 0; i0 < XREGS; i0 += 8) {
@@ -129,7 +152,7 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
 #pragma unroll
         for (int i = 0; i < 8; ++i) piece[i] = load_element(chunk, i0 + i);      // (elements beyond the patch load nothing)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) store_element(i0 + i, piece[i]);
+        for (int i = 0; i < 8; ++i) store_element(buffer, i0 + i, piece[i]);
       }
     }
   };
@@ -138,6 +161,7 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
   const float4v DVMVS_GLOBAL* wq = reinterpret_cast<const float4v DVMVS_GLOBAL*>(as_global(a.packed)) +
                                    static_cast<size_t>(cot) * a.packed_groups * (K * Q * 64) + lane;
   auto load_weights = [&](float4v* w, int cg, int ky) __attribute__((always_inline)) {
+    cg = min(cg, a.packed_groups - 1);      // (requests for the chunk behind the last one are issued unconditionally, see below)
 #pragma unroll
     for (int q = 0; q < Q; ++q) w[q] = wq[(static_cast<size_t>(cg) * K + ky) * (Q * 64) + q * 64];
   };
@@ -152,46 +176,91 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
 #pragma unroll
     for (int nt = 0; nt < NTILE; ++nt) acc[mt][nt] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
 
-  float4v wb[2][Q], w_next[Q];
-  load_patch(0);
-  load_weights(w_next, ks * G, 0);
-  store_patch(0);
-  __syncthreads();
-
-  for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
-    const bool more = chunk + 1 < a.n_chunks;
-    const int cg0 = (chunk * KS + ks) * G;
+  // one (group gg, row ky) step of a chunk: K taps x MT pixel tiles x NTILE channel tiles, A from the patch in `buffer`, B = w
+  auto multiply_step = [&](const float* buffer, int gg, int ky, const float4v* w) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) wb[0][q] = w_next[q];
+    for (int kx = 0; kx < K; ++kx) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int gg = s / K, ky = s % K;
-      if (s + 1 < NS) load_weights(wb[(s + 1) & 1], cg0 + (s + 1) / K, (s + 1) % K);
-      if (s == NS - 2 && more) load_patch(chunk + 1);                              // (younger than every weight request of this chunk)
-      if (s == NS - 1 && more) load_weights(w_next, ((chunk + 1) * KS + ks) * G, 0);
-      __builtin_amdgcn_sched_barrier(0);   // requests stay in front of the step's MFMAs (the scheduler otherwise sinks them to their uses)
-      if (cg0 + gg < a.n_groups) {         // wave-uniform: groups beyond C_in are all-zero padding
+      for (int mt = 0; mt < MT; ++mt) {
+        const float av = buffer[a_base + gg * 4 * CS + ky * RS + kx + mt * MW * S];
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const float av = s_x[a_base + gg * 4 * CS + ky * RS + kx + mt * MW * S];
-#pragma unroll
-            for (int nt = 0; nt < NTILE; ++nt) {
-              const int j = kx * NTILE + nt;
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wb[s & 1][j / 4][j % 4], acc[mt][nt], 0, 0, 0);
-            }
-          }
+        for (int nt = 0; nt < NTILE; ++nt) {
+          const int j = kx * NTILE + nt;
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[j / 4][j % 4], acc[mt][nt], 0, 0, 0);
         }
       }
-      // the padding elements of the step's last quad stay "in use" until here: otherwise their registers are handed to the ds_reads
-      // above while the quad's load is still in flight, and that write-after-write hazard costs an s_waitcnt vmcnt(0) per step
-      asm volatile("" ::"v"(wb[s & 1][Q - 1]));
     }
-    __syncthreads();       // every wave has read its part of this chunk's patch
-    if (more) {
-      store_patch(chunk + 1);
+  };
+
+  // Requests for the NEXT chunk (its patch, its weights) are issued unconditionally, also behind the last chunk, where the patch
+  // requests are all out of range and the weights are not used: with requests and their waits under conditions the compiler's
+  // s_waitcnt placement waits for the new requests in front of this chunk's MFMAs.
+  if (WHOLE) {
+    // 3x3 layers: all NS x Q quads of a chunk's weights and the chunk's patch are requested one whole chunk ahead, nothing is
+    // requested in between (s_waitcnt vmcnt retires in order: any younger request would drag the wait for the patch forward), the
+    // patch goes into the other LDS buffer when this chunk's MFMAs are done: one barrier per chunk.  Two weight register sets swap
+    // roles from chunk to chunk (the loop is unrolled by two): copying "ahead" into "current" makes the compiler wait for the
+    // requests right where they are issued.
+    float4v w_even[NS][Q], w_odd[NS][Q];
+    auto whole_chunk = [&](int chunk, float4v(*w_use)[Q], float4v(*w_load)[Q]) __attribute__((always_inline)) {
+      const int cg0 = (chunk * KS + ks) * G;
+      const float* buffer = s_x + (chunk & 1) * BUF;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) load_weights(w_load[s], ((chunk + 1) * KS + ks) * G + s / K, s % K);
+      load_patch(chunk + 1);
+      __builtin_amdgcn_sched_barrier(0);   // requests stay in front of the chunk's MFMAs (the scheduler otherwise sinks them to their uses)
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        if (cg0 + s / K < a.n_groups) multiply_step(buffer, s / K, s % K, w_use[s]);      // wave-uniform: groups beyond C_in are zero padding
+      // the padding elements of the quads stay "in use" until here: otherwise their registers are handed out while the quad's load is
+      // still in flight, and that write-after-write hazard costs an s_waitcnt vmcnt(0) in front of the MFMAs
+#pragma unroll
+      for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(w_load[s][Q - 1]), "v"(w_use[s][Q - 1]));
+      store_patch(chunk + 1, s_x + ((chunk + 1) & 1) * BUF);
       __syncthreads();
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) load_weights(w_even[s], ks * G + s / K, s % K);
+    load_patch(0);
+    store_patch(0, s_x);
+    __syncthreads();
+    for (int chunk = 0; chunk < a.n_chunks; chunk += 2) {
+      whole_chunk(chunk, w_even, w_odd);
+      if (chunk + 1 < a.n_chunks) whole_chunk(chunk + 1, w_odd, w_even);
+    }
+  } else {
+    // 5x5 layers: weights one (group, ky) step ahead of the MFMAs that use them; the next chunk's patch is requested after the last
+    // weight request of this chunk, so that the MFMAs of the last two steps wait for weights only
+    float4v wb[2][Q], w_next[Q];
+    load_patch(0);
+    load_weights(w_next, ks * G, 0);
+    store_patch(0, s_x);
+    __syncthreads();
+    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+      const bool more = chunk + 1 < a.n_chunks;
+      const int cg0 = (chunk * KS + ks) * G;
+      const float* buffer = s_x + (DOUBLE ? (chunk & 1) * BUF : 0);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) wb[0][q] = w_next[q];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) load_weights(wb[(s + 1) & 1], cg0 + (s + 1) / K, (s + 1) % K);
+        if (s == NS - 2 && (more || DOUBLE)) load_patch(chunk + 1);                  // (younger than every weight request of this chunk)
+        if (s == NS - 1 && (more || DOUBLE)) load_weights(w_next, ((chunk + 1) * KS + ks) * G, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cg0 + s / K < a.n_groups) multiply_step(buffer, s / K, s % K, wb[s & 1]);
+        asm volatile("" ::"v"(wb[s & 1][Q - 1]));      // (as above)
+      }
+      if (DOUBLE) {
+        store_patch(chunk + 1, s_x + ((chunk + 1) & 1) * BUF);
+        __syncthreads();
+      } else {
+        __syncthreads();       // every wave has read its part of this chunk's patch
+        if (more) {
+          store_patch(chunk + 1, s_x);
+          __syncthreads();
+        }
+      }
     }
   }
 
@@ -437,6 +506,7 @@ extern "C" int dvmvs_direct_conv_fwd(const float* x, long long x_batch_stride, c
   a.x_batch_stride = x_batch_stride ? x_batch_stride : static_cast<long long>(C_in) * H * W;
   a.dst_batch_stride = dst_batch_stride ? dst_batch_stride : static_cast<long long>(C_out) * a.OH * a.OW;
   if (a.x_batch_stride < static_cast<long long>(C_in) * H * W || a.dst_batch_stride < static_cast<long long>(C_out) * a.OH * a.OW) return DVMVS_EINVAL;
+  if (static_cast<long long>(C_in + 64) * H * W * 4 >= (1LL << 31)) return DVMVS_EUNSUPPORTED;      // 32-bit byte offsets into one batch item (incl. a padded chunk)
   a.act = activation;
   a.n_groups = (C_in + 3) / 4;
   a.packed_groups = dc_packed_groups(C_in);
