@@ -49,6 +49,18 @@ struct DirectConvArgs {
   int vec4;              // the destination allows 16-byte stores
 };
 
+// ---- optional timeline instrumentation (tools/direct_conv_trace.py; built only by `make trace`): per wave, on the 100 MHz wall clock:
+// [0] start, [1] first patch staged, [2] sum over chunks of "requests issued", [3] of "MFMAs", [4] of "patch stored + barrier",
+// [5] chunk loop left, [6] channel splits added, [7] end ----
+#ifdef DVMVS_SWEEP_TRACE
+constexpr int kDcTraceWords = 8, kDcTraceWaves = 16384;
+__device__ unsigned long long g_dc_trace[kDcTraceWaves * kDcTraceWords];
+#define DC_TRACE(...) __VA_ARGS__
+#define DC_NOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define DC_TRACE(...)
+#endif
+
 constexpr int kDcGroupPad = 16;   // packed input-channel groups are padded (with zeros) to a multiple of every KS * G in use
 
 __host__ __device__ constexpr int dc_round_to_residue(int v, int mod, int res) { return v + ((res - v) % mod + mod) % mod; }
@@ -63,20 +75,24 @@ struct DirectConvConfig {
   static constexpr int NWAVES = PW * KS, NT = 64 * NWAVES;
   static constexpr int CIC = 4 * KS * G;                        // input channels per staged chunk
   static constexpr int TILE_H = PW * MH, TILE_W = MW * MT;      // output pixels of a workgroup
-  static constexpr int PH = (TILE_H - 1) * S + K, PWD = (TILE_W - 1) * S + K;   // its input patch
+  // its input patch: PH rows; columns from the 16-byte boundary 4 floats left of the first output pixel's input column to the one
+  // behind the last tap -- every row of the patch is then a run of ALIGNED float4 in the image (widths are multiples of 4), each
+  // either inside the image or entirely outside it: one buffer_load_dwordx4 + one ds_write_b128 per four elements
+  static constexpr int PH = (TILE_H - 1) * S + K, PWD = TILE_W * S + 8, PWD4 = PWD / 4;
+  static constexpr int SHIFT = 4 - K / 2;                                       // patch column of (first output pixel, tap 0)
   static constexpr int RS = (MH == 1) ? PWD : dc_round_to_residue(PWD, 16, 8);  // patch row stride in LDS (floats)
   static constexpr int CS = dc_round_to_residue(PH * RS, 64, 16);               // channel stride
   static constexpr int Q = (NTILE * K + 3) / 4;                 // float4 per lane and (group, ky) step: K taps x NT output-channel tiles
   static constexpr int NS = G * K;                              // steps per chunk and wave
-  static constexpr int PATCH = CIC * PH * PWD;
-  static constexpr int XREGS = (PATCH + NT - 1) / NT;
+  static constexpr int PATCH = CIC * PH * PWD4;                 // float4 elements of a staged chunk
+  static constexpr int XREGS = (PATCH + NT - 1) / NT;           // ... per thread
   static constexpr int RED_FLOATS = (KS > 1) ? (KS / 2) * PW * MT * NTILE * 256 : 0;    // one round of the split tree
   static constexpr int BUF = CIC * CS;                          // floats of one staged chunk
-  static constexpr bool PREFETCH = S == 1 && XREGS <= 28;       // the next chunk's patch waits in registers while this one is multiplied
+  static constexpr bool PREFETCH = XREGS <= 8;                  // the next chunk's patch waits in registers while this one is multiplied
   static constexpr bool DOUBLE = PREFETCH && sizeof(float) * 2 * BUF <= 150 * 1024;    // two patch buffers: the next chunk is written while this one is read
   static constexpr bool WHOLE = DOUBLE && K == 3 && NS * Q <= 6;           // a whole chunk's weights are requested one chunk ahead
   static constexpr int LDS_FLOATS = ((DOUBLE ? 2 : 1) * BUF > RED_FLOATS) ? (DOUBLE ? 2 : 1) * BUF : RED_FLOATS;
-  static_assert(MW == 16 || MW == 8, "tile shape");
+  static_assert((MW == 16 || MW == 8) && (TILE_W * S) % 4 == 0 && RS % 4 == 0 && CS % 4 == 0, "tile shape");
   static_assert(NWAVES == 8 && NS >= 2 && (kDcGroupPad % (KS * G)) == 0 && (KS & (KS - 1)) == 0, "workgroup shape");
   static_assert(sizeof(float) * LDS_FLOATS <= 160 * 1024, "LDS");
 };
@@ -84,7 +100,7 @@ struct DirectConvConfig {
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) {
   constexpr int K = Cfg::K, S = Cfg::S, MW = Cfg::MW, MT = Cfg::MT, NTILE = Cfg::NTILE, PW = Cfg::PW, KS = Cfg::KS, G = Cfg::G;
-  constexpr int MH = Cfg::MH, NT = Cfg::NT, CIC = Cfg::CIC, PH = Cfg::PH, PWD = Cfg::PWD, RS = Cfg::RS, CS = Cfg::CS, Q = Cfg::Q, NS = Cfg::NS;
+  constexpr int MH = Cfg::MH, NT = Cfg::NT, CIC = Cfg::CIC, PH = Cfg::PH, PWD4 = Cfg::PWD4, RS = Cfg::RS, CS = Cfg::CS, Q = Cfg::Q, NS = Cfg::NS;
   constexpr int XREGS = Cfg::XREGS, PATCH = Cfg::PATCH;
   extern __shared__ __attribute__((aligned(16))) float s_x[];   // [CIC][CS]: the chunk's patch; afterwards the channel-split partial sums
 
@@ -93,17 +109,27 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
   const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
   const int cot = blockIdx.y, b = blockIdx.z;
   const int oy0 = ty * Cfg::TILE_H, ox0 = tx * Cfg::TILE_W;
-  const int iy0 = oy0 * S - K / 2, ix0 = ox0 * S - K / 2;
+  const int iy0 = oy0 * S - K / 2, ix0 = ox0 * S - 4;      // (the patch starts on a 16-byte boundary)
   const int HW = a.H * a.W;
+  DC_TRACE(const unsigned long long tr_start = DC_NOW(); unsigned long long tr_first = 0, tr_req = 0, tr_mfma = 0, tr_store = 0, tr_loop = 0, tr_red = 0, tr_a = 0, tr_b = 0, tr_c = 0;
+           auto dump_trace = [&]() __attribute__((always_inline)) {
+             const unsigned long long tr_end = DC_NOW();
+             const size_t wv = (static_cast<size_t>(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * Cfg::NWAVES + (threadIdx.x >> 6);
+             if ((threadIdx.x & 63) == 0 && wv < kDcTraceWaves) {
+               unsigned long long* t = g_dc_trace + wv * kDcTraceWords;
+               t[0] = tr_start; t[1] = tr_first; t[2] = tr_req; t[3] = tr_mfma; t[4] = tr_store; t[5] = tr_loop; t[6] = tr_red; t[7] = tr_end;
+             }
+           };)
   gcfloat_p xg = as_global(a.x) + static_cast<size_t>(b) * a.x_batch_stride;
 
-  // ---- patch staging: element e = tid + i * NT of the chunk's [CIC][PH][PWD] patch, zero outside the image / beyond C_in.
+  // ---- patch staging: float4 element e = tid + i * NT of the chunk's [CIC][PH][PWD4] patch, zero outside the image / beyond C_in.
   // Raw buffer descriptor over this batch item's input: a load whose byte offset is >= num_records returns 0 without touching memory
   // -- the zero padding ring costs no branch --, an element's offset inside a chunk never changes (computed once, up front) and the
-  // chunk's channel offset rides in the scalar offset operand: a staged element is one buffer_load_dword, no address arithmetic
-  // (per-element bounds branches + 64-bit address multiplies were ~600 instructions per chunk in front of 45 MFMAs).
+  // chunk's channel offset rides in the scalar offset operand: a staged element is one buffer_load_dwordx4, no address arithmetic
+  // (per-element bounds branches + 64-bit address multiplies were ~600 instructions per chunk in front of 45 MFMAs; dword elements
+  // kept the eight waves of a workgroup 0.6 us per chunk in the memory pipeline's issue queue, tools/direct_conv_trace.py).
   // PREFETCH: the next chunk's elements wait in registers while this chunk is multiplied (stride-2 patches are too large for that:
-  // they are staged in pieces of eight elements per thread between the chunk's barriers) ----
+  // they are staged in pieces of four elements per thread between the chunk's barriers) ----
   constexpr bool PREFETCH = Cfg::PREFETCH, DOUBLE = Cfg::DOUBLE, WHOLE = Cfg::WHOLE;
   constexpr int BUF = Cfg::BUF;
   const __amdgpu_buffer_rsrc_t x_resource =
@@ -111,10 +137,10 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
   constexpr unsigned int kOutOfRange = 0x80000000u;      // > any offset inside an input (inputs are < 2 GiB, checked on the host)
   auto element_offset = [&](int i) __attribute__((always_inline)) -> unsigned int {
     const int e = tid + i * NT;
-    const int ch = e / (PH * PWD), rem = e - ch * (PH * PWD);
-    const int row = rem / PWD, col = rem - row * PWD;
-    const int iy = iy0 + row, ix = ix0 + col;
-    const bool in = e < PATCH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const int ch = e / (PH * PWD4), rem = e - ch * (PH * PWD4);
+    const int row = rem / PWD4, col4 = rem - row * PWD4;
+    const int iy = iy0 + row, ix = ix0 + 4 * col4;
+    const bool in = e < PATCH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;      // (ix and W are multiples of 4: all four columns or none)
     return in ? static_cast<unsigned int>(sizeof(float)) * static_cast<unsigned int>(ch * HW + iy * a.W + ix) : kOutOfRange;
   };
   unsigned int x_offset[PREFETCH ? XREGS : 1];
@@ -122,19 +148,19 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
 #pragma unroll
     for (int i = 0; i < XREGS; ++i) x_offset[i] = element_offset(i);
   }
-  auto load_element = [&](int chunk, int i) __attribute__((always_inline)) -> float {
+  auto load_element = [&](int chunk, int i) __attribute__((always_inline)) -> float4v {
     const unsigned int offset = PREFETCH ? x_offset[i] : element_offset(i);
-    const bool live = chunk * CIC + (tid + i * NT) / (PH * PWD) < a.C_in;      // (a ragged last chunk, and the chunk behind the last)
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_resource, static_cast<int>(live ? offset : kOutOfRange),
-                                                                          static_cast<int>(sizeof(float) * static_cast<unsigned int>(chunk * CIC) * HW), 0));
+    const bool live = chunk * CIC + (tid + i * NT) / (PH * PWD4) < a.C_in;      // (a ragged last chunk, and the chunk behind the last)
+    return __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(x_resource, static_cast<int>(live ? offset : kOutOfRange),
+                                                                             static_cast<int>(sizeof(float) * static_cast<unsigned int>(chunk * CIC) * HW), 0));
   };
-  auto store_element = [&](float* buffer, int i, float v) __attribute__((always_inline)) {
+  auto store_element = [&](float* buffer, int i, float4v v) __attribute__((always_inline)) {
     const int e = tid + i * NT;
-    const int ch = e / (PH * PWD), rem = e - ch * (PH * PWD);
-    const int row = rem / PWD, col = rem - row * PWD;
-    if (e < PATCH) buffer[ch * CS + row * RS + col] = v;
+    const int ch = e / (PH * PWD4), rem = e - ch * (PH * PWD4);
+    const int row = rem / PWD4, col4 = rem - row * PWD4;
+    if (e < PATCH) *reinterpret_cast<float4v*>(buffer + ch * CS + row * RS + 4 * col4) = v;
   };
-  float xr[PREFETCH ? XREGS : 1];
+  float4v xr[PREFETCH ? XREGS : 1];
   auto load_patch = [&](int chunk) __attribute__((always_inline)) {
     if (PREFETCH) {
 #pragma unroll
@@ -147,12 +173,12 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
       for (int i = 0; i < XREGS; ++i) store_element(buffer, i, xr[i]);
     } else {
 #pragma unroll 1
-      for (int i0 = 0; i0 < XREGS; i0 += 8) {
-        float piece[8];
+      for (int i0 = 0; i0 < XREGS; i0 += 4) {
+        float4v piece[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) piece[i] = load_element(chunk, i0 + i);      // (elements beyond the patch load nothing)
+        for (int i = 0; i < 4; ++i) piece[i] = load_element(chunk, i0 + i);      // (elements beyond the patch load nothing)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) store_element(buffer, i0 + i, piece[i]);
+        for (int i = 0; i < 4; ++i) store_element(buffer, i0 + i, piece[i]);
       }
     }
   };
@@ -168,7 +194,7 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
 
   // this lane's A-operand position: input channel (lane >> 4) of a group of four, pixel (lane & 15) of a tile
   const int m = lane & 15;
-  const int a_base = ((lane >> 4) + ks * G * 4) * CS + ((pw * MH + m / MW) * S) * RS + (m % MW) * S;
+  const int a_base = ((lane >> 4) + ks * G * 4) * CS + ((pw * MH + m / MW) * S) * RS + (m % MW) * S + Cfg::SHIFT;
 
   float4v acc[MT][NTILE];
 #pragma unroll
@@ -205,25 +231,30 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
     auto whole_chunk = [&](int chunk, float4v(*w_use)[Q], float4v(*w_load)[Q]) __attribute__((always_inline)) {
       const int cg0 = (chunk * KS + ks) * G;
       const float* buffer = s_x + (chunk & 1) * BUF;
+      DC_TRACE(tr_a = DC_NOW(); __builtin_amdgcn_sched_barrier(0);)
 #pragma unroll
       for (int s = 0; s < NS; ++s) load_weights(w_load[s], ((chunk + 1) * KS + ks) * G + s / K, s % K);
       load_patch(chunk + 1);
       __builtin_amdgcn_sched_barrier(0);   // requests stay in front of the chunk's MFMAs (the scheduler otherwise sinks them to their uses)
+      DC_TRACE(tr_b = DC_NOW(); __builtin_amdgcn_sched_barrier(0);)
 #pragma unroll
       for (int s = 0; s < NS; ++s)
         if (cg0 + s / K < a.n_groups) multiply_step(buffer, s / K, s % K, w_use[s]);      // wave-uniform: groups beyond C_in are zero padding
+      DC_TRACE(__builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[MT - 1][NTILE - 1])); tr_c = DC_NOW(); __builtin_amdgcn_sched_barrier(0);)
       // the padding elements of the quads stay "in use" until here: otherwise their registers are handed out while the quad's load is
       // still in flight, and that write-after-write hazard costs an s_waitcnt vmcnt(0) in front of the MFMAs
 #pragma unroll
       for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(w_load[s][Q - 1]), "v"(w_use[s][Q - 1]));
       store_patch(chunk + 1, s_x + ((chunk + 1) & 1) * BUF);
       __syncthreads();
+      DC_TRACE(tr_req += tr_b - tr_a; tr_mfma += tr_c - tr_b; tr_store += DC_NOW() - tr_c;)
     };
 #pragma unroll
     for (int s = 0; s < NS; ++s) load_weights(w_even[s], ks * G + s / K, s % K);
     load_patch(0);
     store_patch(0, s_x);
     __syncthreads();
+    DC_TRACE(tr_first = DC_NOW();)
     for (int chunk = 0; chunk < a.n_chunks; chunk += 2) {
       whole_chunk(chunk, w_even, w_odd);
       if (chunk + 1 < a.n_chunks) whole_chunk(chunk + 1, w_odd, w_even);
@@ -236,12 +267,14 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
     load_weights(w_next, ks * G, 0);
     store_patch(0, s_x);
     __syncthreads();
+    DC_TRACE(tr_first = DC_NOW();)
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
       const bool more = chunk + 1 < a.n_chunks;
       const int cg0 = (chunk * KS + ks) * G;
       const float* buffer = s_x + (DOUBLE ? (chunk & 1) * BUF : 0);
 #pragma unroll
       for (int q = 0; q < Q; ++q) wb[0][q] = w_next[q];
+      DC_TRACE(tr_a = tr_b = DC_NOW(); __builtin_amdgcn_sched_barrier(0);)
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         if (s + 1 < NS) load_weights(wb[(s + 1) & 1], cg0 + (s + 1) / K, (s + 1) % K);
@@ -251,9 +284,11 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
         if (cg0 + s / K < a.n_groups) multiply_step(buffer, s / K, s % K, wb[s & 1]);
         asm volatile("" ::"v"(wb[s & 1][Q - 1]));      // (as above)
       }
+      DC_TRACE(__builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[MT - 1][NTILE - 1])); tr_c = DC_NOW(); __builtin_amdgcn_sched_barrier(0);)
       if (DOUBLE) {
         store_patch(chunk + 1, s_x + ((chunk + 1) & 1) * BUF);
         __syncthreads();
+        DC_TRACE(tr_mfma += tr_c - tr_b; tr_store += DC_NOW() - tr_c;)
       } else {
         __syncthreads();       // every wave has read its part of this chunk's patch
         if (more) {
@@ -264,6 +299,7 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
     }
   }
 
+  DC_TRACE(tr_loop = DC_NOW();)
   // ---- channel splits: a fixed binary tree through LDS -- (0 + 4) + (2 + 6) + ((1 + 5) + (3 + 7)) for eight --, each round the
   // upper half of the remaining waves hands its sums to the lower half ----
   if (KS > 1) {
@@ -285,13 +321,20 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
       }
       if (half > 1) __syncthreads();
     }
-    if (ks > 0) return;
+    if (ks > 0) {
+      DC_TRACE(tr_red = DC_NOW(); dump_trace();)
+      return;
+    }
   }
 
   // ---- epilogue: D[row = (lane >> 4) * 4 + r][col = lane & 15] = pixel (lane >> 4) * 4 + r of the tile, output channel lane & 15 ----
   const int m0 = (lane >> 4) * 4;
   const int oy = oy0 + pw * MH + m0 / MW;
-  if (oy >= a.OH) return;
+  DC_TRACE(tr_red = DC_NOW();)
+  if (oy >= a.OH) {
+    DC_TRACE(dump_trace();)
+    return;
+  }
   gfloat_p dst = as_global(a.dst) + static_cast<size_t>(b) * a.dst_batch_stride;
 #pragma unroll
   for (int nt = 0; nt < NTILE; ++nt) {
@@ -316,6 +359,7 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
       }
     }
   }
+  DC_TRACE(dump_trace();)
 }
 
 // packed[((((cot * GP + cg) * K + ky) * Q + q) * 64 + lane) * 4 + e] = W[16 NT cot + 16 nt + (lane & 15)][4 cg + (lane >> 4)][ky][kx],
@@ -506,6 +550,7 @@ extern "C" int dvmvs_direct_conv_fwd(const float* x, long long x_batch_stride, c
   a.x_batch_stride = x_batch_stride ? x_batch_stride : static_cast<long long>(C_in) * H * W;
   a.dst_batch_stride = dst_batch_stride ? dst_batch_stride : static_cast<long long>(C_out) * a.OH * a.OW;
   if (a.x_batch_stride < static_cast<long long>(C_in) * H * W || a.dst_batch_stride < static_cast<long long>(C_out) * a.OH * a.OW) return DVMVS_EINVAL;
+  if (W % 4 != 0 || a.x_batch_stride % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return DVMVS_EUNSUPPORTED;      // aligned float4 rows
   if (static_cast<long long>(C_in + 64) * H * W * 4 >= (1LL << 31)) return DVMVS_EUNSUPPORTED;      // 32-bit byte offsets into one batch item (incl. a padded chunk)
   a.act = activation;
   a.n_groups = (C_in + 3) / 4;
@@ -536,3 +581,10 @@ extern "C" int dvmvs_conv_head_fwd(const float* x, long long x_batch_stride, con
   }
   return launch_status();
 }
+
+#ifdef DVMVS_SWEEP_TRACE
+extern "C" int dvmvs_debug_direct_conv_trace(unsigned long long* host, int waves) {
+  if (waves > dvmvs::kDcTraceWaves) waves = dvmvs::kDcTraceWaves;
+  return static_cast<int>(hipMemcpyFromSymbol(host, HIP_SYMBOL(dvmvs::g_dc_trace), sizeof(unsigned long long) * dvmvs::kDcTraceWords * waves));
+}
+#endif
