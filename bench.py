@@ -15,6 +15,7 @@ Extra objects on the line:
                       box's host cores on a bounded sample of the same sequence (rank 0, N = 1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -48,9 +49,10 @@ def parse():
     ap.add_argument("--no-feature-cache", action="store_true", help="recompute measurement features every frame like the reference")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-lstm-channels-last", action="store_true")
-    ap.add_argument("--lookahead", type=int, default=2, choices=[0, 1, 2],
+    ap.add_argument("--lookahead", type=int, default=1, choices=[0, 1, 2],
                     help="what the engine is told about the NEXT keyframe: 0 nothing (every stage of a frame on the frame's own stream), 1 its "
                          "image (feature extraction a frame ahead, on a second stream), 2 also its poses (plane sweep + encoder a frame ahead as well)")
+    ap.add_argument("--keep-gc", action="store_true", help="leave CPython's cyclic garbage collector on during the timed steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-reps", type=int, default=10)
@@ -589,7 +591,7 @@ def main():
     modules = build_modules()
     engine = DepthEngine(*modules, device=device, fold_bn=not args.no_fold_bn, cache_features=not args.no_feature_cache,
                          use_graphs=not args.no_graphs, channels_last=args.channels_last,
-                         lstm_channels_last=not args.no_lstm_channels_last)
+                         lstm_channels_last=not args.no_lstm_channels_last, max_lookahead=args.lookahead)
     engine.graph_debug = True
     M = args.measurement_frames
     n_images = 32
@@ -636,10 +638,23 @@ def main():
         def region_start():      # (host time is counted over the timed steps only: warm-up steps run eagerly and capture graphs)
             host_seconds[0], host_seconds[1] = 0.0, 0
             step_events.clear()
+            if not args.keep_gc:
+                # CPython's cyclic collector is off during the timed steps, as in the standard library's timeit: its full collection is
+                # a 4-6 ms host pause at an allocation count that falls a few steps into every run (found with gc.callbacks: one step of
+                # 5.5 ms among twenty of 0.85 ms; gc.freeze() alone only moves it).  Everything allocated so far is collected and frozen
+                # first; the collector is switched back on after the timed region.
+                gc.collect()
+                gc.freeze()
+                gc.disable()
             if mark is not None:
                 mark()
 
-        elapsed = timed_region(lambda i: run_frame(M + i), args.warmup, args.steps, world, device, before=region_start, after=mark)
+        def region_end():
+            if mark is not None:
+                mark()
+            gc.enable()
+
+        elapsed = timed_region(lambda i: run_frame(M + i), args.warmup, args.steps, world, device, before=region_start, after=region_end)
         host_ms = 1e3 * host_seconds[0] / max(host_seconds[1], 1)
     depth_mean = float(engine._static["depth"].mean())
     assert np.isfinite(depth_mean), "non-finite depth"

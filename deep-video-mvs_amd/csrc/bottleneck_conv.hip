@@ -69,13 +69,28 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
   const int b = blockIdx.z / PG, pg = blockIdx.z - b * PG;
   const int c0 = split * a.cs;
 
-  // ---- stage x[b, c0 : c0 + cs] into LDS ----
+  // ---- stage x[b, c0 : c0 + cs] into LDS: eight elements per thread in flight at a time, the zero ring through out-of-range
+  // offsets of a raw buffer descriptor (a branch per element and one load at a time took a third of the kernel) ----
   gcfloat_p xg = as_global(a.x) + (static_cast<size_t>(b) * a.C_in + c0) * (H_IN * W_IN);
-  for (int i = tid; i < a.cs * PLANE; i += kBcWaves * 64) {
-    const int c = i / PLANE, r = i - c * PLANE;
-    const int yy = r / PW, xx = r - yy * PW;
-    const bool in = yy >= 1 && yy <= H_IN && xx >= 1 && xx <= W_IN;
-    xs[i] = in ? xg[c * (H_IN * W_IN) + (yy - 1) * W_IN + (xx - 1)] : 0.0f;
+  const __amdgpu_buffer_rsrc_t x_resource =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, static_cast<int>(sizeof(float) * static_cast<unsigned int>(a.cs) * (H_IN * W_IN)), 0x00020000);
+  const int staged = a.cs * PLANE;
+  for (int i0 = tid; i0 < staged; i0 += 8 * kBcWaves * 64) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * kBcWaves * 64;
+      const int c = i / PLANE, r = i - c * PLANE;
+      const int yy = r / PW, xx = r - yy * PW;
+      const bool in = i < staged && yy >= 1 && yy <= H_IN && xx >= 1 && xx <= W_IN;
+      const unsigned int offset = in ? static_cast<unsigned int>(sizeof(float)) * static_cast<unsigned int>(c * (H_IN * W_IN) + (yy - 1) * W_IN + (xx - 1)) : 0x80000000u;
+      v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_resource, static_cast<int>(offset), 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * kBcWaves * 64;
+      if (i < staged) xs[i] = v[k];
+    }
   }
   __syncthreads();
   if (n_tile >= a.n_tiles) return;

@@ -344,7 +344,7 @@ class DepthEngine:
     def __init__(self, feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder,
                  device="cuda", min_depth=0.25, max_depth=20.0, n_depth_levels=64, fold_bn=True, cache_features=True,
                  use_graphs=True, cache_size=None, channels_last=False, fuse=True, lstm_channels_last=True, sequences=1,
-                 pose_algebra=None, conv_plans=None, bottleneck_convs=None, direct_convs=None):
+                 pose_algebra=None, conv_plans=None, bottleneck_convs=None, direct_convs=None, max_lookahead=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DepthEngine runs on an MI355X; there is no CPU execution path in this package")
@@ -413,6 +413,13 @@ class DepthEngine:
         self.step_clock = None
         self._parity, self._prefetched = 0, None      # buffer set of the next frame; (frame_id, buffer set) whose reference features are ready
         self._side_stream = torch.cuda.Stream(device=self.device)
+        # how much of the NEXT keyframe a step computes when the caller announces it (step's next_* arguments): 1 its feature extraction,
+        # 2 also its sweep + encoder.  Default 1: with the direct convolution kernels the sweep and the encoder fill the chip on their
+        # own, and running them next to the decoder only makes both slower (MI355X, 100 steps: level 0 / 1 / 2 = 827 / 1091 / 999
+        # frames/s); the feature extractor's small kernels are what overlaps well.  DVMVS_LOOKAHEAD overrides.
+        if max_lookahead is None:
+            max_lookahead = int(os.environ.get("DVMVS_LOOKAHEAD", "1"))
+        self.max_lookahead = max(0, min(2, int(max_lookahead)))
         self.sweep_variant_counts = {}     # frames per sweep configuration (dvmvs_cost_volume_fwd's variant) since construction
         # host-planned work list for the sweep: only where the matrices exist on the host, and one plan per launch (one sequence)
         self.sweep_work_list = bool(_utils.SWEEP_WORK_LIST and self.pose_algebra == "reference" and _utils.COST_VOLUME_VARIANT in (0, 2, 3, 4, 5))
@@ -943,11 +950,11 @@ class DepthEngine:
 
         # ---- how much of the next frame this call computes ----
         give, next_frame, n_meas_next = 0, None, 0
-        if self.direct and next_reference_image is not None:
+        if self.direct and next_reference_image is not None and self.max_lookahead >= 1:
             if tuple(next_reference_image.shape) != tuple(reference_image.shape):
                 raise ValueError("next_reference_image must have the reference image's shape")
             give = 1
-            if next_reference_pose is not None and next_measurement_poses is not None and next_measurement_ids is not None and \
+            if self.max_lookahead >= 2 and next_reference_pose is not None and next_measurement_poses is not None and next_measurement_ids is not None and \
                     next_frame_id is not None and self.pose_algebra == "reference" and self.cache_features and \
                     1 <= len(next_measurement_poses) <= _MAX_MEAS and len(next_measurement_ids) == len(next_measurement_poses) and \
                     all(m is not None and (m in self._feature_cache or (m == frame_id and have >= 1)) for m in next_measurement_ids):

@@ -354,6 +354,7 @@ def test_lookahead_is_bit_identical(hip_device):
     mods, shallow = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
     _, deep = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
     _, plain = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
+    deep.max_lookahead = 2      # (the engine's default stops at the feature extraction: DepthEngine.__init__)
     fullK = syn.full_K()
     lines = syn.keyframe_index_lines(2)
     # (index line or None = tracking loss, announce the next frame?: True, False, or "wrong" = another frame than the one that comes)
