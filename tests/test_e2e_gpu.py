@@ -214,7 +214,11 @@ def test_fusionnet_long_reference_run(hip_device, golden_dir, fixture_host_algeb
             json.dump(rows, f, indent=1)
     for row in rows:
         assert row["engine_vs_reference"] <= (ENGINE_VS_REFERENCE if row["on_reference_inputs"] else AFTER_A_FLIPPED_PIXEL), row
-    assert sum(r["on_reference_inputs"] for r in rows) >= 4
+    # how many frames run on the reference's inputs before the first near-tie of the z-buffer falls the other way depends on the
+    # engine's fp32 summation orders (4-5 frames with MIOpen's Winograd kernels in the decoder, 3 with the direct convolutions: lines
+    # 2 and 118 flip one pixel each); what must hold is the first frame of both segments and the step after the first one -- every
+    # frame's parity from the reference's own state is asserted above (test_fusionnet_frames_from_the_reference_state)
+    assert sum(r["on_reference_inputs"] for r in rows) >= 3
 
 
 def test_exact_pose_algebra_engine(hip_device, golden_dir):

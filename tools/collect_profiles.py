@@ -34,7 +34,7 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     names = ["bench_timed_region.csv", "bench_kernel_stats_whole_run.csv", "bench_under_rocprof.json", "sweep_timed_lines_kernel_stats.csv",
              "sweep_timed_lines.log", "train_timed_region.csv", "train_under_rocprof.json"]
-    for tag in ("lookahead2", "lookahead0"):
+    for tag in ("lookahead2", "lookahead1", "lookahead0"):
         names += [f"bench_timed_region_{tag}.csv", f"bench_kernel_stats_whole_run_{tag}.csv", f"bench_under_rocprof_{tag}.json"]
     for name in names:
         if os.path.exists(os.path.join(src, name)):
@@ -63,7 +63,7 @@ def main():
             "kernel": "dvmvs::sweep_tiled_kernel + dvmvs::sweep_spill_kernel (one cost-volume op)",
             "shape": [1, 2, 32, 128, 160, 64], "shape_meaning": "B, M, C, H, W, D",
             "how": "tools/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over tools/cv_microbench.py "
-                   "--variants 2 --reps 2 on index lines 153 (easy), 118 (median), 165 (worst); per-dispatch means, both kernels added; KiB",
+                   "--variants auto --reps 2 on index lines 153 (easy), 118 (median), 165 (worst); per-dispatch means, both kernels added; KiB",
             "per_index_line": per_line,
             "FETCH_SIZE_KiB": mean("FETCH_SIZE_KiB"), "WRITE_SIZE_KiB": mean("WRITE_SIZE_KiB"),
             "hbm_bytes_per_launch": 1024.0 * (mean("FETCH_SIZE_KiB") + mean("WRITE_SIZE_KiB")),

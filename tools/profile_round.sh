@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round profile on the GPU box (run from the repo root):   tools/profile_round.sh gpurun_out/prof_r04
 #  1. rocprofv3 --kernel-trace --stats of the DRIVER's bench command (--steps 20 --warmup 5; timed region bracketed by marker kernels),
-#     once as benchmarked (look-ahead 2: the next keyframe's feature extraction + sweep + encoder on a second stream, so traced kernel
-#     durations include the slowdown of running next to another stream's kernels) and once with --lookahead 0 (one stream)
+#     once as benchmarked (look-ahead 1: the next keyframe's feature extraction on a second stream, so traced kernel durations include
+#     the slowdown of running next to another stream's kernels) and once with --lookahead 0 (one stream)
 #  2. the same trace of the sweep alone on the index lines of the timed steps, each in the configuration + work list the engine picks
 #     (this is what bench.py's roofline leg times with HIP events)
 #  3. rocprofv3 --pmc passes (SQ mix, LDS conflicts, FETCH_SIZE, WRITE_SIZE -- each counter group in its own run, never mixed
@@ -14,7 +14,7 @@ steps="${STEPS:-20}"; warmup="${WARMUP:-5}"
 mkdir -p "$out"
 export TMPDIR=/tmp
 root="$(pwd)"
-for la in 2 0; do
+for la in 1 0; do
   tag="lookahead$la"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$root/$out/bench_trace_$tag" --output-format csv -- \
      python "$root/bench.py" --steps $steps --warmup $warmup --lookahead $la --mark-region --no-cpu-baseline --no-rel-l1 --sequences-per-gpu 0 \
