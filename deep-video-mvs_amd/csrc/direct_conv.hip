@@ -84,8 +84,14 @@ struct DirectConvConfig {
   static constexpr int CS = dc_round_to_residue(PH * RS, 64, 16);               // channel stride
   static constexpr int Q = (NTILE * K + 3) / 4;                 // float4 per lane and (group, ky) step: K taps x NT output-channel tiles
   static constexpr int NS = G * K;                              // steps per chunk and wave
-  static constexpr int PATCH = CIC * PH * PWD4;                 // float4 elements of a staged chunk
-  static constexpr int XREGS = (PATCH + NT - 1) / NT;           // ... per thread
+  // PRIVATE (one pixel-wave per workgroup): every wave reads only its own 4 G channels of a chunk, so it stages exactly those, into
+  // its own part of the buffer, and the chunk loop needs no workgroup barrier at all -- the waves drift apart, and one wave's
+  // requests / LDS stores overlap the other wave's MFMAs on the same SIMD instead of all eight idling the MFMA pipe together
+  static constexpr bool PRIVATE = PW == 1;
+  static constexpr int STAGE_CH = PRIVATE ? 4 * G : CIC;        // channels one staging unit (wave / workgroup) stages per chunk
+  static constexpr int STAGE_NT = PRIVATE ? 64 : NT;            // its threads
+  static constexpr int PATCH = STAGE_CH * PH * PWD4;            // float4 elements a staging unit stages per chunk
+  static constexpr int XREGS = (PATCH + STAGE_NT - 1) / STAGE_NT;      // ... per thread
   static constexpr int RED_FLOATS = (KS > 1) ? (KS / 2) * PW * MT * NTILE * 256 : 0;    // one round of the split tree
   static constexpr int BUF = CIC * CS;                          // floats of one staged chunk
   static constexpr bool PREFETCH = XREGS <= 8;                  // the next chunk's patch waits in registers while this one is multiplied
@@ -100,8 +106,9 @@ struct DirectConvConfig {
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) {
   constexpr int K = Cfg::K, S = Cfg::S, MW = Cfg::MW, MT = Cfg::MT, NTILE = Cfg::NTILE, PW = Cfg::PW, KS = Cfg::KS, G = Cfg::G;
-  constexpr int MH = Cfg::MH, NT = Cfg::NT, CIC = Cfg::CIC, PH = Cfg::PH, PWD4 = Cfg::PWD4, RS = Cfg::RS, CS = Cfg::CS, Q = Cfg::Q, NS = Cfg::NS;
-  constexpr int XREGS = Cfg::XREGS, PATCH = Cfg::PATCH;
+  constexpr int MH = Cfg::MH, CIC = Cfg::CIC, PH = Cfg::PH, PWD4 = Cfg::PWD4, RS = Cfg::RS, CS = Cfg::CS, Q = Cfg::Q, NS = Cfg::NS;
+  constexpr int XREGS = Cfg::XREGS, PATCH = Cfg::PATCH, STAGE_NT = Cfg::STAGE_NT;
+  constexpr bool PRIVATE = Cfg::PRIVATE;
   extern __shared__ __attribute__((aligned(16))) float s_x[];   // [CIC][CS]: the chunk's patch; afterwards the channel-split partial sums
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the per-wave branches are uniform)
@@ -135,13 +142,15 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
   const __amdgpu_buffer_rsrc_t x_resource =
       __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, static_cast<int>(sizeof(float) * static_cast<unsigned int>(a.C_in) * HW), 0x00020000);
   constexpr unsigned int kOutOfRange = 0x80000000u;      // > any offset inside an input (inputs are < 2 GiB, checked on the host)
+  const int stage_tid = PRIVATE ? lane : tid;                   // this thread's place in its staging unit (its wave / the workgroup) ...
+  const int stage_ch0 = PRIVATE ? ks * G * 4 : 0;               // ... and the unit's first channel within a chunk
   auto element_offset = [&](int i) __attribute__((always_inline)) -> unsigned int {
-    const int e = tid + i * NT;
+    const int e = stage_tid + i * STAGE_NT;
     const int ch = e / (PH * PWD4), rem = e - ch * (PH * PWD4);
     const int row = rem / PWD4, col4 = rem - row * PWD4;
     const int iy = iy0 + row, ix = ix0 + 4 * col4;
     const bool in = e < PATCH && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;      // (ix and W are multiples of 4: all four columns or none)
-    return in ? static_cast<unsigned int>(sizeof(float)) * static_cast<unsigned int>(ch * HW + iy * a.W + ix) : kOutOfRange;
+    return in ? static_cast<unsigned int>(sizeof(float)) * static_cast<unsigned int>((stage_ch0 + ch) * HW + iy * a.W + ix) : kOutOfRange;
   };
   unsigned int x_offset[PREFETCH ? XREGS : 1];
   if (PREFETCH) {
@@ -150,15 +159,15 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
   }
   auto load_element = [&](int chunk, int i) __attribute__((always_inline)) -> float4v {
     const unsigned int offset = PREFETCH ? x_offset[i] : element_offset(i);
-    const bool live = chunk * CIC + (tid + i * NT) / (PH * PWD4) < a.C_in;      // (a ragged last chunk, and the chunk behind the last)
+    const bool live = chunk * CIC + stage_ch0 + (stage_tid + i * STAGE_NT) / (PH * PWD4) < a.C_in;      // (a ragged last chunk, and the chunk behind the last)
     return __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(x_resource, static_cast<int>(live ? offset : kOutOfRange),
                                                                              static_cast<int>(sizeof(float) * static_cast<unsigned int>(chunk * CIC) * HW), 0));
   };
   auto store_element = [&](float* buffer, int i, float4v v) __attribute__((always_inline)) {
-    const int e = tid + i * NT;
+    const int e = stage_tid + i * STAGE_NT;
     const int ch = e / (PH * PWD4), rem = e - ch * (PH * PWD4);
     const int row = rem / PWD4, col4 = rem - row * PWD4;
-    if (e < PATCH) *reinterpret_cast<float4v*>(buffer + ch * CS + row * RS + 4 * col4) = v;
+    if (e < PATCH) *reinterpret_cast<float4v*>(buffer + (stage_ch0 + ch) * CS + row * RS + 4 * col4) = v;
   };
   float4v xr[PREFETCH ? XREGS : 1];
   auto load_patch = [&](int chunk) __attribute__((always_inline)) {
@@ -181,6 +190,13 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
         for (int i = 0; i < 4; ++i) store_element(buffer, i0 + i, piece[i]);
       }
     }
+  };
+
+  // between a chunk's last LDS read and the next patch's first use: a workgroup barrier, or -- PRIVATE -- nothing but program order (a
+  // wave's LDS instructions execute in order, and nobody else touches its channels)
+  auto chunk_barrier = [&]() __attribute__((always_inline)) {
+    if (PRIVATE) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
   };
 
   // ---- weights: step (group cg, ky) = Q float4 per lane ----
@@ -246,14 +262,14 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
 #pragma unroll
       for (int s = 0; s < NS; ++s) asm volatile("" ::"v"(w_load[s][Q - 1]), "v"(w_use[s][Q - 1]));
       store_patch(chunk + 1, s_x + ((chunk + 1) & 1) * BUF);
-      __syncthreads();
+      chunk_barrier();
       DC_TRACE(tr_req += tr_b - tr_a; tr_mfma += tr_c - tr_b; tr_store += DC_NOW() - tr_c;)
     };
 #pragma unroll
     for (int s = 0; s < NS; ++s) load_weights(w_even[s], ks * G + s / K, s % K);
     load_patch(0);
     store_patch(0, s_x);
-    __syncthreads();
+    chunk_barrier();
     DC_TRACE(tr_first = DC_NOW();)
     for (int chunk = 0; chunk < a.n_chunks; chunk += 2) {
       whole_chunk(chunk, w_even, w_odd);
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
     load_patch(0);
     load_weights(w_next, ks * G, 0);
     store_patch(0, s_x);
-    __syncthreads();
+    chunk_barrier();
     DC_TRACE(tr_first = DC_NOW();)
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
       const bool more = chunk + 1 < a.n_chunks;
@@ -287,19 +303,20 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
       DC_TRACE(__builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[MT - 1][NTILE - 1])); tr_c = DC_NOW(); __builtin_amdgcn_sched_barrier(0);)
       if (DOUBLE) {
         store_patch(chunk + 1, s_x + ((chunk + 1) & 1) * BUF);
-        __syncthreads();
+        chunk_barrier();
         DC_TRACE(tr_mfma += tr_c - tr_b; tr_store += DC_NOW() - tr_c;)
       } else {
-        __syncthreads();       // every wave has read its part of this chunk's patch
+        chunk_barrier();       // every wave has read its part of this chunk's patch
         if (more) {
           store_patch(chunk + 1, s_x);
-          __syncthreads();
+          chunk_barrier();
         }
       }
     }
   }
 
   DC_TRACE(tr_loop = DC_NOW();)
+  if (PRIVATE && KS > 1) __syncthreads();      // (the split tree reuses the patch buffers: every wave is done with its own)
   // ---- channel splits: a fixed binary tree through LDS -- (0 + 4) + (2 + 6) + ((1 + 5) + (3 + 7)) for eight --, each round the
   // upper half of the remaining waves hands its sums to the lower half ----
   if (KS > 1) {
