@@ -623,7 +623,8 @@ def main():
         ahead = {}
         if level >= 1:      # the sequence is known in advance (as with a pre-computed keyframe index): announce the next keyframe
             ahead = dict(next_reference_image=images[(k + 1) % n_images], next_frame_id=k + 1)
-        if level >= 2:
+            # ... and its poses: the engine evaluates the next frame's parameter block on its planning thread; at level 2 it also runs
+            # that frame's sweep + encoder a frame ahead (at level 1 the engine's max_lookahead stops at the feature extraction)
             ahead.update(next_reference_pose=seq[k + 1][0], next_measurement_poses=seq[k + 1][1], next_measurement_ids=[k - i for i in range(M)])
         return engine.step(images[k % n_images], seq[k][0], meas_images, seq[k][1], full_K,
                            frame_id=k if not args.no_feature_cache else None, measurement_ids=ids if not args.no_feature_cache else None, **ahead)

@@ -413,6 +413,10 @@ class DepthEngine:
         self.step_clock = None
         self._parity, self._prefetched = 0, None      # buffer set of the next frame; (frame_id, buffer set) whose reference features are ready
         self._side_stream = torch.cuda.Stream(device=self.device)
+        self._planner, self._planned, self._param_host_ahead = None, None, None      # see plan_ahead
+        self.plan_frames_ahead = os.environ.get("DVMVS_PLAN_AHEAD", "1") != "0"
+        self.planned_frames_used = 0
+        self.warm_captured_graphs = os.environ.get("DVMVS_WARM_GRAPHS", "1") != "0"
         # how much of the NEXT keyframe a step computes when the caller announces it (step's next_* arguments): 1 its feature extraction,
         # 2 also its sweep + encoder.  Default 1: with the direct convolution kernels the sweep and the encoder fill the chip on their
         # own, and running them next to the decoder only makes both slower (MI355X, 100 steps: level 0 / 1 / 2 = 827 / 1091 / 999
@@ -617,6 +621,26 @@ class DepthEngine:
         Returns (the host pose that becomes "the previous pose" -- committed by step() only after the frame was launched, so that a
         frame that raises leaves (h, c, previous depth, previous pose) those of one frame --, this frame's sweep configuration or
         None, the next frame's or None)."""
+        planned = self._take_planned(n_meas, pose, measurement_poses, full_K, index, own_sweep, next_frame)
+        if planned is not None:
+            result = planned
+        else:
+            result = self._evaluate_frame_parameters(self._param_host, n_meas, pose, measurement_poses, full_K, self._prev_pose_host,
+                                                     self._no_previous, index, own_sweep, next_frame)
+        mirror = self._param_host
+        staging, event = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        event.synchronize()
+        staging.copy_(mirror)
+        with torch.cuda.device(self.device):     # the ring guard must be recorded on the engine's device, whichever is current
+            self._static["params"].copy_(staging, non_blocking=True)
+            event.record(torch.cuda.current_stream(self.device))
+        return result
+
+    def _evaluate_frame_parameters(self, mirror, n_meas, pose, measurement_poses, full_K, previous_pose, no_previous, index, own_sweep, next_frame):
+        """The host half of ``_upload_frame_parameters``: evaluates the matrices, the sweep configuration and the work list and writes
+        them into ``mirror`` (the host copy of the parameter block).  Touches no engine state -- it also runs on the planning thread, a
+        frame ahead, into a second mirror (``plan_ahead``)."""
         S = self.sequences
         host = _pose_algebra.to_host
         pose, full_K = host(pose).reshape(S, 4, 4), host(full_K).reshape(S, 3, 3)
@@ -627,8 +651,7 @@ class DepthEngine:
         # A sequence without a previous frame (S > 1 runs every sequence through the previous-frame path) gets the identity as
         # relative pose: its previous depth is all zero, and under the identity every zero-depth point stays at z = 0, which the
         # splat never writes -- an exactly empty depth estimate, as on the reference's first-frame path.
-        previous = torch.where(self._no_previous.view(S, 1, 1), pose, self._prev_pose_host)
-        mirror = self._param_host
+        previous = torch.where(no_previous.view(S, 1, 1), pose, previous_pose)
 
         def put(name, tensor):
             o, n = self._param_offsets[name]
@@ -661,10 +684,10 @@ class DepthEngine:
                 next_variant = put_sweep(1 - index, host(next_frame[0]).reshape(S, 4, 4), [host(p).reshape(S, 4, 4) for p in next_frame[1]])
             if self.is_fusionnet:
                 eye = torch.eye(4).expand(S, 4, 4)
-                if bool(self._no_previous.all()):      # nothing to relate to: the identity, exactly (see above)
+                if bool(no_previous.all()):      # nothing to relate to: the identity, exactly (see above)
                     reproject_T = lstm_T = eye
                 else:
-                    fresh = self._no_previous.view(S, 1, 1)
+                    fresh = no_previous.view(S, 1, 1)
                     reproject_T = torch.where(fresh, eye, _pose_algebra.relative_pose_host(pose, previous))   # utils.py:121
                     lstm_T = torch.where(fresh, eye, _pose_algebra.relative_pose_host(previous, pose))        # convlstm.py:30
                 put("reproject_T", reproject_T)
@@ -675,14 +698,42 @@ class DepthEngine:
         put("pose", pose)
         put("prev_pose", previous)
         put("meas_pose", torch.stack(measurement_poses))
-        staging, event = self._ring[self._ring_pos]
-        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
-        event.synchronize()
-        staging.copy_(mirror)
-        with torch.cuda.device(self.device):     # the ring guard must be recorded on the engine's device, whichever is current
-            self._static["params"].copy_(staging, non_blocking=True)
-            event.record(torch.cuda.current_stream(self.device))
         return pose.clone(), sweep_variant, next_variant
+
+    # ---- planning a frame ahead on a second host thread -----------------------------------------------------------------
+    def plan_ahead(self, n_meas, pose, measurement_poses, full_K, previous_pose, index):
+        """Starts evaluating the NEXT frame's parameter block (pose algebra, sweep configuration, work list: ~0.3 ms of small host
+        operations) on the planning thread, while this thread is inside hipGraphLaunch (0.4 ms, GIL released).  With the direct
+        convolutions a frame takes the device 0.8 ms and took the host 0.9: the host had become the bound.  The next step takes the
+        result if it is called with these very poses (else it evaluates its own, as before): same functions on the same inputs."""
+        if self._planner is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._planner = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dvmvs-plan")
+            self._param_host_ahead = torch.zeros_like(self._param_host)
+        no_previous = torch.zeros(self.sequences, dtype=torch.bool)
+        inputs = (pose, list(measurement_poses), full_K)
+        future = self._planner.submit(self._evaluate_frame_parameters, self._param_host_ahead, n_meas, pose, measurement_poses, full_K,
+                                      previous_pose, no_previous, index, True, None)
+        self._planned = (inputs, previous_pose, index, future)
+
+    def _take_planned(self, n_meas, pose, measurement_poses, full_K, index, own_sweep, next_frame):
+        """The block planned a frame ahead, copied into the mirror, if it was planned for exactly this call; else None."""
+        planned, self._planned = self._planned, None
+        if planned is None:
+            return None
+        (p_pose, p_meas, p_K), p_previous, p_index, future = planned
+        try:
+            result = future.result()          # (also when it is not used: the second mirror must be idle before the next plan)
+        except Exception:
+            return None                       # evaluated again by the caller, which raises in the caller's thread
+        same = lambda a, b: a is b or (tuple(a.shape) == tuple(b.shape) and a.device == b.device and torch.equal(a, b))
+        if not (own_sweep and next_frame is None and p_index == index and len(p_meas) == n_meas == len(measurement_poses)
+                and not bool(self._no_previous.any()) and same(p_pose, pose) and same(p_K, full_K)
+                and all(same(a, b) for a, b in zip(p_meas, measurement_poses)) and torch.equal(p_previous, self._prev_pose_host)):
+            return None
+        self._param_host.copy_(self._param_host_ahead)
+        self.planned_frames_used += 1
+        return result
 
     # ---- destination-passing frame body (one sequence) ------------------------------------------------------------------
     def _fpn_direct(self, taps, outs):
@@ -975,6 +1026,10 @@ class DepthEngine:
         committed_pose, sweep_variant, next_variant = self._upload_frame_parameters(n_meas, reference_pose, measurement_poses, full_K, index=parity,
                                                                                     own_sweep=have < 2, next_frame=next_frame)
         mark("parameters planned + uploaded")
+        if self.direct and give < 2 and self.pose_algebra == "reference" and self.plan_frames_ahead and next_reference_pose is not None and \
+                next_measurement_poses is not None and 1 <= len(next_measurement_poses) <= _MAX_MEAS:
+            # the announced next frame's parameter block, evaluated on the planning thread while this thread launches the frame
+            self.plan_ahead(len(next_measurement_poses), next_reference_pose, list(next_measurement_poses), full_K, committed_pose, 1 - parity)
         if have == 2:
             sweep_variant = ready["sweep_variant"]
         self.sweep_variant_counts[sweep_variant] = self.sweep_variant_counts.get(sweep_variant, 0) + 1
@@ -996,6 +1051,7 @@ class DepthEngine:
             self._frame_body(*body)
             self._warm.add(kind)
         else:
+            known = set(self._graphs)
             if key not in self._graphs:
                 # Capture records launches, it executes nothing -- so what this kind of frame will need later is captured now, while the
                 # caller is still warming up: with look-ahead the steady-state pattern (this frame's share prefetched, the next frame's
@@ -1017,6 +1073,18 @@ class DepthEngine:
                             k = graph_key(par, have, 0, v, 0)
                             if k not in self._graphs:
                                 self._graphs[k] = self._capture((n_meas, kind[1], v, par, have, 0, 0, 0))
+            fresh = [k for k in self._graphs if k not in known and k != key]
+            if fresh and self.warm_captured_graphs:
+                # A graph's FIRST launch stalls the device for ~5 ms (its kernel arguments and code are set up then, not at capture):
+                # once per pre-captured graph, i.e. a few steps into every run, whenever a geometry first asks for another sweep
+                # configuration or buffer set.  So every graph captured ahead is launched once now, during warm-up, on throw-away
+                # results: the recurrent state is put back afterwards, and everything else the launch writes is rewritten by the real
+                # frame below (same image, same features) before anybody reads it.
+                keep = [s[k].clone() for k in ("h", "c", "prev_depth")] if self.is_fusionnet else []
+                for k in fresh:
+                    self._graphs[k].replay()
+                for name, saved in zip(("h", "c", "prev_depth"), keep):
+                    s[name].copy_(saved)
             self._graphs[key].replay()
         mark("frame launched")
         self._prev_pose_host = committed_pose

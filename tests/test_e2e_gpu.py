@@ -395,3 +395,37 @@ def test_lookahead_is_bit_identical(hip_device):
     assert any(k[4] == 1 and k[5] == 1 for k in shallow._graphs)      # ... through replayed graphs of the steady-state patterns
     assert any(k[4] == 2 and k[5] == 2 for k in deep._graphs)
     assert deep.sweep_variant_counts == plain.sweep_variant_counts
+
+
+def test_planning_a_frame_ahead_is_bit_identical(hip_device):
+    """DepthEngine.plan_ahead: the announced next frame's parameter block (pose algebra, sweep configuration, work list) is evaluated
+    on a second host thread during this frame's graph launch.  Same functions on the same inputs: depth equals, bit for bit, an engine
+    that evaluates every block inside its own step -- through a tracking loss, a wrong announcement and a missing one."""
+    dev = hip_device
+    mods, ahead = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
+    _, inline = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
+    inline.plan_frames_ahead = False
+    assert ahead.plan_frames_ahead
+    fullK = syn.full_K()
+    lines = syn.keyframe_index_lines(2)
+    schedule = [(0, True), (1, True), (2, True), (3, True), (4, False), (5, True), (None, None), (117, True), (118, True), (119, "wrong"),
+                (200, True), (201, True), (202, True)]
+    frames = [(None if i is None else lines[i], flag) for i, flag in schedule]
+    for n, (item, announce) in enumerate(frames):
+        if item is None:
+            ahead.reset()
+            inline.reset()
+            continue
+        r, ms = item
+        args = (syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK)
+        upcoming = next((f[0] for f in frames[n + 1:] if f[0] is not None), None)
+        kw = {}
+        if announce and upcoming is not None:
+            nxt, nms = upcoming if announce is True else lines[7]
+            kw = dict(next_reference_image=syn.e2e_image(nxt).to(dev), next_frame_id=nxt, next_reference_pose=syn.pose(nxt),
+                      next_measurement_poses=[syn.pose(i) for i in nms], next_measurement_ids=list(nms))
+        a = ahead.step(*args, frame_id=r, measurement_ids=list(ms), **kw).clone()
+        b = inline.step(*args, frame_id=r, measurement_ids=list(ms), **kw).clone()
+        assert torch.equal(a, b), n
+    print(f"parameter blocks taken from the planning thread: {ahead.planned_frames_used} of {sum(f[0] is not None for f in frames)} frames")
+    assert ahead.planned_frames_used >= 6 and inline.planned_frames_used == 0

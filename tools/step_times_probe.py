@@ -18,7 +18,10 @@ def main():
     level = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2
     from dvmvs.engine import DepthEngine
     dev = torch.device("cuda:0")
-    engine = DepthEngine(*bench.build_modules(), device=dev)
+    engine = DepthEngine(*bench.build_modules(), device=dev, max_lookahead=level)
+    if "--no-gc" in sys.argv:
+        import gc
+        gc.disable()
     M, n_images, total = 2, 32, 70
     images, seq, full_K = bench.synthetic_sequence(0, n_images, total + M + 2, M)
     images = [im.to(dev) for im in images]
@@ -32,7 +35,6 @@ def main():
             ahead = {}
             if level >= 1:
                 ahead = dict(next_reference_image=images[(k + 1) % n_images], next_frame_id=k + 1)
-            if level >= 2:
                 ahead.update(next_reference_pose=seq[k + 1][0], next_measurement_poses=seq[k + 1][1], next_measurement_ids=[k - j for j in range(M)])
             sync_each = "--free-running" not in sys.argv
             engine.step_clock = clocks
