@@ -266,8 +266,8 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
 
     ``pose_sets``: (reference pose, [measurement poses]) of index lines -- the duration depends on the epipolar geometry
     (how large the LDS-staged footprint of a tile is, how many runs of planes are queued for the second pass), so one geometry is
-    not representative.  Each geometry runs in the sweep configuration the engine would pick for it (dvmvs.utils.sweep_variant: the
-    host-side plan model on the host copies of the matrices).  Per configuration a hipGraph of ``reps`` back-to-back ops (no host
+    not representative.  Each geometry runs in the sweep configuration the engine picks for it (dvmvs_sweep_plan, one sequence: the
+    host-side plan model on the host copies of the matrices; lock-step batches: dvmvs.utils.sweep_variant).  Per configuration a hipGraph of ``reps`` back-to-back ops (no host
     gaps) is timed with HIP events on the stream it is replayed on.
     Returns (mean seconds per op, algorithmic bytes per op, [per-geometry seconds], [per-geometry variant])."""
     from dvmvs import pose_algebra, utils
@@ -294,6 +294,13 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
         h, k, host = pose_algebra.sweep_matrices(ref_pose, meas_poses[:n_meas], half_K, ref.device, engine.pose_algebra, with_host=True)
         Hm.copy_(h)
         kt.copy_(k)
+        if use_list and B == 1:
+            # exactly what DepthEngine._evaluate_frame_parameters does: configuration (2 / 3, or their single-pass forms 4 / 5 when the
+            # plan queues nothing) and work list in one walk
+            items = torch.zeros(work_list.numel(), dtype=torch.int32)
+            variant = _ops.sweep_plan_host(host[0], host[1], H, W, D, engine.min_depth, engine.max_depth, 0, items)
+            work_list.copy_(items)
+            return variant
         variant = utils.sweep_variant(host, H, W, D, engine.min_depth, engine.max_depth)
         if use_list:
             work_list.copy_(_ops.sweep_work_list_host(host[0], host[1], H, W, D, engine.min_depth, engine.max_depth, variant))
