@@ -209,6 +209,8 @@ class FusedConv2d(nn.Module):
                 tuple(self.padding) != (k[2] // 2, k[2] // 2):
             return None
         B, _, H, W = x.shape
+        if x.data_ptr() % 16 != 0 or (out is not None and out.data_ptr() % 4 != 0):
+            return None      # (the kernel stages aligned float4 rows; torch's own allocations always are)
         stride = self.stride[0]
         bias = None if raw or self.bias is None else self.bias
         if raw:
