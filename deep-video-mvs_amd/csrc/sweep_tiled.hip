@@ -466,8 +466,8 @@ __host__ __device__ inline SweepWork decode_work(int block, int tiles, int chunk
 }
 
 // GATHER: there is no second pass (no spill workspace, or the single-pass variants 4 / 5 that the host's plan picks when it expects
-// nothing to be queued): runs of planes that cannot be staged are gathered inline -- slow, but then never taken; compiled into its own
-// instantiation so that the two-pass kernel carries none of its registers (162 VGPRs against 127-133: still three waves per SIMD).
+// nothing to be queued): runs of planes that cannot be staged are gathered by the same workgroup behind its output write -- slow, but
+// then never taken.  A cold loop at the end of the kernel: the staged path is the two-pass kernel's, instruction for instruction.
 template <class Cfg, bool NHWC, bool GATHER>
 __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_tiled_kernel(CostVolumeArgs a) {
   constexpr int TW = Cfg::TW, TH = Cfg::TH, DP = Cfg::DP, CCH = Cfg::CCH, CAP = Cfg::CAP, NT = Cfg::NT, REC = Cfg::REC;
@@ -476,7 +476,6 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_tiled_kernel(CostVo
   constexpr int kMaxRuns = max_runs<DP, Cfg::MINSEG>();
   extern __shared__ __attribute__((aligned(16))) float s_tile[];   // [CAP][REC]
   __shared__ float s_H[DVMVS_MAX_MEASUREMENTS * 9];
-  __shared__ float s_kt[DVMVS_MAX_MEASUREMENTS * 3];
   __shared__ float4v s_ktd[DVMVS_MAX_MEASUREMENTS * DP];
   __shared__ int s_runs[kMaxRuns * kRunWords];
   __shared__ int s_n_runs;
@@ -519,8 +518,6 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_tiled_kernel(CostVo
     gcfloat_p Hm_g = as_global(a.Hm) + static_cast<size_t>(b) * a.M * 9;
     gcfloat_p kt_g = as_global(a.kt) + static_cast<size_t>(b) * a.M * 3;
     for (int i = first; i < a.M * 9; i += stride) s_H[i] = Hm_g[i];
-    if (GATHER)
-      for (int i = first; i < a.M * 3; i += stride) s_kt[i] = kt_g[i];
     for (int i = first; i < a.M * DP; i += stride) {
       const int m = i / DP, j = i - m * DP;
       float4v k = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -581,20 +578,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_tiled_kernel(CostVo
     const int w0 = __builtin_amdgcn_readfirstlane(s_runs[e * kRunWords]);
     if ((w0 >> 24) != 0) continue;
     const int m = w0 & 0xff, seg_lo = (w0 >> 8) & 0xff, seg_len = (w0 >> 16) & 0xff;
-    if (!GATHER) {
-      if (tid == 0) slot[1 + n_spilled] = spill_pack(m, seg_lo, seg_len);
-      ++n_spilled;
-    } else {
-      const SweepRay ray = sweep_ray(s_H + m * 9, xf, yf);
-      const float* kt = s_kt + m * 3;
-      gcfloat_p meas = as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW;
-#pragma unroll
-      for (int j = 0; j < DPT; ++j)
-        if (j0 + j >= seg_lo && j0 + j < seg_lo + seg_len) {
-          const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j0 + j);
-          acc2[j].x += live ? gather_plane<NHWC>(a, meas, ref, HW, ray, kt[0] / depth, kt[1] / depth, kt[2] / depth, sc) : 0.0f;
-        }
-    }
+    if (!GATHER && tid == 0) slot[1 + n_spilled] = spill_pack(m, seg_lo, seg_len);
+    ++n_spilled;      // (GATHER: gathered behind the output write, see the end of the kernel)
   }
 
   // ---- staged runs, software-pipelined over (run, channel pass) stages ----
@@ -787,20 +772,8 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_tiled_kernel(CostVo
     for (int j = 0; j < DPT; ++j) acc2[j] = float2v{0.0f, 0.0f};
     n_spilled = 0;
     for (int m = 0; m < a.M; ++m) {
-      if (!GATHER) {
-        if (tid == 0) slot[1 + n_spilled] = spill_pack(m, 0, planes);
-        ++n_spilled;
-      } else {
-        const SweepRay ray = sweep_ray(s_H + m * 9, xf, yf);
-        const float* kt = s_kt + m * 3;
-        gcfloat_p meas = as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW;
-#pragma unroll
-        for (int j = 0; j < DPT; ++j)
-          if (j0 + j < planes && live) {
-            const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j0 + j);
-            acc2[j].x += gather_plane<NHWC>(a, meas, ref, HW, ray, kt[0] / depth, kt[1] / depth, kt[2] / depth, sc);
-          }
-      }
+      if (!GATHER && tid == 0) slot[1 + n_spilled] = spill_pack(m, 0, planes);
+      ++n_spilled;
     }
   }
 
@@ -830,6 +803,31 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_tiled_kernel(CostVo
     t[13] = tr_switch; t[14] = static_cast<unsigned long long>(n_runs); t[15] = tr_loop_end - tr_start;
   }
 #endif
+  if (GATHER && n_spilled > 0) {
+    // No second pass: the runs that could not be staged (none when the host's plan promised so: variants 4 / 5) are gathered here,
+    // behind the output write, one plane at a time like the second pass does -- a cold loop that shares no register with the staged
+    // path above (inlined into it, round 4's first form, it cost the sweep 29 registers and 1 us per launch).
+    gcfloat_p kt_g = as_global(a.kt) + static_cast<size_t>(b) * a.M * 3;
+    gfloat_p out = as_global(a.out) + (static_cast<size_t>(b) * a.D + d_block) * HW + pix;
+    const int n_items = any_violated ? a.M : n_runs;
+    for (int e = 0; e < n_items; ++e) {
+      int m = e, seg_lo = 0, seg_len = planes;
+      if (!any_violated) {
+        const int w0 = __builtin_amdgcn_readfirstlane(s_runs[e * kRunWords]);
+        if ((w0 >> 24) != 0) continue;
+        m = w0 & 0xff, seg_lo = (w0 >> 8) & 0xff, seg_len = (w0 >> 16) & 0xff;
+      }
+      const SweepRay ray = sweep_ray(s_H + m * 9, xf, yf);
+      gcfloat_p meas = as_global(a.image2[m]) + static_cast<size_t>(b) * a.C * HW;
+#pragma unroll 1
+      for (int j = max(seg_lo, j0); j < min(seg_lo + seg_len, j0 + DPT); ++j) {
+        if (!live) continue;
+        const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, d_block + j);
+        const float part = gather_plane<NHWC>(a, meas, ref, HW, ray, kt_g[m * 3 + 0] / depth, kt_g[m * 3 + 1] / depth, kt_g[m * 3 + 2] / depth, sc);
+        out[static_cast<size_t>(j) * HW] += (part / static_cast<float>(a.C)) / static_cast<float>(a.M);   // as the second pass scales
+      }
+    }
+  }
   if (!GATHER && n_spilled > 0) {
     if (tid == 0) {
       slot[0] = static_cast<unsigned int>(n_spilled);

@@ -419,6 +419,7 @@ class DepthEngine:
         self.plan_frames_ahead = os.environ.get("DVMVS_PLAN_AHEAD", "1") != "0"
         self.planned_frames_used = 0
         self.warm_captured_graphs = os.environ.get("DVMVS_WARM_GRAPHS", "1") != "0"
+        self.warm_graph_launches = max(1, int(os.environ.get("DVMVS_WARM_GRAPH_LAUNCHES", "1")))
         # how much of the NEXT keyframe a step computes when the caller announces it (step's next_* arguments): 1 its feature extraction,
         # 2 also its sweep + encoder.  Default 1: with the direct convolution kernels the sweep and the encoder fill the chip on their
         # own, and running them next to the decoder only makes both slower (MI355X, 100 steps: level 0 / 1 / 2 = 827 / 1091 / 999
@@ -1083,8 +1084,9 @@ class DepthEngine:
                 # results: the recurrent state is put back afterwards, and everything else the launch writes is rewritten by the real
                 # frame below (same image, same features) before anybody reads it.
                 keep = [s[k].clone() for k in ("h", "c", "prev_depth")] if self.is_fusionnet else []
-                for k in fresh:
-                    self._graphs[k].replay()
+                for _ in range(self.warm_graph_launches):
+                    for k in fresh:
+                        self._graphs[k].replay()
                 for name, saved in zip(("h", "c", "prev_depth"), keep):
                     s[name].copy_(saved)
             self._graphs[key].replay()

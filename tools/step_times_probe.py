@@ -51,6 +51,7 @@ def main():
     gaps = [events[i - 1].elapsed_time(events[i]) for i in range(1, len(events))]
     print("device time between the ends of consecutive steps (ms):", " ".join(f"{g:.2f}" for g in gaps))
     print(f"look-ahead {level}: step, host ms inside step(), ms until the device is idle (a sync after every step: no overlap between steps)")
+    print("frames per sweep configuration:", engine.sweep_variant_counts, " graphs:", len(engine._graphs), " planned blocks used:", engine.planned_frames_used)
     for (i, h, d), marks in zip(rows, clocks):
         parts = "  ".join(f"{name} {1e3 * (t - marks[j][1]):6.3f}" for j, (name, t) in enumerate(marks[1:]))
         print(f"  {i:3d}  {h:8.3f}  {d:8.3f}   | {parts}")
