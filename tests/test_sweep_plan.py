@@ -230,3 +230,35 @@ def test_one_walk_plan_equals_selection_plus_work_list():
     assert ops.sweep_plan_host(Hm, kt, H, W, D, 0.25, 20.0, 2, out) == 2                           # (line 170 queues runs in both)
     with pytest.raises(RuntimeError):
         ops.sweep_plan_host(Hm, kt, H, W, D, 0.25, 20.0, 1, out)
+
+
+@pytest.mark.parametrize("M", [4, 8])
+def test_work_list_never_writes_past_its_buffer(M):
+    """with M >= 4 measurement frames every (tile, chunk) has more staged runs than an item may have, so everything is
+    cut, and the capacity guard has to count the ranges still pending on the cut stack.  A canary behind the buffer, random geometries,
+    both configurations: the item count never exceeds the capacity, the canary survives, the items still partition (tile, plane)."""
+    lib = _capi.lib()
+    rng = np.random.default_rng(7 + M)
+    shape = (128, 160, 64)
+    words = int(lib.dvmvs_sweep_work_list_bytes(1, *shape)) // 4
+    capacity = (words - 2) // 2
+    poses = torch.from_numpy(syn.sample_poses()).float()
+    K = syn.scaled_K(syn.full_K(), 2.0)
+    for trial in range(60):
+        ref = int(rng.integers(0, poses.shape[0]))
+        meas = [int(np.clip(ref + rng.integers(-40, 41), 0, poses.shape[0] - 1)) for _ in range(M)]
+        Hm, kt = pose_algebra.sweep_matrices_host(poses[ref:ref + 1], [poses[m:m + 1] for m in meas], K)
+        Hm, kt = Hm.contiguous().float(), kt.contiguous().float()
+        for configuration in (0, 1):
+            buf = np.full(words + 64, 0xDEADBEEF, dtype=np.uint32)
+            rc = lib.dvmvs_sweep_work_list(Hm.data_ptr(), kt.data_ptr(), 1, M, *shape, 0.25, 20.0, configuration,
+                                           buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint)), words * 4)
+            assert rc > 0, (trial, configuration, rc)
+            assert (buf[words:] == 0xDEADBEEF).all(), (trial, configuration, "wrote past the work list")
+            n = int(buf[0])
+            assert n <= capacity and rc == 2 + 2 * n
+            items = buf[2:2 + 2 * n].astype(np.int64).reshape(n, 2)
+            cover = np.zeros((80, 64), dtype=np.int64)
+            for w0, w1 in items:
+                cover[w0 & 0xffff, (w1 & 0xffff):(w1 & 0xffff) + (w1 >> 16)] += 1
+            assert (cover == 1).all(), (trial, configuration)
