@@ -155,7 +155,7 @@ def _cost_volume_op(image1: Tensor, image2s: Sequence[Tensor], Hm: Tensor, kt: T
     image1 = image1.contiguous()
     # Measurement maps that are already channels-last in memory (the frame engine caches them that way) are passed as NHWC;
     # anything else is made NCHW-contiguous, the reference's layout.
-    nhwc_ok = bool(dot_product) and variant != 1 and C % 4 == 0 and C > 1 and H * W >= 64 * 64
+    nhwc_ok = bool(dot_product) and variant != 1 and C % 4 == 0 and C > 1 and (H * W >= 64 * 64 or (variant == 6 and C <= 32))
     nhwc = nhwc_ok and all(t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous() for t in image2s)
     image2s = list(image2s) if nhwc else [t.contiguous() for t in image2s]
     Hm, kt = Hm.contiguous(), kt.contiguous()

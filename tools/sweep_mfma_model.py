@@ -1,7 +1,7 @@
 """Work model of the correlate-then-interpolate sweep (csrc/sweep_mfma.hip) on the sample scene's keyframe pairs (CPU, numpy).
 
 For a pixel-group shape (gw x gh = 16 pixels), planes per wave and table capacity it counts, per keyframe pair (all M frames):
-the 16-cell MFMA tiles (8 v_mfma_f32_16x16x4_f32 each), the waves, the samples left to the gather path, and prints the MFMA time at
+the 16-cell MFMA tiles (8 v_mfma_f32_16x16x4_f32 each), the waves, the lookup rounds per sample (strips), and prints the MFMA time at
 the fp32 matrix peak.  Used to choose the shipped configuration before touching the GPU; not part of the product.
 
     python tools/sweep_mfma_model.py [--every 8] [--configs 4x4x16x128,8x2x16x128]
@@ -34,30 +34,27 @@ def chunk_boxes(sx, sy, gw, gh, planes):
     return cells, n_alive
 
 
-def model(sx, sy, gw, gh, pw, cap, levels):
-    """tiles, gathered samples for one frame; hierarchy: pw planes per wave, split into `levels` (e.g. (16, 4)) while a box exceeds cap"""
-    tiles = 0
-    gathered = 0
-    passes = 0
-    # evaluate from the finest level up: a coarse box is used when it fits, else its children
+def model(sx, sy, gw, gh, pw, cap, levels, thr=1.0):
+    """tiles, lookup rounds and passes for one frame.  Hierarchy: a box of `levels[0]` planes is split into boxes of the next level while
+    it has more than thr * cap cells; a box that is not split is processed in strips of cap cells (one lookup round per strip)."""
     fine = None
     for lv in sorted(levels):
         cells, n_alive = chunk_boxes(sx, sy, gw, gh, lv)
-        t = np.where(cells > 0, np.ceil((cells + 1) / 16.0), 0)
-        fits = cells <= cap
+        t = np.ceil(cells / 16.0)
+        rounds = np.ceil(cells / float(cap)) * lv
+        own_p = (cells > 0) * 1
         if fine is None:
-            cost_t = np.where(fits, t, 0)
-            cost_g = np.where(fits, 0, n_alive)
-            cost_p = np.where(fits & (cells > 0), 1, 0)
+            cost_t, cost_r, cost_p = t, rounds, own_p
         else:
-            f_t, f_g, f_p, f_lv = fine
+            f_t, f_r, f_p, f_lv = fine
             r = lv // f_lv
             nd = cells.shape[0]
             child = lambda v: v.reshape(nd, r, *v.shape[1:]).sum(axis=1)
-            cost_t = np.where(fits, t, child(f_t))
-            cost_g = np.where(fits, 0, child(f_g))
-            cost_p = np.where(fits, (cells > 0) * 1, child(f_p))
-        fine = (cost_t, cost_g, cost_p, lv)
+            keep = cells <= thr * cap
+            cost_t = np.where(keep, t, child(f_t))
+            cost_r = np.where(keep, rounds, child(f_r))
+            cost_p = np.where(keep, own_p, child(f_p) + 1)
+        fine = (cost_t, cost_r, cost_p, lv)
     return fine[0].sum(), fine[1].sum(), fine[2].sum()
 
 
@@ -74,16 +71,16 @@ def main():
     configs = []
     for c in args.configs.split(","):
         p = c.split("x")
-        configs.append((int(p[0]), int(p[1]), int(p[2]), int(p[3]), tuple(int(v) for v in p[4].split("."))))
+        configs.append((int(p[0]), int(p[1]), int(p[2]), int(p[3]), tuple(int(v) for v in p[4].split(".")), float(p[5]) if len(p) > 5 else 1.0))
     res = {c: [] for c in configs}
     for li in sel:
         ref, *meas = lines[li]
         pos = [sample_positions(poses[ref], poses[m], K) for m in meas]
         for c in configs:
-            gw, gh, pw, cap, levels = c
+            gw, gh, pw, cap, levels, thr = c
             tt = gg = pp = 0
             for sx, sy, _ in pos:
-                t, g, p = model(sx, sy, gw, gh, pw, cap, levels)
+                t, g, p = model(sx, sy, gw, gh, pw, cap, levels, thr)
                 tt += t; gg += g; pp += p
             res[c].append((tt, gg, pp))
     total_samples = D * H * W * 2
@@ -92,8 +89,8 @@ def main():
         r = np.array(res[c], dtype=np.float64)
         tiles = r[:, 0]
         us = tiles * 8 * 2048 / 157.3e12 * 1e6
-        print(f"{c[0]}x{c[1]} pw{c[2]:<3} cap{c[3]:<4} lv{'.'.join(map(str, c[4])):<8} tiles mean {tiles.mean():9.0f} max {tiles.max():9.0f} | mfma us mean {us.mean():5.2f} "
-              f"p90 {np.percentile(us, 90):5.2f} max {us.max():5.2f} | passes/wave-frame {r[:, 2].mean() / (H * W / 16 * D / c[2] * 2):.2f} | gathered frac mean {np.mean(r[:, 1]) / total_samples:.4f} max {r[:, 1].max() / total_samples:.4f}")
+        print(f"{c[0]}x{c[1]} pw{c[2]:<3} cap{c[3]:<4} lv{'.'.join(map(str, c[4])):<8} thr{c[5]:<4} tiles mean {tiles.mean():9.0f} max {tiles.max():9.0f} | mfma us mean {us.mean():5.2f} "
+              f"p90 {np.percentile(us, 90):5.2f} max {us.max():5.2f} | passes/wave-frame {r[:, 2].mean() / (H * W / 16 * D / c[2] * 2):.2f} | lookup rounds per sample mean {np.mean(r[:, 1]) * 16 / total_samples:.3f} max {r[:, 1].max() * 16 / total_samples:.3f}")
 
 
 if __name__ == "__main__":
