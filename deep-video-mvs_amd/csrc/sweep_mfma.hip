@@ -24,17 +24,30 @@
 
 namespace dvmvs {
 
-template <int CTRL>
-__device__ inline int dpp_exchange(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+typedef short short2v __attribute__((ext_vector_type(2)));
 
-// maximum over the wave (returned wave-uniform): butterflies inside each row of 16 lanes on the VALU's DPP path, then four readlanes
-__device__ inline int wave_max_i32(int v) {
-  v = max(v, dpp_exchange<0xB1>(v));    // quad_perm [1,0,3,2]
-  v = max(v, dpp_exchange<0x4E>(v));    // quad_perm [2,3,0,1]
-  v = max(v, dpp_exchange<0x141>(v));   // row_half_mirror
-  v = max(v, dpp_exchange<0x140>(v));   // row_mirror
-  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-             max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ inline int dpp_exchange(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false); }
+
+__device__ inline int pk_min_i16(int a, int b) {
+  return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
+}
+__device__ inline int pk_max_i16(int a, int b) {
+  return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
+}
+
+// Minimum / maximum of a packed (x | y << 16) pair of int16 over the wave, returned wave-uniform: butterflies inside each row of 16 lanes
+// and the two row broadcasts of the GFX9 DPP path (all VALU, no LDS), one readlane.
+template <bool MAX>
+__device__ inline int wave_reduce_pk_i16(int v) {
+  auto op = [](int a, int b) { return MAX ? pk_max_i16(a, b) : pk_min_i16(a, b); };
+  v = op(v, dpp_exchange<0xB1>(v));          // quad_perm [1,0,3,2]
+  v = op(v, dpp_exchange<0x4E>(v));          // quad_perm [2,3,0,1]
+  v = op(v, dpp_exchange<0x141>(v));         // row_half_mirror
+  v = op(v, dpp_exchange<0x140>(v));         // row_mirror: every lane holds its row's result
+  v = op(v, dpp_exchange<0x142, 0xa>(v));    // row_bcast15 into rows 1 and 3
+  v = op(v, dpp_exchange<0x143, 0xc>(v));    // row_bcast31 into rows 2 and 3: lane 63 holds the wave's result
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Lanes of ONE wave exchange data through its private LDS slice.  The hardware executes a wave's LDS operations in order, so no
@@ -46,20 +59,25 @@ __device__ inline void wave_lds_fence() {
   asm volatile("" ::: "memory");
 }
 
-// GW x GH = 16 reference pixels per wave; CAP = cells of the dot table; NW = waves per workgroup (x-adjacent groups of the same plane
-// chunk: they share the CU's L1, not LDS); WAVES = waves per SIMD the register allocation is held to; PREFETCH = the operands of the
-// next two tiles are requested before the MFMAs of the current two.
-template <int GW_, int GH_, int CAP_, int NW_, int WAVES_, bool PREFETCH_, int TPI_ = 1, int ABLATE_ = 0>
+// The small per-frame matrices are wave-uniform: read through the constant address space they arrive as scalar loads in SGPRs (the
+// vector memory pipe carries the measurement cells), and the next frame's are requested a whole frame ahead.
+typedef const float __attribute__((address_space(4)))* ccfloat_p;
+__device__ inline ccfloat_p as_constant(const float* p) { return (ccfloat_p)p; }
+
+// GW x GH = 16 reference pixels per wave; CAP = cells of the dot table; CPW = chunks of 16 planes a wave works through one after the
+// other (same pixels: the reference features stay in registers); WAVES = waves per SIMD the register allocation is held to.
+template <int GW_, int GH_, int CAP_, int CPW_, int WAVES_, int ABLATE_ = 0, int STAGGER_ = 0, int ORDER_ = 0>
 struct MfmaSweepConfig {
-  static constexpr int GW = GW_, GH = GH_, CAP = CAP_, NW = NW_, WAVES = WAVES_;
-  static constexpr bool PREFETCH = PREFETCH_;
-  static constexpr int TPI = TPI_;                     // tiles per operand request / MFMA block (2 = two accumulators interleaved)
+  static constexpr int GW = GW_, GH = GH_, CAP = CAP_, CPW = CPW_, WAVES = WAVES_;
+  static constexpr int STAGGER = STAGGER_;             // 1: s_setprio by wave slot (waves of a SIMD leave lockstep: one's MFMA phase beside another's VALU phase)
+  static constexpr int ORDER = ORDER_;                 // 1: within an XCD far chunks (more tiles) first
   static constexpr int ABLATE = ABLATE_;               // tools only (timing experiments, wrong results): 1 no operand loads, 2 no MFMAs, 4 no interpolation
-  static constexpr int PW = 16;                        // planes per wave
+  static constexpr int PW = 16;                        // planes per chunk
   static constexpr int SPLIT = 2;                      // a 16-plane box of more than SPLIT * CAP cells is redone per 4 planes (tools/sweep_mfma_model.py)
-  static constexpr int PITCH = CAP + 16 + 4;           // floats per pixel row of the table (16-byte aligned rows; the odd tile of a pair may be written)
-  static constexpr size_t kLdsBytes = sizeof(float) * NW * (16 * PITCH + 4 * PW);
-  static_assert(GW * GH == 16 && CAP % 16 == 0 && NW >= 1 && NW <= 4, "group shape");
+  static constexpr int PITCH = CAP + 16 + 4;           // floats per pixel row of the table (16-byte aligned rows; the last tile may be partial)
+  static constexpr int kTableFloats = 16 * PITCH;
+  static constexpr size_t lds_bytes(int M) { return sizeof(float) * (kTableFloats + 4 * PW * CPW * M); }
+  static_assert(GW * GH == 16 && CAP % 16 == 0 && (CPW == 1 || CPW == 2 || CPW == 4), "group shape");
 };
 
 // ---- optional timeline instrumentation (tools/sweep_mfma_trace.py; built only by `make trace`) -------------------------------------
@@ -73,35 +91,69 @@ __device__ unsigned long long g_sweep_mfma_trace[kMfmaTraceWaves * kMfmaTraceWor
 
 constexpr int kMfmaSweepChannels = 32;   // the K extent of a tile's eight MFMAs; fewer channels are padded with zero operands
 
+// this lane's four samples of one (chunk, frame): north-west tap (x | y << 16, int16 each), fractional position, alive bits (some tap
+// can lie inside the image)
+struct SweepSamples {
+  int xy[4];
+  float frx[4], fry[4];
+  unsigned int alive;
+};
+
 // FULL: exactly 32 channels (the hot-path shape: no per-channel bounds tests); otherwise any C <= 32 (NHWC: a multiple of 4).
 template <class Cfg, bool NHWC, bool FULL>
-__global__ __launch_bounds__(64 * Cfg::NW, Cfg::WAVES) void sweep_mfma_kernel(CostVolumeArgs a) {
-  constexpr int GW = Cfg::GW, GH = Cfg::GH, PW = Cfg::PW, CAP = Cfg::CAP, NW = Cfg::NW, PITCH = Cfg::PITCH;
+__global__ __launch_bounds__(64, Cfg::WAVES) void sweep_mfma_kernel(CostVolumeArgs a) {
+  constexpr int GW = Cfg::GW, GH = Cfg::GH, PW = Cfg::PW, CAP = Cfg::CAP, CPW = Cfg::CPW, PITCH = Cfg::PITCH;
+  constexpr int WP = PW * CPW;   // planes per wave
   const int C = FULL ? kMfmaSweepChannels : a.C;
   extern __shared__ __attribute__((aligned(16))) float s_lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = threadIdx.x;
   const int p = lane & 15, q = lane >> 4;
-  float* T = s_lds + wave * (16 * PITCH + 4 * PW);                               // [16 pixels][PITCH]: <f1(pixel), f2(cell)>
-  float4v* ktd = reinterpret_cast<float4v*>(s_lds + wave * (16 * PITCH + 4 * PW) + 16 * PITCH);   // [PW] K t / depth of the frame in work
+  float* T = s_lds;                                                              // [16 pixels][PITCH]: <f1(pixel), f2(cell)>
+  float4v* ktd = reinterpret_cast<float4v*>(s_lds + Cfg::kTableFloats);          // [M][WP]: K t / depth per frame and plane of this wave
 
-  // ---- work item: NW x-adjacent groups x one chunk of PW planes; XCD k (= blockIdx % 8) gets a contiguous range of image rows, so a
+  // ---- work item: one group x CPW chunks of 16 planes; XCD k (= blockIdx % 8) gets a contiguous range of image rows, so a
   // measurement footprint is fetched into one L2 ----
   const int groups_x = (a.W + GW - 1) / GW, groups_y = (a.H + GH - 1) / GH;
-  const int gblocks_x = (groups_x + NW - 1) / NW;
-  const int chunks = (a.D + PW - 1) / PW;
-  const int per_b = groups_y * gblocks_x * chunks, total = per_b * a.B;
+  const int wchunks = (a.D + WP - 1) / WP;
+  const int per_b = groups_y * groups_x * wchunks, total = per_b * a.B;
   const int per_xcd = (total + 7) / 8;
   const int item = static_cast<int>(blockIdx.x & 7) * per_xcd + static_cast<int>(blockIdx.x >> 3);
   if (item >= total) return;
   const int b = item / per_b;
   int rem = item - b * per_b;
-  const int chunk = rem % chunks;
-  rem /= chunks;
-  const int gbx = rem % gblocks_x, gy = rem / gblocks_x;
-  const int gx = gbx * NW + wave;
-  if (gx >= groups_x) return;   // (waves are independent of each other: no workgroup barrier anywhere below)
-  const int d_block = chunk * PW;
+  int wchunk, gx, gy;
+  if (Cfg::ORDER == 1 && a.B == 1 && per_xcd * 8 == total && per_xcd % wchunks == 0) {
+    // chunk-major within the XCD's range of groups: the far chunks, whose boxes hold more cells, start first; the launch's tail is made of
+    // the cheap near chunks
+    const int l = static_cast<int>(blockIdx.x >> 3), xcd = static_cast<int>(blockIdx.x & 7), groups_per_xcd = per_xcd / wchunks;
+    wchunk = l / groups_per_xcd;
+    const int g = xcd * groups_per_xcd + l % groups_per_xcd;
+    gx = g % groups_x;
+    gy = g / groups_x;
+  } else {
+    wchunk = rem % wchunks;
+    rem /= wchunks;
+    gx = rem % groups_x;
+    gy = rem / groups_x;
+  }
+  if (Cfg::STAGGER >= 2) {   // a start delay by wave slot (64 * STAGGER_UNIT cycles per slot step)
+    constexpr int U = Cfg::STAGGER == 2 ? 8 : Cfg::STAGGER == 3 ? 16 : Cfg::STAGGER == 4 ? 32 : 64;
+    switch (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 3) {
+      case 1: __builtin_amdgcn_s_sleep(U); break;
+      case 2: __builtin_amdgcn_s_sleep(2 * U); break;
+      case 3: __builtin_amdgcn_s_sleep(3 * U); break;
+      default: break;
+    }
+  }
+  if (Cfg::STAGGER == 1) {
+    switch (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 3) {   // HW_ID.WAVE_ID: the wave's slot on its SIMD
+      case 0: __builtin_amdgcn_s_setprio(3); break;
+      case 1: __builtin_amdgcn_s_setprio(2); break;
+      case 2: __builtin_amdgcn_s_setprio(1); break;
+      default: __builtin_amdgcn_s_setprio(0); break;
+    }
+  }
+  const int d_wave = wchunk * WP;
   MFMA_TRACE(const unsigned long long tr_start = __builtin_amdgcn_s_memtime(), tr_real0 = __builtin_amdgcn_s_memrealtime();)
   MFMA_TRACE(unsigned long long tr_pos = 0, tr_box = 0, tr_tiles = 0, tr_look = 0, tr_ntiles = 0, tr_nstrips = 0, tr_first = 0;)
 
@@ -114,216 +166,266 @@ __global__ __launch_bounds__(64 * Cfg::NW, Cfg::WAVES) void sweep_mfma_kernel(Co
   const unsigned int plane_bytes = static_cast<unsigned int>(HW) * 4u;
   const unsigned int map_bytes = static_cast<unsigned int>(C) * plane_bytes;
 
-  // B operand of every MFMA of this wave: lane (p, q) holds f1[8 q + jj][pixel p], jj = 0..7
-  gcfloat_p ref = as_global(a.image1) + static_cast<size_t>(b) * C * HW + pix;
+  // B operand of every MFMA of this wave: lane (p, q) holds f1[8 q + jj][pixel p], jj = 0..7 (requested first, needed last; the channel
+  // rides in the scalar offset: no per-load address arithmetic)
+  const __amdgpu_buffer_rsrc_t ref_rsrc = map_resource(as_global(a.image1) + static_cast<size_t>(b) * C * HW, map_bytes);
   float f1v[8];
+  {
+    const unsigned int vo = (8u * q * static_cast<unsigned int>(HW) + static_cast<unsigned int>(pix)) * 4u;
 #pragma unroll
-  for (int jj = 0; jj < 8; ++jj) {
-    const float v = ref[static_cast<size_t>(FULL ? 8 * q + jj : min(8 * q + jj, C - 1)) * HW];
-    f1v[jj] = (FULL || 8 * q + jj < C) ? v : 0.0f;
+    for (int jj = 0; jj < 8; ++jj) f1v[jj] = buffer_f32(ref_rsrc, (FULL || 8 * q + jj < C) ? vo : kBufferOutOfRange, static_cast<unsigned int>(jj) * plane_bytes);
   }
 
-  // depth of plane d_block + (lane & 15) as the reference's python-double expression (utils.py:59-66)
-  const int d_lane = d_block + p;
-  const float depth_lane = plane_depth(a.inv_depth_base, a.inv_depth_step, min(d_lane, a.D - 1));
-
-  gcfloat_p Hm_g = as_global(a.Hm) + static_cast<size_t>(b) * a.M * 9;
-  gcfloat_p kt_g = as_global(a.kt) + static_cast<size_t>(b) * a.M * 3;
-
-  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // sum over frames and taps of w <f1, f2>; plane d_block + 4 j + q
-
-  for (int m = 0; m < a.M; ++m) {
-    MFMA_TRACE(const unsigned long long tr_f0 = __builtin_amdgcn_s_memtime(); if (m == 0) tr_first = tr_f0;)
-    // ---- K t / depth of the chunk's planes for this frame (utils.py:66-68: IEEE fp32 division by the fp32-rounded depth) ----
-    if (lane < PW) {
+  // ---- K t / depth for every frame and every plane of this wave (utils.py:59-68: the depth as the reference's python-double
+  // expression, then an IEEE fp32 division by the fp32-rounded depth): one pass of the wave, before any frame needs it ----
+  {
+    const int pl = lane & (WP - 1);
+    const float depth = plane_depth(a.inv_depth_base, a.inv_depth_step, min(d_wave + pl, a.D - 1));
+    gcfloat_p kt_g = as_global(a.kt) + static_cast<size_t>(b) * a.M * 3;
+    for (int i = lane; i < a.M * WP; i += 64) {
+      const int m = i / WP;
       float4v k = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (d_lane < a.D) {
-        k.x = kt_g[m * 3 + 0] / depth_lane;
-        k.y = kt_g[m * 3 + 1] / depth_lane;
-        k.z = kt_g[m * 3 + 2] / depth_lane;
+      if (d_wave + pl < a.D) {
+        k.x = kt_g[m * 3 + 0] / depth;
+        k.y = kt_g[m * 3 + 1] / depth;
+        k.z = kt_g[m * 3 + 2] / depth;
       }
-      ktd[lane] = k;
+      ktd[i] = k;
     }
-    wave_lds_fence();
+  }
+  wave_lds_fence();
+  const ccfloat_p Hm_c = as_constant(a.Hm) + static_cast<size_t>(b) * a.M * 9;
+
+  // sample positions of chunk c, frame m (the reference's fp32 arithmetic: sweep_sample.h)
+  auto positions = [&](int c, int m, SweepSamples& S) {
     float Hm[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Hm[k] = Hm_g[m * 9 + k];
+    for (int k = 0; k < 9; ++k) Hm[k] = Hm_c[m * 9 + k];
     const SweepRay ray = sweep_ray(Hm, xf, yf);
-    const __amdgpu_buffer_rsrc_t meas_rsrc = map_resource(as_global(a.image2[m]) + static_cast<size_t>(b) * C * HW, map_bytes);
-
-    // ---- this lane's four samples: north-west tap, fractional position, alive = some tap can be inside the image ----
-    int x0s[4], y0s[4];
-    float frx[4], fry[4];
-    unsigned int alive = 0u;
+    S.alive = 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float4v kd = ktd[4 * j + q];
+      const float4v kd = ktd[m * WP + c * PW + 4 * j + q];
       float ix, iy;
       sweep_sample(ray, kd.x, kd.y, kd.z, sc, &ix, &iy);   // clamped to [-1, W] x [-1, H]; NaN -> -1
-      const bool al = live && (d_block + 4 * j + q < a.D) && (ix > -1.0f) && (ix < sc.Wf) && (iy > -1.0f) && (iy < sc.Hf);
+      const bool al = live & (d_wave + c * PW + 4 * j + q < a.D) & (ix > -1.0f) & (ix < sc.Wf) & (iy > -1.0f) & (iy < sc.Hf);   // (no short-circuit: one basic block)
       const float fx = floorf(ix), fy = floorf(iy);
-      x0s[j] = static_cast<int>(fx);
-      y0s[j] = static_cast<int>(fy);
-      frx[j] = ix - fx;
-      fry[j] = iy - fy;
-      alive |= al ? (1u << j) : 0u;
+      S.xy[j] = (static_cast<int>(fx) & 0xffff) | (static_cast<int>(fy) << 16);
+      S.frx[j] = ix - fx;
+      S.fry[j] = iy - fy;
+      S.alive |= al ? (1u << j) : 0u;
     }
+  };
 
-    MFMA_TRACE(asm volatile("s_nop 0" :: "v"(x0s[0]), "v"(x0s[1]), "v"(x0s[2]), "v"(x0s[3]));)   // (the positions are complete here)
-    MFMA_TRACE(tr_pos += __builtin_amdgcn_s_memtime() - tr_f0;)
-    // ---- passes: the 16 planes as one box; a box of more than SPLIT x CAP cells (diagonal or fast epipolar motion: the box is mostly
-    // empty) is redone per 4 planes.  A box is processed in STRIPS of CAP cells of its row-major index space: one strip almost always;
-    // several under strong magnification, where a tap simply belongs to the strip that holds its cell -- no footprint is too large ----
-    int n_pass = 1;
-    for (int s = 0; s < n_pass; ++s) {
-      const int jlo = n_pass == 1 ? 0 : s, jhi = n_pass == 1 ? 4 : s + 1;
-      MFMA_TRACE(const unsigned long long tr_b0 = __builtin_amdgcn_s_memtime();)
-      // bounding box of the in-image taps of the alive samples (clipped to the image: taps outside it get weight 0 below)
-      int nlx = -100000, hx = -100000, nly = -100000, hy = -100000;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j >= jlo && j < jhi && ((alive >> j) & 1u)) {
-          nlx = max(nlx, -max(x0s[j], 0));
-          hx = max(hx, min(x0s[j] + 1, a.W - 1));
-          nly = max(nly, -max(y0s[j], 0));
-          hy = max(hy, min(y0s[j] + 1, a.H - 1));
-        }
-      const int x_hi = wave_max_i32(hx);
-      if (x_hi < 0) continue;   // no alive sample in this pass: nothing to add
-      const int x_lo = -wave_max_i32(nlx), y_lo = -wave_max_i32(nly), y_hi = wave_max_i32(hy);
-      const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1, cells = bw * bh;
-      if (n_pass == 1 && cells > Cfg::SPLIT * CAP) {
-        n_pass = 4;
-        s = -1;
-        continue;
-      }
-      const float rcp_bw = 1.0f / static_cast<float>(bw);
-      MFMA_TRACE(tr_box += __builtin_amdgcn_s_memtime() - tr_b0;)
+  SweepSamples S, Sn;
+  MFMA_TRACE(tr_first = __builtin_amdgcn_s_memtime();)
+  positions(0, 0, S);
+  MFMA_TRACE(tr_pos += __builtin_amdgcn_s_memtime() - tr_first;)
 
-      for (int base = 0; base < cells; base += CAP) {
-        const int n = min(CAP, cells - base);
-        MFMA_TRACE(const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime();)
-        // ---- dot table of the strip: cells 16 at a time through the matrix core ----
-        const int ntiles = (n + 15) >> 4;
-        constexpr int TPI = Cfg::TPI;
-        auto issue = [&](float (&A)[TPI][8], int t0) {   // operand requests of tiles t0 .. t0 + TPI - 1 (beyond the strip: no traffic, zeros)
-#pragma unroll
-          for (int u = 0; u < TPI; ++u) {
-            const int li = (t0 + u) * 16 + p;
-            // (row, column) of box cell base + li: float quotient (exact operands below 2^24: a map has fewer cells), then one step of
-            // correction either way
-            const int idx = base + li;
-            int r = static_cast<int>(static_cast<float>(idx) * rcp_bw);
-            int c = idx - r * bw;
-            if (c < 0) { c += bw; --r; }
-            if (c >= bw) { c -= bw; ++r; }
-            const unsigned int cell = static_cast<unsigned int>((y_lo + r) * a.W + x_lo + c);
-            const bool ok = li < n;
-            if (Cfg::ABLATE & 1) {
-#pragma unroll
-              for (int jj = 0; jj < 8; ++jj) A[u][jj] = static_cast<float>(cell + jj) * 1e-6f;
-            } else if (NHWC) {
-              const unsigned int vo = ok ? (cell * C + 8u * q) * 4u : kBufferOutOfRange;
-              const float4v lo = buffer_f32x4(meas_rsrc, (FULL || 8 * q < C) ? vo : kBufferOutOfRange, 0u);
-              const float4v hi = buffer_f32x4(meas_rsrc, (FULL || 8 * q + 4 < C) ? vo + 16u : kBufferOutOfRange, 0u);
-              A[u][0] = lo.x; A[u][1] = lo.y; A[u][2] = lo.z; A[u][3] = lo.w;
-              A[u][4] = hi.x; A[u][5] = hi.y; A[u][6] = hi.z; A[u][7] = hi.w;
-            } else {
-              const unsigned int vo = ok ? (8u * q * static_cast<unsigned int>(HW) + cell) * 4u : kBufferOutOfRange;
-#pragma unroll
-              for (int jj = 0; jj < 8; ++jj)
-                A[u][jj] = buffer_f32(meas_rsrc, (FULL || 8 * q + jj < C) ? vo : kBufferOutOfRange, static_cast<unsigned int>(jj) * plane_bytes);
-            }
-          }
-        };
-        auto compute = [&](const float (&A)[TPI][8], int t0) {   // D[cell][pixel]: this lane gets its own pixel p, cells 4 q .. 4 q + 3 of each tile
-          float4v c[TPI];
-#pragma unroll
-          for (int u = 0; u < TPI; ++u) c[u] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj)
-#pragma unroll
-            for (int u = 0; u < TPI; ++u) {
-              if (Cfg::ABLATE & 2) c[u][jj & 3] += A[u][jj] * f1v[jj];
-              else c[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u][jj], f1v[jj], c[u], 0, 0, 0);
-            }
-#pragma unroll
-          for (int u = 0; u < TPI; ++u)
-            if (u == 0 || t0 + u < ntiles) *reinterpret_cast<float4v*>(T + p * PITCH + (t0 + u) * 16 + 4 * q) = c[u];
-        };
-        if (Cfg::PREFETCH) {
-          float A0[TPI][8], A1[TPI][8];
-          issue(A0, 0);
-          for (int t = 0; t < ntiles; t += 2 * TPI) {
-            issue(A1, t + TPI);
-            compute(A0, t);
-            issue(A0, t + 2 * TPI);
-            if (t + TPI < ntiles) compute(A1, t + TPI);
-          }
-        } else {
-          for (int t = 0; t < ntiles; t += TPI) {
-            float A0[TPI][8];
-            issue(A0, t);
-            compute(A0, t);
-          }
-        }
-        wave_lds_fence();
-        MFMA_TRACE(const unsigned long long tr_t1 = __builtin_amdgcn_s_memtime(); tr_tiles += tr_t1 - tr_t0; tr_ntiles += ntiles; ++tr_nstrips;)
+  for (int c = 0; c < CPW; ++c) {
+    const int d_block = d_wave + c * PW;
+    if (d_block >= a.D) break;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // sum over frames and taps of w <f1, f2>; plane d_block + 4 j + q
 
-        // ---- interpolation: four table entries per sample.  Tap indices live in the box's row-major index space, clamped into the box (a
-        // tap outside the image -- the only way to fall outside the box -- has weight 0: grid_sample's zeros padding); a tap whose cell
-        // lies in another strip contributes there ----
-        const float* Tp = T + p * PITCH;
-        const int last = n - 1;
-        const unsigned int un = static_cast<unsigned int>(n);
+    for (int m = 0; m < a.M; ++m) {
+      const bool frame_follows = m + 1 < a.M;
+      const bool has_next = frame_follows || (c + 1 < CPW && d_block + PW < a.D);
+      const int c_next = frame_follows ? c : c + 1, m_next = frame_follows ? m + 1 : 0;
+      bool next_done = false;
+      const __amdgpu_buffer_rsrc_t meas_rsrc = map_resource(as_global(a.image2[m]) + static_cast<size_t>(b) * C * HW, map_bytes);
+
+      // ---- passes: the 16 planes as one box; a box of more than SPLIT x CAP cells (diagonal or fast epipolar motion: the box is
+      // mostly empty) is redone per 4 planes.  A box is processed in STRIPS of CAP cells of its row-major index space: one strip
+      // almost always; several under strong magnification, where a tap simply belongs to the strip that holds its cell ----
+      int n_pass = 1;
+      for (int s = 0; s < n_pass; ++s) {
+        const int jlo = n_pass == 1 ? 0 : s, jhi = n_pass == 1 ? 4 : s + 1;
+        MFMA_TRACE(const unsigned long long tr_b0 = __builtin_amdgcn_s_memtime();)
+        // bounding box of the taps of the alive samples: north-west taps lie in [-1, W-1] x [-1, H-1], so the box may reach one cell
+        // beyond the image -- those cells are requested out of range and arrive as zeros: grid_sample's zeros padding as a zero
+        // apron in the table, no per-tap bounds logic
+        int lo = 0x7fff7fff, hi = static_cast<int>(0x80008000u);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if ((Cfg::ABLATE & 4) && j >= jlo && j < jhi) {
-            acc[j] += Tp[min(x0s[j] & 15, last)];
-          } else if (j >= jlo && j < jhi) {
-            const int xa = x0s[j], ya = y0s[j];
-            const bool al = (alive >> j) & 1u;
-            const bool in_w = al && xa >= 0, in_e = al && xa + 1 <= a.W - 1, in_n = ya >= 0, in_s = ya + 1 <= a.H - 1;
-            const int rxa = min(max(xa - x_lo, 0), bw - 1), rxb = min(max(xa + 1 - x_lo, 0), bw - 1);
-            const int rya = min(max(ya - y_lo, 0), bh - 1) * bw - base, ryb = min(max(ya + 1 - y_lo, 0), bh - 1) * bw - base;
-            const int k_nw = rya + rxa, k_ne = rya + rxb, k_sw = ryb + rxa, k_se = ryb + rxb;
-            const float t_nw = Tp[min(max(k_nw, 0), last)], t_ne = Tp[min(max(k_ne, 0), last)];
-            const float t_sw = Tp[min(max(k_sw, 0), last)], t_se = Tp[min(max(k_se, 0), last)];
-            float2v w_n, w_s;
-            tap_weights(frx[j], fry[j], &w_n, &w_s);
-            float f = acc[j];
-            f = fmaf(t_nw, (in_w && in_n && static_cast<unsigned int>(k_nw) < un) ? w_n.x : 0.0f, f);
-            f = fmaf(t_ne, (in_e && in_n && static_cast<unsigned int>(k_ne) < un) ? w_n.y : 0.0f, f);
-            f = fmaf(t_sw, (in_w && in_s && static_cast<unsigned int>(k_sw) < un) ? w_s.x : 0.0f, f);
-            f = fmaf(t_se, (in_e && in_s && static_cast<unsigned int>(k_se) < un) ? w_s.y : 0.0f, f);
-            acc[j] = f;
+          if (j >= jlo && j < jhi && ((S.alive >> j) & 1u)) {
+            lo = pk_min_i16(lo, S.xy[j]);
+            hi = pk_max_i16(hi, S.xy[j]);
           }
-        wave_lds_fence();   // (the next strip / pass overwrites the table)
-        MFMA_TRACE(asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); tr_look += __builtin_amdgcn_s_memtime() - tr_t1;)
+        const int hi_u = wave_reduce_pk_i16<true>(hi);
+        if (hi_u == static_cast<int>(0x80008000u)) continue;   // no alive sample in this pass: nothing to add
+        const int lo_u = wave_reduce_pk_i16<false>(lo);
+        const int x_lo = static_cast<short>(lo_u & 0xffff), y_lo = lo_u >> 16;
+        const int bw = static_cast<short>(hi_u & 0xffff) + 1 - x_lo + 1, bh = (hi_u >> 16) + 1 - y_lo + 1, cells = bw * bh;
+        if (n_pass == 1 && cells > Cfg::SPLIT * CAP) {
+          n_pass = 4;
+          s = -1;
+          continue;
+        }
+        const float rcp_bw = __builtin_amdgcn_rcpf(static_cast<float>(bw));   // (1 ulp: the quotients below are corrected / rounded with a margin)
+        MFMA_TRACE(tr_box += __builtin_amdgcn_s_memtime() - tr_b0;)
+
+        // The lane's cell of successive tiles moves 16 places through the box's row-major index space: (row, column, byte offset) are
+        // kept incrementally -- per request one add, one wrap test, the bounds tests (a cell outside the image, i.e. in the zero apron, or
+        // beyond the strip is requested out of range: zeros, no traffic).  The column / row steps of 16 places are wave-uniform.
+        const int step_r = bw > 16 ? 0 : static_cast<int>(16.0f * rcp_bw + 1e-3f), step_c = 16 - step_r * bw;   // 16 = step_r * bw + step_c, 0 <= step_c < bw
+        const int cell_bytes = NHWC ? C * 4 : 4, row_bytes = a.W * cell_bytes;
+        const int step_bytes = step_r * row_bytes + step_c * cell_bytes, wrap_bytes = row_bytes - bw * cell_bytes;
+        int cur_r = 0, cur_c = 0, cur_left = 0;     // row / column in the box of the next request's cell, cells left in the strip from it
+        unsigned int cur_off = 0u;
+        auto seek = [&](int base, int n) {   // first tile of a strip: (row, column) of box cell base + p by a float quotient (exact operands
+                                             // below 2^24: a map has fewer cells) and one step of correction either way
+          const int idx = base + p;
+          int r = static_cast<int>(static_cast<float>(idx) * rcp_bw);
+          int col = idx - __mul24(r, bw);
+          if (col < 0) { col += bw; --r; }
+          if (col >= bw) { col -= bw; ++r; }
+          cur_r = r; cur_c = col; cur_left = n - p;
+          cur_off = static_cast<unsigned int>(__mul24(y_lo + r, row_bytes) + __mul24(x_lo + col, cell_bytes) + (NHWC ? 32 * q : 8 * q * HW * 4));
+        };
+        float A0[8], A1[8];
+        auto issue = [&](float (&A)[8]) {   // operand request of the next tile of the strip
+          bool ok = cur_left > 0 && static_cast<unsigned int>(x_lo + cur_c) < static_cast<unsigned int>(a.W);
+          if (!NHWC) ok = ok && static_cast<unsigned int>(y_lo + cur_r) < static_cast<unsigned int>(a.H);   // (NHWC: a row outside the image is out of range by itself)
+          const unsigned int vo = ok ? cur_off : kBufferOutOfRange;
+          if (Cfg::ABLATE & 1) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) A[jj] = static_cast<float>(vo + jj) * 1e-9f;
+          } else if (NHWC) {
+            const float4v v0 = buffer_f32x4(meas_rsrc, (FULL || 8 * q < C) ? vo : kBufferOutOfRange, 0u);
+            const float4v v1 = buffer_f32x4(meas_rsrc, (FULL || 8 * q + 4 < C) ? vo + 16u : kBufferOutOfRange, 0u);
+            A[0] = v0.x; A[1] = v0.y; A[2] = v0.z; A[3] = v0.w;
+            A[4] = v1.x; A[5] = v1.y; A[6] = v1.z; A[7] = v1.w;
+          } else {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+              A[jj] = buffer_f32(meas_rsrc, (FULL || 8 * q + jj < C) ? vo : kBufferOutOfRange, static_cast<unsigned int>(jj) * plane_bytes);
+          }
+          cur_left -= 16;
+          cur_c += step_c;
+          cur_r += step_r;
+          cur_off += static_cast<unsigned int>(step_bytes);
+          if (cur_c >= bw) { cur_c -= bw; ++cur_r; cur_off += static_cast<unsigned int>(wrap_bytes); }
+        };
+        auto compute = [&](const float (&A)[8], int t) {   // D[cell][pixel]: this lane gets its own pixel p, cells 4 q .. 4 q + 3 of the tile
+          float4v d = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            if (Cfg::ABLATE & 2) d[jj & 3] += A[jj] * f1v[jj];
+            else d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[jj], f1v[jj], d, 0, 0, 0);
+          }
+          *reinterpret_cast<float4v*>(T + p * PITCH + t * 16 + 4 * q) = d;
+        };
+
+        for (int base = 0; base < cells; base += CAP) {
+          const int n = min(CAP, cells - base);
+          const int ntiles = (n + 15) >> 4;
+          MFMA_TRACE(const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime();)
+          seek(base, n);
+          issue(A0);
+          issue(A1);
+          if (has_next && !next_done) {
+            // the next (chunk, frame)'s sample positions, in the shadow of the first operand requests
+            MFMA_TRACE(const unsigned long long tr_p0 = __builtin_amdgcn_s_memtime();)
+            positions(c_next, m_next, Sn);
+            next_done = true;
+            MFMA_TRACE(asm volatile("s_nop 0" :: "v"(Sn.xy[0]), "v"(Sn.xy[1]), "v"(Sn.xy[2]), "v"(Sn.xy[3]));)
+            MFMA_TRACE(const unsigned long long tr_p1 = __builtin_amdgcn_s_memtime(); tr_pos += tr_p1 - tr_p0; tr_tiles -= tr_p1 - tr_p0;)
+          }
+          for (int t = 0; t < ntiles; t += 2) {
+            compute(A0, t);
+            issue(A0);
+            if (t + 1 < ntiles) {
+              compute(A1, t + 1);
+              issue(A1);
+            }
+          }
+          wave_lds_fence();
+          MFMA_TRACE(const unsigned long long tr_t1 = __builtin_amdgcn_s_memtime(); tr_tiles += tr_t1 - tr_t0; tr_ntiles += ntiles; ++tr_nstrips;)
+
+          // ---- interpolation: four table entries per sample ----
+          const float* Tp = T + p * PITCH;
+          if (cells <= CAP) {
+            // the whole box is in the table and every tap of an alive sample lies in the box: index arithmetic only
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j >= jlo && j < jhi) {
+                const bool al = (S.alive >> j) & 1u;
+                const int x0 = static_cast<short>(S.xy[j] & 0xffff), y0 = S.xy[j] >> 16;
+                const int k = al ? __mul24(y0 - y_lo, bw) + (x0 - x_lo) : 0;
+                if (Cfg::ABLATE & 4) {
+                  acc[j] += Tp[k];
+                } else {
+                  const float t_nw = Tp[k], t_ne = Tp[k + 1], t_sw = Tp[k + bw], t_se = Tp[k + bw + 1];
+                  float2v w_n, w_s;
+                  tap_weights(S.frx[j], S.fry[j], &w_n, &w_s);
+                  float f = acc[j];
+                  f = fmaf(t_nw, w_n.x, f);
+                  f = fmaf(t_ne, w_n.y, f);
+                  f = fmaf(t_sw, w_s.x, f);
+                  f = fmaf(t_se, w_s.y, f);
+                  acc[j] = al ? f : acc[j];
+                }
+              }
+          } else {
+            // strips: a tap contributes in the strip that holds its cell
+            const int last = n - 1;
+            const unsigned int un = static_cast<unsigned int>(n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j >= jlo && j < jhi) {
+                const bool al = (S.alive >> j) & 1u;
+                const int x0 = static_cast<short>(S.xy[j] & 0xffff), y0 = S.xy[j] >> 16;
+                const int k_nw = (al ? __mul24(y0 - y_lo, bw) + (x0 - x_lo) : 0) - base, k_ne = k_nw + 1, k_sw = k_nw + bw, k_se = k_sw + 1;
+                const float t_nw = Tp[min(max(k_nw, 0), last)], t_ne = Tp[min(max(k_ne, 0), last)];
+                const float t_sw = Tp[min(max(k_sw, 0), last)], t_se = Tp[min(max(k_se, 0), last)];
+                float2v w_n, w_s;
+                tap_weights(S.frx[j], S.fry[j], &w_n, &w_s);
+                float f = acc[j];
+                f = fmaf(t_nw, (al && static_cast<unsigned int>(k_nw) < un) ? w_n.x : 0.0f, f);
+                f = fmaf(t_ne, (al && static_cast<unsigned int>(k_ne) < un) ? w_n.y : 0.0f, f);
+                f = fmaf(t_sw, (al && static_cast<unsigned int>(k_sw) < un) ? w_s.x : 0.0f, f);
+                f = fmaf(t_se, (al && static_cast<unsigned int>(k_se) < un) ? w_s.y : 0.0f, f);
+                acc[j] = f;
+              }
+          }
+          wave_lds_fence();   // (the next strip / pass overwrites the table)
+          MFMA_TRACE(asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); tr_look += __builtin_amdgcn_s_memtime() - tr_t1;)
+        }
+      }
+      if (has_next) {
+        if (!next_done) positions(c_next, m_next, Sn);   // (this frame had nothing to do)
+        S = Sn;
+      }
+    }
+
+    // sum over frames, then / C, then / M (for power-of-two counts x * 2^-k is x / 2^k exactly: the reference's per-frame / C followed
+    // by the mean over frames, bit for bit; otherwise one rounding closer to exact)
+    if (live) {
+      const __amdgpu_buffer_rsrc_t out_rsrc = map_resource(as_global(a.out) + static_cast<size_t>(b) * a.D * HW, static_cast<unsigned int>(a.D) * plane_bytes);
+      const unsigned int vo = (static_cast<unsigned int>(q) * static_cast<unsigned int>(HW) + static_cast<unsigned int>(pix)) * 4u;
+      const float Cf = static_cast<float>(C), Mf = static_cast<float>(a.M);
+      if (((C & (C - 1)) | (a.M & (a.M - 1))) == 0) {   // (wave-uniform)
+        const float rC = 1.0f / Cf, rM = 1.0f / Mf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (d_block + 4 * j + q < a.D)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, (acc[j] * rC) * rM), out_rsrc, static_cast<int>(vo),
+                                                  static_cast<int>(static_cast<unsigned int>(d_block + 4 * j) * plane_bytes), 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (d_block + 4 * j + q < a.D)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, (acc[j] / Cf) / Mf), out_rsrc, static_cast<int>(vo),
+                                                  static_cast<int>(static_cast<unsigned int>(d_block + 4 * j) * plane_bytes), 0);
       }
     }
   }
-
-  // sum over frames, then / C, then / M (for power-of-two counts x * 2^-k is x / 2^k exactly: the reference's per-frame / C followed
-  // by the mean over frames, bit for bit; otherwise one rounding closer to exact)
-  if (live) {
-    gfloat_p out = as_global(a.out) + (static_cast<size_t>(b) * a.D + d_block + q) * HW + pix;
-    const float Cf = static_cast<float>(C), Mf = static_cast<float>(a.M);
-    const bool pow2 = ((C & (C - 1)) | (a.M & (a.M - 1))) == 0;
-    const float rC = 1.0f / Cf, rM = 1.0f / Mf;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (d_block + 4 * j + q < a.D) out[static_cast<size_t>(4 * j) * HW] = pow2 ? (acc[j] * rC) * rM : (acc[j] / Cf) / Mf;
-  }
 #ifdef DVMVS_SWEEP_TRACE
-  {
-    const int wid = item * NW + wave;
-    if (lane == 0 && wid < kMfmaTraceWaves) {
-      unsigned long long* t = g_sweep_mfma_trace + static_cast<size_t>(wid) * kMfmaTraceWords;
-      t[0] = tr_start; t[1] = __builtin_amdgcn_s_memtime(); t[2] = tr_first - tr_start; t[3] = tr_pos; t[4] = tr_box; t[5] = tr_tiles; t[6] = tr_look;
-      t[7] = tr_ntiles | (tr_nstrips << 32); t[8] = __builtin_amdgcn_s_getreg((31 << 11) | 4); t[9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-      t[10] = tr_real0; t[11] = __builtin_amdgcn_s_memrealtime(); t[12] = blockIdx.x; t[13] = static_cast<unsigned long long>(chunk);
-    }
+  if (lane == 0 && item < kMfmaTraceWaves) {
+    unsigned long long* t = g_sweep_mfma_trace + static_cast<size_t>(item) * kMfmaTraceWords;
+    t[0] = tr_start; t[1] = __builtin_amdgcn_s_memtime(); t[2] = tr_first - tr_start; t[3] = tr_pos; t[4] = tr_box; t[5] = tr_tiles; t[6] = tr_look;
+    t[7] = tr_ntiles | (tr_nstrips << 32); t[8] = __builtin_amdgcn_s_getreg((31 << 11) | 4); t[9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    t[10] = tr_real0; t[11] = __builtin_amdgcn_s_memrealtime(); t[12] = blockIdx.x; t[13] = static_cast<unsigned long long>(wchunk);
   }
 #endif
 }
@@ -332,40 +434,30 @@ __global__ __launch_bounds__(64 * Cfg::NW, Cfg::WAVES) void sweep_mfma_kernel(Co
 template <class Cfg, bool NHWC, bool FULL>
 int launch_sweep_mfma_layout(const CostVolumeArgs& a, hipStream_t stream) {
   const long long groups_x = (a.W + Cfg::GW - 1) / Cfg::GW, groups_y = (a.H + Cfg::GH - 1) / Cfg::GH;
-  const long long total = groups_y * ((groups_x + Cfg::NW - 1) / Cfg::NW) * ((a.D + Cfg::PW - 1) / Cfg::PW) * a.B;
+  const long long total = groups_y * groups_x * ((a.D + Cfg::PW * Cfg::CPW - 1) / (Cfg::PW * Cfg::CPW)) * a.B;
   if (total > (1LL << 30)) return DVMVS_EUNSUPPORTED;
   const unsigned int grid = static_cast<unsigned int>((total + 7) / 8 * 8);
-  auto kernel = sweep_mfma_kernel<Cfg, NHWC, FULL>;
-  if (Cfg::kLdsBytes > 48 * 1024) {
-    static bool configured[64] = {};
-    int device = 0;
-    DVMVS_RETURN_IF_HIP(hipGetDevice(&device));
-    const bool tracked = device >= 0 && device < 64;
-    if (!tracked || !configured[device]) {   // idempotent per-device function attribute; racing threads write the same value
-      DVMVS_RETURN_IF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              static_cast<int>(Cfg::kLdsBytes)));
-      if (tracked) configured[device] = true;
-    }
-  }
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * Cfg::NW), Cfg::kLdsBytes, stream, a);
+  hipLaunchKernelGGL((sweep_mfma_kernel<Cfg, NHWC, FULL>), dim3(grid), dim3(64), Cfg::lds_bytes(a.M), stream, a);   // (< 48 KB of LDS: no attribute)
   return launch_status();
 }
 
 template <class Cfg>
 int launch_sweep_mfma_cfg(const CostVolumeArgs& a, hipStream_t stream) {
+  static_assert(Cfg::lds_bytes(DVMVS_MAX_MEASUREMENTS) <= 48 * 1024, "dynamic LDS beyond the default limit");
   if (a.C == kMfmaSweepChannels)
     return a.image2_nhwc ? launch_sweep_mfma_layout<Cfg, true, true>(a, stream) : launch_sweep_mfma_layout<Cfg, false, true>(a, stream);
   return a.image2_nhwc ? launch_sweep_mfma_layout<Cfg, true, false>(a, stream) : launch_sweep_mfma_layout<Cfg, false, false>(a, stream);
 }
 
-// up to 32 channels (channels-last measurement maps: a multiple of 4), maps below 2 GiB (32-bit buffer offsets), fewer than 2^24 cells
+// up to 32 channels (channels-last measurement maps: a multiple of 4), maps and one batch item's volume below 2 GiB (32-bit buffer offsets), image sides that fit the
+// packed int16 tap coordinates, fewer than 2^24 cells
 bool sweep_mfma_supports(const CostVolumeArgs& a) {
   return a.C >= 1 && a.C <= kMfmaSweepChannels && (!a.image2_nhwc || a.C % 4 == 0) && static_cast<long long>(a.C) * a.H * a.W * 4 < (1LL << 31) &&
-         static_cast<long long>(a.H) * a.W < (1LL << 24);
+         static_cast<long long>(a.D) * a.H * a.W * 4 < (1LL << 31) && a.H < 32000 && a.W < 32000 && static_cast<long long>(a.H) * a.W < (1LL << 24);
 }
 
 // the shipped configuration
-using MfmaSweepDefault = MfmaSweepConfig<4, 4, 128, 1, 4, true, 1>;
+using MfmaSweepDefault = MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1>;
 int launch_sweep_mfma(const CostVolumeArgs& a, hipStream_t stream) {
   if (!sweep_mfma_supports(a)) return DVMVS_EUNSUPPORTED;
   return launch_sweep_mfma_cfg<MfmaSweepDefault>(a, stream);
@@ -374,27 +466,37 @@ int launch_sweep_mfma(const CostVolumeArgs& a, hipStream_t stream) {
 #ifdef DVMVS_SWEEP_TUNING   // tools-only builds: configurations for tools/cv_microbench.py (variants 96 + k)
 int launch_sweep_mfma_tuning(int which, const CostVolumeArgs& a, hipStream_t stream) {
   if (!sweep_mfma_supports(a)) return DVMVS_EUNSUPPORTED;
-  switch (which) {   // <GW, GH, CAP, NW, WAVES, PREFETCH, TPI>
-    case 0: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, true, 1>>(a, stream);
-    case 1: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, false, 1>>(a, stream);
-    case 2: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, false, 2>>(a, stream);
-    case 3: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 3, true, 2>>(a, stream);
-    case 4: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 2, 4, true, 1>>(a, stream);
-    case 5: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 4, 4, true, 1>>(a, stream);
-    case 6: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 256, 1, 3, true, 2>>(a, stream);
-    case 7: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 256, 1, 4, true, 1>>(a, stream);
-    case 8: return launch_sweep_mfma_cfg<MfmaSweepConfig<8, 2, 128, 1, 4, true, 1>>(a, stream);
-    case 9: return launch_sweep_mfma_cfg<MfmaSweepConfig<2, 8, 128, 1, 4, true, 1>>(a, stream);
-    case 10: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 5, false, 1>>(a, stream);
-    case 11: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 4, 4, false, 1>>(a, stream);
-    case 12: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 64, 1, 4, true, 1>>(a, stream);
-    case 13: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 2, true, 2>>(a, stream);
+  switch (which) {   // <GW, GH, CAP, CPW, WAVES, ABLATE>
+    case 0: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4>>(a, stream);
+    case 1: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 2, 3>>(a, stream);
+    case 2: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 4, 2>>(a, stream);
+    case 3: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 5>>(a, stream);
+    case 4: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 2, 4>>(a, stream);
+    case 5: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 96, 1, 5>>(a, stream);
+    case 6: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 192, 2, 3>>(a, stream);
+    case 7: return launch_sweep_mfma_cfg<MfmaSweepConfig<8, 2, 128, 1, 4>>(a, stream);
+    case 8: return launch_sweep_mfma_cfg<MfmaSweepConfig<2, 8, 128, 1, 4>>(a, stream);
+    case 9: return launch_sweep_mfma_cfg<MfmaSweepConfig<8, 2, 128, 2, 3>>(a, stream);
+    case 10: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 4, 3>>(a, stream);
+    case 11: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 3>>(a, stream);
+    case 12: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 1, 0>>(a, stream);   // staggered priorities
+    case 13: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1>>(a, stream);   // far chunks first
+    case 14: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 1, 1>>(a, stream);   // both
+    case 15: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 2, 3, 0, 1, 1>>(a, stream);
+    case 21: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 2, 1>>(a, stream);   // start delays by wave slot
+    case 22: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 3, 1>>(a, stream);
+    case 23: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 4, 1>>(a, stream);
+    case 24: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 5, 1>>(a, stream);
+    case 25: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 2, 3, 0, 0, 1>>(a, stream);
+    case 26: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 3, 0, 0, 1>>(a, stream);
+    case 27: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 2, 0, 0, 1>>(a, stream);
+    case 28: return launch_sweep_mfma_cfg<MfmaSweepConfig<8, 2, 128, 1, 4, 0, 0, 1>>(a, stream);
     // ablations of configuration 0 (wrong results; where does the time go)
-    case 16: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, true, 1, 1>>(a, stream);   // no operand loads
-    case 17: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, true, 1, 2>>(a, stream);   // no MFMAs
-    case 18: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, true, 1, 4>>(a, stream);   // no interpolation
-    case 19: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, true, 1, 3>>(a, stream);   // neither loads nor MFMAs
-    case 20: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, true, 1, 7>>(a, stream);   // positions + boxes + table writes only
+    case 16: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 1, 0, 1>>(a, stream);   // no operand loads
+    case 17: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 2, 0, 1>>(a, stream);   // no MFMAs
+    case 18: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 4, 0, 1>>(a, stream);   // no interpolation
+    case 19: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 3, 0, 1>>(a, stream);   // neither loads nor MFMAs
+    case 20: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 7, 0, 1>>(a, stream);   // positions + boxes + table writes only
     default: return DVMVS_EINVAL;
   }
 }
