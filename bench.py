@@ -69,6 +69,7 @@ def parse():
                     help="secondary measurement: S independent sequences in lockstep on one engine (batch S); 0 = skip. "
                          "The headline value is always one sequence per GPU (BASELINE.json configs[2]).")
     ap.add_argument("--batched-steps", type=int, default=40)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (collector on, causal pipeline, pairnet)")
     return ap.parse_args()
 
 
@@ -107,7 +108,7 @@ def index_pose_sets(n_meas, count):
     names = {n: i for i, n in enumerate(syn.sample_image_names())}
     lines = [l.split() for l in open(os.path.join(ROOT, "tests", "golden", "indices", "keyframe+hololens-dataset+000+nmeas+2"))]
     lines = [[names[x] for x in l] for l in lines if len(l) == 3]
-    picks = sorted({(i * (len(lines) - 1)) // max(count - 1, 1) for i in range(count)})
+    picks = list(range(len(lines))) if count >= len(lines) else sorted({(i * (len(lines) - 1)) // max(count - 1, 1) for i in range(count)})
     sets = []
     for j in picks:
         ref, *meas = lines[j]
@@ -261,7 +262,7 @@ def batched_throughput(modules, device, args, S, M):
     return S * steps / elapsed, 1e3 * elapsed / steps, kernel_s, alg_bytes
 
 
-def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
+def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets, force_variant=None, rounds=3):
     """Average duration of one fused cost-volume op (the sweep launch + its second-pass launch) over keyframe geometries.
 
     ``pose_sets``: (reference pose, [measurement poses]) of index lines -- the duration depends on the epipolar geometry
@@ -269,6 +270,7 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
     not representative.  Each geometry runs in the sweep configuration the engine picks for it (dvmvs_sweep_plan, one sequence: the
     host-side plan model on the host copies of the matrices; lock-step batches: dvmvs.utils.sweep_variant).  Per configuration a hipGraph of ``reps`` back-to-back ops (no host
     gaps) is timed with HIP events on the stream it is replayed on.
+    ``force_variant``: time that kernel variant on every geometry instead (no work list), e.g. 6 = the correlate-then-interpolate sweep.
     Returns (mean seconds per op, algorithmic bytes per op, [per-geometry seconds], [per-geometry variant])."""
     from dvmvs import pose_algebra, utils
     from dvmvs.hip import _capi
@@ -287,13 +289,15 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
     lib = _capi.lib()
     workspace, ws_bytes = _ops.sweep_workspace(ref.device, B, n_meas, H, W, D)
 
-    use_list = engine.sweep_work_list            # as the engine launches it: with the host-planned work list of the geometry
+    use_list = engine.sweep_work_list and force_variant is None   # as the engine launches it: with the host-planned work list of the geometry
     work_list = torch.zeros(_ops.sweep_work_list_words(B, H, W, D), dtype=torch.int32, device=ref.device)
 
     def set_geometry(ref_pose, meas_poses):
         h, k, host = pose_algebra.sweep_matrices(ref_pose, meas_poses[:n_meas], half_K, ref.device, engine.pose_algebra, with_host=True)
         Hm.copy_(h)
         kt.copy_(k)
+        if force_variant is not None:
+            return force_variant
         if use_list and B == 1:
             # exactly what DepthEngine._evaluate_frame_parameters does: configuration (2 / 3, or their single-pass forms 4 / 5 when the
             # plan queues nothing) and work list in one walk
@@ -326,7 +330,6 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets):
         return graphs[variant]
 
     per_geometry, variants = [], []
-    rounds = 3
     for ref_pose, meas_poses in pose_sets:
         variant = set_geometry(ref_pose, meas_poses)
         graph = graph_for(variant)
@@ -356,6 +359,58 @@ def count_graph_kernels(graph):
         return len(re.findall(r"label=\"[^\"]*(KERNEL|kernel)", text)) or None
     except Exception:
         return None
+
+
+def make_frame_runner(engine, images, seq, full_K, M, level, cache):
+    """run_frame(k): keyframe k of the synthetic sequence through ``engine`` (the reference loop of fusionnet / pairnet run-testing.py:151-204 /
+    :136-166); ``level`` >= 1 announces the next keyframe (image + poses), as a pre-computed keyframe index allows."""
+    n_images = len(images)
+
+    def run_frame(k):
+        ids = [k - 1 - i for i in range(M)]
+        meas_images = None if cache else [images[i % n_images] for i in ids]
+        ahead = {}
+        if cache and level >= 1:
+            ahead = dict(next_reference_image=images[(k + 1) % n_images], next_frame_id=k + 1, next_reference_pose=seq[k + 1][0],
+                         next_measurement_poses=seq[k + 1][1], next_measurement_ids=[k - i for i in range(M)])
+        return engine.step(images[k % n_images], seq[k][0], meas_images, seq[k][1], full_K,
+                           frame_id=k if cache else None, measurement_ids=ids if cache else None, **ahead)
+
+    return run_frame
+
+
+def gc_quiet():
+    """CPython's cyclic collector off for a timed region, as in the standard library's timeit: its full collection is a 4-6 ms host pause
+    at an allocation count that falls a few steps into every run.  Everything allocated so far is collected and frozen first."""
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+
+
+def gc_restore():
+    gc.enable()
+    gc.unfreeze()
+
+
+def secondary_leg(modules, device, args, M, lookahead, steps, warmup, gc_on=False):
+    """A secondary throughput figure on its own engine (one sequence, this GPU): frames/s of ``steps`` keyframes after ``warmup``,
+    timed like the headline (barrier-free: world size 1), cyclic collector off unless ``gc_on``."""
+    from dvmvs.engine import DepthEngine
+    engine = DepthEngine(*modules, device=device, fold_bn=not args.no_fold_bn, cache_features=not args.no_feature_cache,
+                         use_graphs=not args.no_graphs, channels_last=args.channels_last,
+                         lstm_channels_last=not args.no_lstm_channels_last, max_lookahead=lookahead)
+    cache = not args.no_feature_cache
+    images, seq, full_K = synthetic_sequence(0, 32, warmup + steps + M + 2, M)
+    images = [im.to(device) for im in images]
+    run_frame = make_frame_runner(engine, images, seq, full_K, M, lookahead, cache)
+    with torch.no_grad():
+        if cache:
+            for k in range(M):
+                engine._half_features(k, images[k % len(images)])
+        elapsed = timed_region(lambda i: run_frame(M + i), warmup, steps, 1, device,
+                               before=None if gc_on else gc_quiet, after=None if gc_on else gc_restore)
+    assert np.isfinite(float(engine._static["depth"].mean()))
+    return steps / elapsed, engine
 
 
 def measure_small_kernels(engine, reps=20):
@@ -567,15 +622,50 @@ def train_mode(args, world, rank, device):
         dist.destroy_process_group()
 
 
+def relaunch_under_torchrun(gpus):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): replace this process by the contract's own launch line --
+    one rank per GPU on this node, rendezvous on 127.0.0.1 -- so that the command works in either shape and still prints one JSON line
+    (rank 0's).  Driven on CPU by tests/test_bench_harness.py."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def stub_mode(args, world, rank):
+    """TEST ONLY (DVMVS_BENCH_STUB_STEP_MS set; tests/test_bench_harness.py): the launch + harness path of `bench.py --gpus N` on a box
+    without GPUs -- gloo instead of RCCL, a sleeping stub instead of the frame engine -- printing a line that says so.  Never a result."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ms = float(os.environ["DVMVS_BENCH_STUB_STEP_MS"])
+    elapsed = timed_region(lambda i: time.sleep(1e-3 * ms * (1 + rank)), args.warmup, args.steps, world, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"metric": "STUB (test of the launch path only)", "value": world * args.steps / elapsed, "unit": "stub steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "data": "stub",
+                          "config": {"workload": "stub", "launched_by": os.environ.get("TORCHELASTIC_RUN_ID", "direct")}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        relaunch_under_torchrun(args.gpus)      # (does not return)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if os.environ.get("DVMVS_BENCH_STUB_STEP_MS"):
+        return stub_mode(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the plane-sweep path has no CPU fallback")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -612,6 +702,9 @@ def main():
 
     step_events = []             # one device event after every timed step: per-step device times (diagnostic, short runs)
 
+    level = 0 if args.no_feature_cache else args.lookahead      # the sequence is known in advance (as with a pre-computed keyframe index):
+    run_frame_inner = make_frame_runner(engine, images, seq, full_K, M, level, not args.no_feature_cache)   # every step announces the next keyframe
+
     def run_frame(k):
         t_host = time.perf_counter()
         try:
@@ -622,19 +715,6 @@ def main():
             if len(step_events) < 64:
                 step_events.append(torch.cuda.Event(enable_timing=True))
                 step_events[-1].record()
-
-    def run_frame_inner(k):
-        ids = [k - 1 - i for i in range(M)]
-        meas_images = None if not args.no_feature_cache else [images[i % n_images] for i in ids]
-        level = 0 if args.no_feature_cache else args.lookahead
-        ahead = {}
-        if level >= 1:      # the sequence is known in advance (as with a pre-computed keyframe index): announce the next keyframe
-            ahead = dict(next_reference_image=images[(k + 1) % n_images], next_frame_id=k + 1)
-            # ... and its poses: the engine evaluates the next frame's parameter block on its planning thread; at level 2 it also runs
-            # that frame's sweep + encoder a frame ahead (at level 1 the engine's max_lookahead stops at the feature extraction)
-            ahead.update(next_reference_pose=seq[k + 1][0], next_measurement_poses=seq[k + 1][1], next_measurement_ids=[k - i for i in range(M)])
-        return engine.step(images[k % n_images], seq[k][0], meas_images, seq[k][1], full_K,
-                           frame_id=k if not args.no_feature_cache else None, measurement_ids=ids if not args.no_feature_cache else None, **ahead)
 
     with torch.no_grad():
         # buffer fill: the first M keyframes only contribute features (reference: keyframe-buffer response 0 / short lists)
@@ -647,20 +727,15 @@ def main():
             host_seconds[0], host_seconds[1] = 0.0, 0
             step_events.clear()
             if not args.keep_gc:
-                # CPython's cyclic collector is off during the timed steps, as in the standard library's timeit: its full collection is
-                # a 4-6 ms host pause at an allocation count that falls a few steps into every run (found with gc.callbacks: one step of
-                # 5.5 ms among twenty of 0.85 ms; gc.freeze() alone only moves it).  Everything allocated so far is collected and frozen
-                # first; the collector is switched back on after the timed region.
-                gc.collect()
-                gc.freeze()
-                gc.disable()
+                gc_quiet()      # (stated in config.cyclic_gc; value_gc_on is the same run with the collector left on)
             if mark is not None:
                 mark()
 
         def region_end():
             if mark is not None:
                 mark()
-            gc.enable()
+            if not args.keep_gc:
+                gc_restore()
 
         elapsed = timed_region(lambda i: run_frame(M + i), args.warmup, args.steps, world, device, before=region_start, after=region_end)
         host_ms = 1e3 * host_seconds[0] / max(host_seconds[1], 1)
@@ -669,7 +744,7 @@ def main():
 
     result = None
     if rank == 0:
-        picks, whole_index = [], None
+        picks, whole_index, all_pairs, mfma_variant = [], None, None, None
         if args.no_roofline_leg:
             kernel_s, alg_bytes, per_geometry, variants = float("nan"), (1 + M) * 32 * 128 * 160 * 4 + 64 * 128 * 160 * 4, [], []
         else:
@@ -682,6 +757,22 @@ def main():
             whole_index = {"kernel_us": w_s * 1e6, "frac": alg_bytes / w_s / 1e9 / HBM_PEAK_GBPS, "index_lines": picks,
                            "kernel_us_per_geometry": [round(t * 1e6, 2) for t in w_per], "sweep_variant_per_geometry": w_var,
                            "worst_us": max(w_per) * 1e6}
+            # ... and EVERY keyframe pair of the index (285 lines; fewer repetitions per pair): the figure that does not flatter
+            all_lines, all_sets = index_pose_sets(M, 10 ** 6)
+            reps_all = max(2, args.kernel_reps // 3)
+            a_s, _, a_per, a_var = measure_cost_volume_kernel(engine, M, reps_all, all_sets, rounds=2)
+            all_pairs = {"pairs": len(a_per), "kernel_us": a_s * 1e6, "frac": alg_bytes / a_s / 1e9 / HBM_PEAK_GBPS, "worst_us": max(a_per) * 1e6,
+                         "worst_index_line": all_lines[int(np.argmax(a_per))], "p90_us": float(np.percentile(a_per, 90)) * 1e6,
+                         "sweep_variants": {str(v): a_var.count(v) for v in sorted(set(a_var))}}
+            # the correlate-then-interpolate sweep on the fp32 matrix cores (variant 6, csrc/sweep_mfma.hip: built and parity-tested this
+            # round, NOT the engine's choice -- DESIGN.md section 4.1b says why) on the same geometries, same harness
+            m_s, _, m_per, _ = measure_cost_volume_kernel(engine, M, args.kernel_reps, timed, force_variant=6)
+            ma_s, _, ma_per, _ = measure_cost_volume_kernel(engine, M, reps_all, all_sets, force_variant=6, rounds=2)
+            mfma_variant = {"kernel": "sweep_mfma_kernel (variant 6: tap dots per measurement cell on v_mfma_f32_16x16x4_f32, table look-ups per plane)",
+                            "engine_uses_it": False, "kernel_us_timed_steps": m_s * 1e6, "frac_timed_steps": alg_bytes / m_s / 1e9 / HBM_PEAK_GBPS,
+                            "kernel_us_all_pairs": ma_s * 1e6, "frac_all_pairs": alg_bytes / ma_s / 1e9 / HBM_PEAK_GBPS,
+                            "worst_us_all_pairs": max(ma_per) * 1e6, "pairs_where_faster_than_engine_choice": int(sum(1 for x, y in zip(ma_per, a_per) if x < y)),
+                            "kernel_us_per_geometry_timed_steps": [round(t * 1e6, 2) for t in m_per]}
         achieved = alg_bytes / kernel_s / 1e9
         # HBM bytes per op from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: only when the committed measurement was taken on
         # exactly the kernel sources that are being benchmarked, otherwise null (profiles/README.md says how to re-collect)
@@ -703,18 +794,21 @@ def main():
         valu_tflops = useful_flop / kernel_s / 1e12
         lds_bytes = 128 * 160 * 64 * M * 4 * 32 * 4
         other_kernels = None if args.no_roofline_leg else measure_small_kernels(engine)
-        launches_per_frame = None
-        try:     # kernel nodes of the captured frame graph (what one replay launches); None where the runtime cannot dump a graph
-            launches_per_frame = {f"n_meas={k[0]},has_previous={k[1]},sweep_variant={k[2]}": count_graph_kernels(g) for k, g in engine._graphs.items()}
+        launches_per_frame = {}
+        try:     # kernel nodes of the captured frame graph (what one replay launches), where the runtime can dump a graph
+            counts = {f"n_meas={k[0]},has_previous={k[1]},sweep_variant={k[2]}": count_graph_kernels(g) for k, g in engine._graphs.items()}
+            launches_per_frame.update({k: v for k, v in counts.items() if v is not None})
         except Exception:
             pass
-        try:     # ... and the count a rocprofv3 kernel trace of this command's timed region recorded (profiles/, per round)
-            import glob
-            region = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_timed_region*.csv")))[-1]
+        try:     # ... and the count a rocprofv3 kernel trace of THIS command's timed region recorded at the benchmarked look-ahead level
+            import glob      # (profiles/, per round: the newest round that has one)
+            level = 0 if args.no_feature_cache else args.lookahead
+            region = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_timed_region_lookahead{level}.csv")))[-1]
             last = open(region).read().strip().splitlines()[-1].split(",")
-            launches_per_frame = dict(launches_per_frame or {}, profiled=float(last[5]) / float(last[7]), profiled_source=os.path.relpath(region, ROOT))
+            launches_per_frame.update(profiled=float(last[5]) / float(last[7]), profiled_source=os.path.relpath(region, ROOT), profiled_lookahead=level)
         except Exception:
             pass
+        launches_per_frame = launches_per_frame or None
         rel = golden_rel_l1(modules, device, args) if not args.no_rel_l1 else None
         result = {
             "metric": "depth frames/sec/GPU @ 320x256x64 planes (fusionnet); rel-L1 vs ref",
@@ -735,9 +829,14 @@ def main():
                        "conv_epilogues_inside_miopen": (lambda rep: f"{sum(1 for r in rep if r[2])} of {len(rep)} dense convolution problems "
                                                         "(bit-identical to convolution + epilogue AND faster at warm-up)")(engine.conv_plan_report()),
                        "weights": "seeded (tests/synthetic.py) + published FPN checkpoint",
+                       "cyclic_gc": "left on" if args.keep_gc else "disabled during the timed steps (gc.collect + gc.freeze before, re-enabled after), as "
+                                    "timeit does; value_gc_on = the same measurement with CPython's collector left on",
                        "parallelism": f"sequence-sharded x{world}, no data-path collective"},
             "roofline": {"kernel": "sweep_tiled_kernel + sweep_spill_kernel (fused warp + correlation, all planes, all measurement frames)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "sample": "frac / achieved / kernel_us: mean over the keyframe geometries of the timed steps (easy sideways pairs on a short run); "
+                                   "all_pairs: every pair of the 285-line keyframe index; whole_index: 25 lines spread over it",
+                         "all_pairs": all_pairs,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel_us": kernel_s * 1e6, "algorithmic_bytes": alg_bytes,
                          "geometries": f"the keyframe geometries of the {len(per_geometry)} timed steps (index lines "
                                        f"{(M + args.warmup + 37 * rank) % 286}.. of the sample scene's nmeas+2 index, consecutive), each in the sweep "
@@ -760,6 +859,7 @@ def main():
             "roofline_lds": {"bound": "lds", "achieved": lds_bytes / kernel_s / 1e12, "peak": LDS_PEAK_TBPS, "unit": "TB/s",
                              "frac": lds_bytes / kernel_s / 1e12 / LDS_PEAK_TBPS, "lds_bytes": lds_bytes,
                              "pattern_floor_us": SWEEP_LDS_PATTERN_FLOOR_US, "frac_of_pattern_floor": SWEEP_LDS_PATTERN_FLOOR_US / (kernel_s * 1e6)},
+            "roofline_mfma_variant": mfma_variant,
             "roofline_other": other_kernels,
             "launches_per_frame": launches_per_frame,
             "rel_l1": None if rel is None else {
@@ -794,6 +894,31 @@ def main():
             except Exception as e:   # the secondary figure must never cost the headline line
                 result["value_batched"] = None
                 result["batched"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_secondary:
+            # secondary figures, each on its own engine, never at the cost of the headline line: (i) the collector left on, (ii) the causal
+            # pipeline (no look-ahead: what an online caller without the next frame gets), (iii) BASELINE.json configs[1]: pairnet inference
+            # (M = 1, no ConvLSTM; /root/reference/dvmvs/pairnet/run-testing.py:136-166)
+            steps2, warm2 = min(args.steps, 60), max(args.warmup, 5)
+            level = 0 if args.no_feature_cache else args.lookahead
+            for key, fn in (("value_gc_on", lambda: secondary_leg(modules, device, args, M, level, steps2, warm2, gc_on=True)[0]),
+                            ("value_causal", lambda: secondary_leg(modules, device, args, M, 0, steps2, warm2)[0])):
+                try:
+                    result[key] = fn()
+                except Exception as e:
+                    result[key] = None
+                    result[key + "_error"] = f"{type(e).__name__}: {e}"
+            try:
+                import synthetic as syn
+                from dvmvs.pairnet.model import CostVolumeDecoder, CostVolumeEncoder, FeatureExtractor, FeatureShrinker
+                pair_modules = syn.build_e2e_modules((FeatureExtractor, FeatureShrinker, CostVolumeEncoder, CostVolumeDecoder))
+                pair_modules.insert(3, None)
+                fps_p, pair_engine = secondary_leg(pair_modules, device, args, 1, level, steps2, warm2)
+                result["pairnet"] = {"value": fps_p, "unit": "frames/s", "ms_per_step": 1e3 / fps_p, "steps": steps2, "warmup": warm2,
+                                     "config": {"workload": "pairnet inference, one synthetic-image sequence on the sample scene's keyframe poses, 320x256, "
+                                                            "64 planes, M=1 measurement frame, batch 1 (BASELINE.json configs[1])",
+                                                "lookahead": level, "hip_graphs": not args.no_graphs, "feature_cache": not args.no_feature_cache}}
+            except Exception as e:
+                result["pairnet"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             cpu_mods = build_modules()
             result["cpu_baseline"] = cpu_baseline(args, cpu_mods, M)

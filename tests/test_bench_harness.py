@@ -55,3 +55,33 @@ def test_timed_region_single_process():
     elapsed = bench.timed_region(lambda i: seen.append(i), warmup=2, steps=5, world=1, device=torch.device("cpu"),
                                  before=lambda: seen.append("before"), after=lambda: seen.append("after"))
     assert seen == [0, 1, "before", 2, 3, 4, 5, 6, "after"] and 0.0 <= elapsed < 0.5
+
+
+def test_bench_py_gpus_2_launches_itself(tmp_path):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must not exit -- it re-executes itself under
+    torch.distributed.run (one rank per GPU, 127.0.0.1 rendezvous) and rank 0 prints ONE JSON line.  Here: the stub step on CPU / gloo
+    (DVMVS_BENCH_STUB_STEP_MS), the same launch path."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DVMVS_BENCH_STUB_STEP_MS"] = "3"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 6 and rec["data"] == "stub"
+    assert rec["ms_per_step"] >= 6.0          # the slow rank (2 x 3 ms per step) decides
+    # the launcher shape the driver uses still works unchanged
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len([l for l in out.stdout.splitlines() if l.startswith("{")]) == 1
+    # a world size that contradicts --gpus is still an error
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=dict(env, WORLD_SIZE="2", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "does not match" in bad.stderr
