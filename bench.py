@@ -861,6 +861,9 @@ def main():
                              "pattern_floor_us": SWEEP_LDS_PATTERN_FLOOR_US, "frac_of_pattern_floor": SWEEP_LDS_PATTERN_FLOOR_US / (kernel_s * 1e6)},
             "roofline_mfma_variant": mfma_variant,
             "roofline_other": other_kernels,
+            # what the engine's warm-up costs (outside the timed steps): eager first frames, graph capture, first launches of the graphs
+            # captured ahead; device memory reserved beyond live tensors (the captured graphs' private pools are part of it)
+            "warmup": engine.graph_memory_report(),
             "launches_per_frame": launches_per_frame,
             "rel_l1": None if rel is None else {
                 "what": "depth rel-L1 mean(|d - d_ref| / d_ref) of this engine configuration (graph replay included) vs the REFERENCE forward "

@@ -29,6 +29,7 @@ MI355X-specific execution choices (none of them changes results beyond fp32 roun
   launch.  ``pose_algebra="exact"`` evaluates them on the device in fp64 inside the captured frame instead.
 """
 import copy
+import time
 import os
 from collections import OrderedDict
 
@@ -427,6 +428,10 @@ class DepthEngine:
         if max_lookahead is None:
             max_lookahead = int(os.environ.get("DVMVS_LOOKAHEAD", "1"))
         self.max_lookahead = max(0, min(2, int(max_lookahead)))
+        # what warming up costs (bench.py reports it): wall seconds of the eager first frames, of graph capture, of the first launches of
+        # graphs captured ahead; how many such graphs
+        self.warmup_seconds = {"eager_first_frames": 0.0, "graph_capture": 0.0, "graph_first_launches": 0.0}
+        self.warmup_graphs_launched = 0
         self.sweep_variant_counts = {}     # frames per sweep configuration (dvmvs_cost_volume_fwd's variant) since construction
         # host-planned work list for the sweep: only where the matrices exist on the host, and one plan per launch (one sequence)
         self.sweep_work_list = bool(_utils.SWEEP_WORK_LIST and self.pose_algebra == "reference" and _utils.COST_VOLUME_VARIANT in (0, 2, 3, 4, 5))
@@ -525,6 +530,7 @@ class DepthEngine:
                 self._feature_pool = torch.empty((self.cache_size + 1,) + tuple(half.shape), device=self.device, dtype=torch.float32)
                 self._feature_free = list(range(self.cache_size, -1, -1))
                 self._feature_cache.clear()
+                self._feature_slot = {}
             if frame_id in self._feature_cache:
                 slot = self._feature_cache.pop(frame_id)
             else:
@@ -956,7 +962,6 @@ class DepthEngine:
         measurement_ids = measurement_ids or [None] * n_meas
         clock = self.step_clock      # None, or a list that receives this step's host checkpoints (tools/step_times_probe.py)
         if clock is not None:
-            import time
             marks = [("enter", time.perf_counter())]
             clock.append(marks)
             mark = lambda name: marks.append((name, time.perf_counter()))
@@ -972,7 +977,11 @@ class DepthEngine:
 
         # ---- what the previous call prepared for this frame: 0 nothing, 1 its reference features, 2 also its sweep + encoder ----
         have, ready = 0, self._prefetched
-        if self.direct and frame_id is not None and ready is not None and ready["frame_id"] == frame_id and ready["parity"] == parity:
+        # (a frame id alone does not identify an image: the prepared features are taken only for the very tensor that was announced --
+        # same storage, unmodified since; the engine keeps the announced tensor alive, so the address cannot have been reused)
+        if self.direct and frame_id is not None and ready is not None and ready["frame_id"] == frame_id and ready["parity"] == parity and \
+                ready["image"].data_ptr() == reference_image.data_ptr() and ready["image_version"] == reference_image._version and \
+                ready["image"].device == reference_image.device and tuple(ready["image"].stride()) == tuple(reference_image.stride()):
             have = 1
             if ready["level"] == 2 and ready["measurement_ids"] == list(measurement_ids) and len(ready["measurement_poses"]) == n_meas and \
                     torch.equal(ready["full_K"], _pose_algebra.to_host(full_K).reshape(-1, 3, 3)) and \
@@ -1051,8 +1060,11 @@ class DepthEngine:
         elif kind not in self._warm:
             # first occurrence of this kind of frame: run eagerly (lets MIOpen pick its solvers, times the fusion plans); state
             # buffers are updated by the body, so this is a real frame, not a throw-away
+            t_eager = time.perf_counter()
             self._frame_body(*body)
             self._warm.add(kind)
+            torch.cuda.synchronize(self.device)
+            self.warmup_seconds["eager_first_frames"] += time.perf_counter() - t_eager
         else:
             known = set(self._graphs)
             if key not in self._graphs:
@@ -1060,6 +1072,7 @@ class DepthEngine:
                 # caller is still warming up: with look-ahead the steady-state pattern (this frame's share prefetched, the next frame's
                 # being prefetched) for both buffer sets and both sweep configurations, without it both configurations.  A later frame
                 # whose geometry asks for the other configuration finds its graph ready instead of paying ~0.1 s of capture mid-run.
+                t_capture = time.perf_counter()
                 self._graphs[key] = self._capture(body)
                 if give:
                     tiled = (2, 3, 4, 5)      # the sweep's configurations x (two passes, one pass): whichever a later geometry asks for
@@ -1076,6 +1089,7 @@ class DepthEngine:
                             k = graph_key(par, have, 0, v, 0)
                             if k not in self._graphs:
                                 self._graphs[k] = self._capture((n_meas, kind[1], v, par, have, 0, 0, 0))
+                self.warmup_seconds["graph_capture"] += time.perf_counter() - t_capture
             fresh = [k for k in self._graphs if k not in known and k != key]
             if fresh and self.warm_captured_graphs:
                 # A graph's FIRST launch stalls the device for ~5 ms (its kernel arguments and code are set up then, not at capture):
@@ -1083,12 +1097,22 @@ class DepthEngine:
                 # configuration or buffer set.  So every graph captured ahead is launched once now, during warm-up, on throw-away
                 # results: the recurrent state is put back afterwards, and everything else the launch writes is rewritten by the real
                 # frame below (same image, same features) before anybody reads it.
+                # One exception: a frame whose sweep + encoder ran a frame ahead (have == 2) does NOT recompute them, and a fresh graph of the
+                # other parity runs ITS look-ahead stage -- other measurement count, other sweep configuration, the work list of another
+                # geometry -- on this frame's buffer set.  Those buffers are saved and put back as well.
+                t_warm = time.perf_counter()
                 keep = [s[k].clone() for k in ("h", "c", "prev_depth")] if self.is_fusionnet else []
+                keep_set = self._snapshot(cur) if (self.direct and have == 2) else None
                 for _ in range(self.warm_graph_launches):
                     for k in fresh:
                         self._graphs[k].replay()
                 for name, saved in zip(("h", "c", "prev_depth"), keep):
                     s[name].copy_(saved)
+                if keep_set is not None:
+                    self._restore(cur, keep_set)
+                torch.cuda.synchronize(self.device)
+                self.warmup_seconds["graph_first_launches"] += time.perf_counter() - t_warm
+                self.warmup_graphs_launched += len(fresh)
             self._graphs[key].replay()
         mark("frame launched")
         self._prev_pose_host = committed_pose
@@ -1097,7 +1121,8 @@ class DepthEngine:
         if self.direct:
             self._prefetched = None
             if give >= 1 and next_frame_id is not None:
-                self._prefetched = dict(frame_id=next_frame_id, parity=1 - parity, level=give, sweep_variant=next_variant)
+                self._prefetched = dict(frame_id=next_frame_id, parity=1 - parity, level=give, sweep_variant=next_variant,
+                                        image=next_reference_image, image_version=next_reference_image._version)
                 if give == 2:
                     to_host = _pose_algebra.to_host
                     self._prefetched.update(pose=to_host(next_reference_pose).reshape(-1, 4, 4).clone(), measurement_ids=list(next_measurement_ids),
@@ -1108,6 +1133,52 @@ class DepthEngine:
             self._remember(frame_id, s["ref_half"])
         mark("done")
         return s["depth"]
+
+    @staticmethod
+    def _snapshot(tree):
+        """Clones every tensor of a (nested dict / list of) buffer set."""
+        if isinstance(tree, torch.Tensor):
+            return tree.clone()
+        if isinstance(tree, dict):
+            return {k: DepthEngine._snapshot(v) for k, v in tree.items()}
+        if isinstance(tree, (list, tuple)):
+            return [DepthEngine._snapshot(v) for v in tree]
+        return None
+
+    @staticmethod
+    def _restore(tree, saved):
+        if isinstance(tree, torch.Tensor):
+            tree.copy_(saved)
+        elif isinstance(tree, dict):
+            for k, v in tree.items():
+                DepthEngine._restore(v, saved[k])
+        elif isinstance(tree, (list, tuple)):
+            for v, w in zip(tree, saved):
+                DepthEngine._restore(v, w)
+
+    def graph_memory_report(self):
+        """Captured frame graphs and the device memory of their private pools (bytes; None where the runtime does not say)."""
+        pools = None
+        try:
+            stats = torch.cuda.memory_stats(self.device)
+            pools = int(stats.get("reserved_bytes.all.current", 0)) - int(stats.get("allocated_bytes.all.current", 0))
+        except Exception:
+            pass
+        return {"graphs": len(self._graphs), "graphs_launched_once_at_warmup": self.warmup_graphs_launched,
+                "reserved_minus_allocated_bytes": pools, "warmup_seconds": {k: round(v, 4) for k, v in self.warmup_seconds.items()}}
+
+    def refresh_weights(self):
+        """Call after loading new parameters into this engine's modules (``engine.fe`` ... ``engine.dec``): the MFMA convolution kernels
+        read re-packed copies of the weights, made at first use.  They are re-packed IN PLACE, so captured graphs stay valid."""
+        for m in (self.fe, self.fs, self.enc, self.lstm, self.dec):
+            for sub in ([] if m is None else m.modules()):
+                if isinstance(sub, FusedConv2d):
+                    if sub._bottleneck_packed is not None:
+                        sub._bottleneck_packed.copy_(_ops.bottleneck_conv_pack(sub.weight.detach()))
+                    for tile, packed in sub._direct_packed.items():
+                        packed.copy_(_ops.direct_conv_pack(sub.weight.detach(), tile))
+        if self._lstm_packed is not None:
+            self._lstm_packed.copy_(_ops.bottleneck_conv_pack(self.lstm.lstm_cell.conv.weight.detach()))
 
     def _capture(self, key):
         """Captures the frame body for ``key`` into a hipGraph.  Capture only records the launches (nothing executes, no

@@ -366,19 +366,21 @@ def test_lookahead_is_bit_identical(hip_device):
                 (200, True), (201, True), (202, True), (203, True), (204, False)]
     frames = [(None if i is None else lines[i], flag) for i, flag in schedule]
     used = {"shallow": 0, "deep": 0}
+    held = {}      # the device image of a frame: the SAME tensor when it is announced and when it comes (what a runner hands over)
+    image = lambda i: held.setdefault(i, syn.e2e_image(i).to(dev))
     for n, (item, announce) in enumerate(frames):
         if item is None:
             for e in (shallow, deep, plain):
                 e.reset()
             continue
         r, ms = item
-        args = (syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK)
+        args = (image(r), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK)
         upcoming = next((f[0] for f in frames[n + 1:] if f[0] is not None), None)
         kw1, kw2 = {}, {}
         if announce and upcoming is not None:
             nr, nms = upcoming
             nxt = nr if announce is True else nr + 1
-            kw1 = dict(next_reference_image=syn.e2e_image(nxt).to(dev), next_frame_id=nxt)
+            kw1 = dict(next_reference_image=image(nxt), next_frame_id=nxt)
             kw2 = dict(kw1, next_reference_pose=syn.pose(nxt), next_measurement_poses=[syn.pose(i) for i in nms], next_measurement_ids=list(nms))
         ready = {name: (e._prefetched["level"] if e._prefetched and e._prefetched["frame_id"] == r else 0) for name, e in (("shallow", shallow), ("deep", deep))}
         a = shallow.step(*args, frame_id=r, measurement_ids=list(ms), **kw1).clone()
@@ -395,6 +397,63 @@ def test_lookahead_is_bit_identical(hip_device):
     assert any(k[4] == 1 and k[5] == 1 for k in shallow._graphs)      # ... through replayed graphs of the steady-state patterns
     assert any(k[4] == 2 and k[5] == 2 for k in deep._graphs)
     assert deep.sweep_variant_counts == plain.sweep_variant_counts
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_lookahead_random_schedules_are_bit_identical(hip_device, seed):
+    """Property test: random schedules of keyframes with correct / wrong / missing announcements, an announced frame id
+    that then comes with ANOTHER image, tracking losses and changes of the measurement count, through engines at look-ahead levels 1 and 2
+    (level 2 is where a newly needed graph is captured while this frame's sweep + encoder are already done: ADVICE r4) -- every depth map
+    and the recurrent state equal, bit for bit, those of an engine without look-ahead."""
+    dev = hip_device
+    rng = np.random.default_rng(seed)
+    mods, shallow = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True, max_lookahead=1)
+    _, deep = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True, max_lookahead=2)
+    _, plain = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True, max_lookahead=0)
+    fullK = syn.full_K()
+    lines = syn.keyframe_index_lines(2)
+    held = {}
+    image = lambda i: held.setdefault(i, syn.e2e_image(i).to(dev))
+    start = int(rng.integers(0, 200))
+    schedule = []      # (index line or None, number of measurement frames)
+    for j in range(22):
+        if j in (7, 15) and rng.random() < 0.7:
+            schedule.append((None, 0))
+        schedule.append((start + j, 1 if rng.random() < 0.25 else 2))
+    accepted = {"shallow": 0, "deep": 0}
+    for n, (li, n_meas) in enumerate(schedule):
+        if li is None:
+            for e in (shallow, deep, plain):
+                e.reset()
+            continue
+        r, ms = lines[li]
+        ms = list(ms)[:n_meas]
+        upcoming = next(((lines[l], k) for l, k in schedule[n + 1:] if l is not None), None)
+        kw1, kw2 = {}, {}
+        what = rng.choice(["right", "right", "right", "none", "wrong_frame", "wrong_image"]) if upcoming is not None else "none"
+        if what != "none":
+            (nr, nms), nk = upcoming
+            nms = list(nms)[:nk]
+            if what == "wrong_frame":
+                nr = nr + 1
+            # "wrong_image": the right frame id, but the image that will come is another tensor (here: a fresh copy of another frame's image)
+            announced = image(nr) if what != "wrong_image" else syn.e2e_image(nr + 2).to(dev)
+            kw1 = dict(next_reference_image=announced, next_frame_id=nr)
+            kw2 = dict(kw1, next_reference_pose=syn.pose(nr), next_measurement_poses=[syn.pose(i) for i in nms], next_measurement_ids=nms)
+        args = (image(r), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK)
+        for name, e in (("shallow", shallow), ("deep", deep)):
+            p = e._prefetched
+            accepted[name] += bool(p and p["frame_id"] == r and p["image"].data_ptr() == args[0].data_ptr())
+        a = shallow.step(*args, frame_id=r, measurement_ids=ms, **kw1).clone()
+        b = deep.step(*args, frame_id=r, measurement_ids=ms, **kw2).clone()
+        c = plain.step(*args, frame_id=r, measurement_ids=ms).clone()
+        assert torch.equal(a, c), (seed, n, li, what, "level 1")
+        assert torch.equal(b, c), (seed, n, li, what, "level 2")
+        for e in (shallow, deep):
+            assert torch.equal(e._static["h"], plain._static["h"]) and torch.equal(e._static["c"], plain._static["c"]), (seed, n)
+    print(f"seed {seed}: prepared stages accepted on {accepted} of {sum(l is not None for l, _ in schedule)} frames; "
+          f"graphs: level 1 {len(shallow._graphs)}, level 2 {len(deep._graphs)}; warm-up {deep.graph_memory_report()}")
+    assert accepted["shallow"] >= 4 and accepted["deep"] >= 4
 
 
 def test_planning_a_frame_ahead_is_bit_identical(hip_device):
