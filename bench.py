@@ -428,13 +428,24 @@ def measure_small_kernels(engine, reps=20):
     T = torch.eye(4, device=dev).repeat(S, 1, 1)
     T[:, 0, 3] = 0.05
     prev_depth = torch.rand(S, 1, H, W, device=dev) * 3 + 0.5
-    zbuffer, low = torch.zeros(S, H // 2, W // 2, device=dev), torch.zeros(S, 1, H // 32, W // 32, device=dev)
+    low = [torch.zeros(S, 1, H // 32, W // 32, device=dev) for _ in range(2)]
     full_K, half_K, lstm_K = s["full_K"].clone(), s["half_K"].clone(), s["lstm_K"].clone()
+    n_splits = 16      # K-splits of the cell's convolution (dvmvs_bottleneck_conv_fwd) that the gates kernel adds up itself
+    parts = torch.randn(n_splits * S * 2048 * (H // 32) * (W // 32), device=dev) * 0.25
+    flip = [0]
+
+    def reproject():      # as the engine calls it: two estimate buffers alternating, each launch zero-fills the other one
+        flip[0] ^= 1
+        _ops.depth_reproject_estimate_into(T, prev_depth, full_K, half_K, low[flip[0]], low[1 - flip[0]], 16)
+
     calls = {
         "lstm_gates": (lambda: _ops.lstm_gates_into(cc, c_state, h_state), 2048 * 80 * 4 + 512 * 80 * 4 + 2 * 512 * 80 * 4, 1),
+        # what the engine launches since round 5: the gates on the convolution's 16 partial sums (no reduction launch in front)
+        "lstm_gates_on_partial_sums": (lambda: _ops.lstm_gates_partials_into(parts, n_splits, c_state, h_state),
+                                       n_splits * 2048 * 80 * 4 + 512 * 80 * 4 + 2 * 512 * 80 * 4, 1),
         "hidden_warp": (lambda: _ops.hidden_warp_into(h_state, estimate, T, lstm_K, True, warped), 2 * 512 * 80 * 4 + 80 * 4, 1),
-        "depth_reproject": (lambda: _ops.depth_reproject_lowres_into(T, prev_depth, full_K, half_K, zbuffer, low, 16),
-                            H * W * 4 + (H // 2) * (W // 2) * 4, 2),
+        # one launch since round 5 (straight into the 8x10 estimate; reads the previous depth once)
+        "depth_reproject": (reproject, H * W * 4 + 2 * (H // 32) * (W // 32) * 4, 1),
     }
     out = {}
     for name, (fn, alg_bytes, launches) in calls.items():

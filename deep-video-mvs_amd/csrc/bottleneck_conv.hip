@@ -192,8 +192,8 @@ int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * static_cast<size_t>(a.cs) * PLANE;
   if (lds > kBcLdsBytes) return DVMVS_EUNSUPPORTED;
   const dim3 grid((a.n_tiles + kBcWaves - 1) / kBcWaves, a.splits, a.B * (P / kBcPixels)), block(kBcWaves * 64);
-  const int groups = a.cs / 16;
-#ifdef DVMVS_SWEEP_TUNING      // tools-only build: DVMVS_BC_CH=1|2|4 forces the request burst (tools/lstm_conv_probe.py)
+#ifdef DVMVS_SWEEP_TUNING
+  const int groups = a.cs / 16;      // tools-only build: DVMVS_BC_CH=1|2|4 forces the request burst (tools/lstm_conv_probe.py)
   if (const char* ch = getenv("DVMVS_BC_CH")) {
     const int c = atoi(ch);
     if (c == 1 || groups % c == 0) {

@@ -45,6 +45,48 @@ __global__ __launch_bounds__(256) void depth_splat_kernel(const float* __restric
   atomicMax(out_bits + static_cast<size_t>(b) * hh * hw + static_cast<int>(v) * hw + static_cast<int>(u), __float_as_uint(z_store));
 }
 
+// Frame path (round 5): the ConvLSTM reads only rows / columns 0, f, 2f, ... of the half-resolution estimate
+// (F.interpolate(scale_factor=1/f, mode="nearest"), fusionnet/run-testing.py:176-189), so only source points that land on those
+// pixels matter: the splat goes straight into the [Ho, Wo] estimate (same atomicMax on the same relu(z) bits: the value that the
+// half-resolution z-buffer would hold there), and the launch clears the OTHER estimate buffer for the frame after next -- frames
+// alternate between two buffers, so there is neither a half-resolution z-buffer nor a decimate / clear launch.
+__global__ __launch_bounds__(256) void depth_splat_estimate_kernel(const float* __restrict__ trans, const float* __restrict__ prev_depth,
+                                                                   const float* __restrict__ full_K, const float* __restrict__ half_K,
+                                                                   unsigned int* __restrict__ estimate_bits, float* __restrict__ clear,
+                                                                   int B, int Hf, int Wf, int f) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.y;
+  const float* s_T = trans + b * 16;
+  const int HWf = Hf * Wf;
+  const int hw = Wf / 2, hh = Hf / 2;
+  const int wo = hw / f, ho = hh / f;
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (clear != nullptr && pix < ho * wo) clear[static_cast<size_t>(b) * ho * wo + pix] = 0.0f;
+  if (pix >= HWf) return;
+  const int y = pix / Wf, x = pix - y * Wf;
+  const float* Kf = full_K + b * 9;
+  const float* Kh = half_K + b * 9;
+  const float d = prev_depth[static_cast<size_t>(b) * HWf + pix];
+  // (the arithmetic of depth_splat_kernel, operation for operation)
+  const float px = ((static_cast<float>(x) - Kf[2]) / Kf[0]) * d;
+  const float py = ((static_cast<float>(y) - Kf[5]) / Kf[4]) * d;
+  const float pz = d;
+  float q[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) q[r] = ((s_T[r * 4 + 0] * px + s_T[r * 4 + 1] * py) + s_T[r * 4 + 2] * pz) + s_T[r * 4 + 3];
+  const float sw = fabsf(q[3]) > kReprojEps ? 1.0f / q[3] : 1.0f;
+  const float X = sw * q[0], Y = sw * q[1], Z = sw * q[2];
+  const float z_store = fmaxf(Z, 0.0f);
+  const float sz = fabsf(Z) > kReprojEps ? 1.0f / Z : 1.0f;
+  const float u = rintf((X * sz) * Kh[0] + Kh[2]);
+  const float v = rintf((Y * sz) * Kh[4] + Kh[5]);
+  if (!(u >= 0.0f && v >= 0.0f && u < static_cast<float>(hw) && v < static_cast<float>(hh))) return;
+  if (!(z_store > 0.0f)) return;
+  const int ui = static_cast<int>(u), vi = static_cast<int>(v);
+  if (ui % f != 0 || vi % f != 0 || ui / f >= wo || vi / f >= ho) return;   // not a pixel the nearest-neighbour decimation picks
+  atomicMax(estimate_bits + (static_cast<size_t>(b) * ho + vi / f) * wo + ui / f, __float_as_uint(z_store));
+}
+
 // Zero-fill as an ordinary kernel node.  hipMemsetAsync is avoided on purpose: captured into a hipGraph it becomes a
 // memset node, and on ROCm 7.x replays of such a graph were observed to run the splat kernel against a buffer that was
 // cleared late (all-zero output whenever the device was idle at launch); kernel -> kernel edges do not have the problem.
@@ -92,6 +134,21 @@ extern "C" int dvmvs_depth_reproject_lowres_fwd(const float* transformation, con
   if (rc != 0) return rc;
   const int n = B * hh * hw;
   hipLaunchKernelGGL(decimate_clear_kernel, dim3((n + 255) / 256), dim3(256), 0, s, zbuffer, out_lowres, B, hh, hw, lowres_factor);
+  return launch_status();
+}
+
+extern "C" int dvmvs_depth_reproject_estimate_fwd(const float* transformation, const float* previous_depth, const float* full_K,
+                                                  const float* half_K, float* estimate, float* estimate_to_clear, int lowres_factor,
+                                                  int B, int full_height, int full_width, dvmvs_stream_t stream) {
+  using namespace dvmvs;
+  if (!transformation || !previous_depth || !full_K || !half_K || !estimate || estimate == estimate_to_clear) return DVMVS_EINVAL;
+  if (B <= 0 || full_height < 2 || full_width < 2 || B > 65535 || lowres_factor <= 0) return DVMVS_EINVAL;
+  const int hh = full_height / 2, hw = full_width / 2;
+  if (hh / lowres_factor <= 0 || hw / lowres_factor <= 0) return DVMVS_EINVAL;
+  const int HWf = full_height * full_width;
+  hipLaunchKernelGGL(depth_splat_estimate_kernel, dim3((HWf + 255) / 256, B), dim3(256), 0, static_cast<hipStream_t>(stream), transformation,
+                     previous_depth, full_K, half_K, reinterpret_cast<unsigned int*>(estimate), estimate_to_clear, B, full_height, full_width,
+                     lowres_factor);
   return launch_status();
 }
 

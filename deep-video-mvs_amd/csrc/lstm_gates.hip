@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void lstm_gates_fwd_kernel(const float* __rest
     gg[k] = cc[cc_base + 3 * gate_stride + es];
     cc_[k] = c_cur[st_base + es];
   }
+#pragma unroll 4   // (four partial sums' loads in flight; the additions stay in ascending order)
   for (int s = 1; s < n_partials; ++s) {
     const float* part = cc + static_cast<size_t>(s) * partial_stride;
 #pragma unroll
@@ -200,8 +201,9 @@ inline int launch_gates(hipStream_t stream, int rows, Args... args) {
 template <bool FWD, typename... Args>
 inline int dispatch_gates(hipStream_t stream, int rows, int HW, Args... args) {
   if (HW <= 16 * 4) return launch_gates<FWD, 16, 4>(stream, rows, args...);
-  if (HW <= 16 * 5) return launch_gates<FWD, 16, 5>(stream, rows, args...);
-  if (HW <= 16 * 8) return launch_gates<FWD, 16, 8>(stream, rows, args...);
+  // 65 .. 128 elements (80 at 320x256): one wave per row -- four times the workgroups of the 16-lane form (the cell's 512 rows: 128
+  // workgroups instead of 32), and the row statistics are summed in ONE order whether the convolution arrives whole or as partial sums
+  if (HW <= 64 * 2) return launch_gates<FWD, 64, 2>(stream, rows, args...);
   if (HW <= 64 * 4) return launch_gates<FWD, 64, 4>(stream, rows, args...);
   if (HW <= 64 * 8) return launch_gates<FWD, 64, 8>(stream, rows, args...);
   if (HW <= 64 * 16) return launch_gates<FWD, 64, 16>(stream, rows, args...);
@@ -224,6 +226,8 @@ extern "C" int dvmvs_lstm_gates_partials_fwd(const float* conv_partials, int n_p
   using namespace dvmvs;
   if (!conv_partials || !c_cur || !h_next || !c_next) return DVMVS_EINVAL;
   if (B <= 0 || hidden <= 0 || H <= 0 || W <= 0 || n_partials <= 0) return DVMVS_EINVAL;
+  // (K-split partial sums multiply the bytes of a row by n_partials: with one WAVE per LayerNorm row -- dispatch_gates, 512 waves for the
+  // cell's 512 channels -- instead of 16 lanes per row (32 workgroups: 30 us over 16 splits, round 4) the separate reduction launch is gone)
   return dispatch_gates<true>(static_cast<hipStream_t>(stream), B * hidden, H * W, conv_partials, c_cur, h_next, c_next, B,
                               hidden, H * W, n_partials, static_cast<long long>(B) * 4 * hidden * H * W);
 }

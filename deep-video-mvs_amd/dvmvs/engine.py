@@ -432,6 +432,7 @@ class DepthEngine:
         # graphs captured ahead; how many such graphs
         self.warmup_seconds = {"eager_first_frames": 0.0, "graph_capture": 0.0, "graph_first_launches": 0.0}
         self.warmup_graphs_launched = 0
+        self.lstm_gates_on_partials = os.environ.get("DVMVS_LSTM_GATES_ON_PARTIALS", "1") != "0"      # (0: reduction launch + gates, round 4)
         self.sweep_variant_counts = {}     # frames per sweep configuration (dvmvs_cost_volume_fwd's variant) since construction
         # host-planned work list for the sweep: only where the matrices exist on the host, and one plan per launch (one sequence)
         self.sweep_work_list = bool(_utils.SWEEP_WORK_LIST and self.pose_algebra == "reference" and _utils.COST_VOLUME_VARIANT in (0, 2, 3, 4, 5))
@@ -461,8 +462,9 @@ class DepthEngine:
             if self._static is not None:
                 for k in ("h", "c", "prev_depth"):
                     self._static[k].zero_()
-                if self._direct_buffers:      # the splat's all-zero z-buffer invariant, also after a frame that failed half-way
-                    self._direct_buffers["zbuffer"].zero_()
+                if self._direct_buffers:      # the splat's all-zero estimate invariant, also after a frame that failed half-way
+                    for buffer_set in self._direct_buffers["sets"]:
+                        buffer_set["estimate"].zero_()
         else:
             self._no_previous[sequence] = True
             if self._static is not None:
@@ -571,14 +573,15 @@ class DepthEngine:
                                        z(1, 32 + 8 * hc, H // 16, W // 16)],
                               dec_cat=[z(1, 16 * hc, H // 16, W // 16), z(1, 8 * hc + 1, H // 8, W // 8), z(1, 4 * hc + 1, H // 4, W // 4),
                                        z(1, 2 * hc + 1, H // 2, W // 2)],
-                              full_in=z(1, hc + 1 + 3, H, W), lstm_cat=z(1, 32 * hc, H // 32, W // 32), zbuffer=z(1, H // 2, W // 2),
+                              full_in=z(1, hc + 1 + 3, H, W), lstm_cat=z(1, 32 * hc, H // 32, W // 32),
                               estimate=z(1, 1, H // 32, W // 32), depth_store=z(1, H, W))
             if self.direct:
                 # feature look-ahead (step(next_reference_image=...)): the NEXT frame's image and FPN outputs need a home while this
                 # frame's encoder / decoder read their own -- a second set of the buffers the feature extraction writes and of the
                 # buffer that holds the image; frames alternate between the two sets
                 # and, for the deeper look-ahead (the next frame's sweep + encoder as well), of everything the encoder writes
-                keys = ("enc_cat", "dec_cat", "full_in", "lstm_cat")
+                # ... and of the 8x10 depth estimate: a frame's splat zero-fills the OTHER set's buffer on the way (no clear launch)
+                keys = ("enc_cat", "dec_cat", "full_in", "lstm_cat", "estimate")
                 clone = lambda v: [torch.zeros_like(t) for t in v] if isinstance(v, list) else torch.zeros_like(v)
                 direct["sets"] = [dict({k: direct[k] for k in keys}, index=0, meas_feat=[]),
                                   dict({k: clone(direct[k]) for k in keys}, index=1, meas_feat=[])]
@@ -872,8 +875,11 @@ class DepthEngine:
                 exact = self.pose_algebra == "exact"
                 reproject_T = _ops.relative_pose(s["pose"], s["prev_pose"]) if exact else s["reproject_T"]
                 lstm_T = _ops.relative_pose(s["prev_pose"], s["pose"]) if exact else s["lstm_T"]
-                _ops.depth_reproject_lowres_into(reproject_T, s["prev_depth"], s["full_K"], s["half_K"], d["zbuffer"], d["estimate"], 16)
-                _ops.hidden_warp_into(s["h"], d["estimate"], lstm_T, s["lstm_K"], True, lstm_cat[:, 512:])
+                # re-projection of the previous depth straight into this buffer set's 8x10 estimate (one launch: it also zero-fills the
+                # other set's estimate for the next frame), then the hidden-state warp
+                other = d["sets"][1 - buffers["index"]]["estimate"]
+                _ops.depth_reproject_estimate_into(reproject_T, s["prev_depth"], s["full_K"], s["half_K"], buffers["estimate"], other, 16)
+                _ops.hidden_warp_into(s["h"], buffers["estimate"], lstm_T, s["lstm_K"], True, lstm_cat[:, 512:])
             else:
                 lstm_cat[:, 512:].copy_(s["h"])      # first frame of a sequence: the (zero) state as it is, no warp (convlstm.py:29)
             if self._lstm_bottleneck(lstm_cat):
@@ -881,9 +887,13 @@ class DepthEngine:
                 # pipe), added up in a fixed order by a chip-wide reduction (the gates kernel can add them itself --
                 # lstm_gates_partials_into -- but its 32 workgroups take 30 us over 16 splits; reduction + gates: 5.6 + 5.3 us)
                 splits = _ops.bottleneck_conv_into(lstm_cat, self._lstm_packed, cell.conv.weight.shape[0], 1, self._lstm_partials)
-                _ops.partial_sums_bias_act_into(self._lstm_partials, splits, self._lstm_combined, None, _ops.ACTIVATIONS["none"],
-                                                tuple(self._lstm_combined.shape))
-                _ops.lstm_gates_into(self._lstm_combined, s["c"], s["h"])
+                if self.lstm_gates_on_partials:
+                    # the gates kernel adds the K-split partial sums itself, in ascending order (one wave per LayerNorm row): no reduction launch
+                    _ops.lstm_gates_partials_into(self._lstm_partials, splits, s["c"], s["h"])
+                else:
+                    _ops.partial_sums_bias_act_into(self._lstm_partials, splits, self._lstm_combined, None, _ops.ACTIVATIONS["none"],
+                                                    tuple(self._lstm_combined.shape))
+                    _ops.lstm_gates_into(self._lstm_combined, s["c"], s["h"])
             else:
                 combined = cell.conv(lstm_cat)
                 if not combined.is_contiguous():       # channels-last convolution (lstm_channels_last): back to the gates' NCHW rows
@@ -974,6 +984,8 @@ class DepthEngine:
         parity = self._parity if self.direct else 0
         sets = self._direct_buffers.get("sets")
         cur = sets[parity] if self.direct else None
+        if self.direct:
+            self._direct_buffers["estimate"] = cur["estimate"]      # (diagnostics: the 8x10 depth estimate of the frame this call computes)
 
         # ---- what the previous call prepared for this frame: 0 nothing, 1 its reference features, 2 also its sweep + encoder ----
         have, ready = 0, self._prefetched
@@ -1110,6 +1122,9 @@ class DepthEngine:
                     s[name].copy_(saved)
                 if keep_set is not None:
                     self._restore(cur, keep_set)
+                if self.direct:      # (the splat's invariant: a frame finds its estimate buffer all-zero; the throw-away launches wrote into both)
+                    for buffer_set in sets:
+                        buffer_set["estimate"].zero_()
                 torch.cuda.synchronize(self.device)
                 self.warmup_seconds["graph_first_launches"] += time.perf_counter() - t_warm
                 self.warmup_graphs_launched += len(fresh)

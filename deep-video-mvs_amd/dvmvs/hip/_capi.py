@@ -17,7 +17,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVMVS_HIP_LIB", os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libdvmvs_hip.so")))
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_MEASUREMENTS = 8
 MAX_DEPTH_LEVELS = 256
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
@@ -78,6 +78,7 @@ SIGNATURES = {
     "dvmvs_depthwise_conv_bwd_workspace_bytes": (ctypes.c_size_t, [_c_int] * 6),
     "dvmvs_depthwise_conv_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_depth_reproject_lowres_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "dvmvs_depth_reproject_estimate_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_tsdf_integrate": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_float, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_stream]),
     "dvmvs_depthwise_conv_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

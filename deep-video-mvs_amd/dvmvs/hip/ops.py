@@ -869,6 +869,26 @@ def depth_reproject_lowres_into(transformation: Tensor, previous_depth: Tensor, 
     return out_lowres
 
 
+def depth_reproject_estimate_into(transformation: Tensor, previous_depth: Tensor, full_K: Tensor, half_K: Tensor, estimate: Tensor,
+                                  estimate_to_clear: Optional[Tensor], factor: int) -> Tensor:
+    """The frame path's re-projection in one launch (dvmvs_depth_reproject_estimate_fwd): splat straight into ``estimate``
+    [B,1,H/2/f,W/2/f] (all-zero on entry), zero-filling ``estimate_to_clear`` (the buffer of the frame after next) on the way."""
+    _dev_f32("depth_reproject_estimate_into", transformation, previous_depth, full_K, half_K, estimate)
+    B, one, Hf, Wf = previous_depth.shape
+    shape = (B, 1, Hf // 2 // factor, Wf // 2 // factor)
+    if one != 1 or tuple(estimate.shape) != shape or not estimate.is_contiguous() or not previous_depth.is_contiguous() or \
+            (estimate_to_clear is not None and (tuple(estimate_to_clear.shape) != shape or not estimate_to_clear.is_contiguous() or
+                                                estimate_to_clear.data_ptr() == estimate.data_ptr())):
+        raise ValueError("dvmvs::depth_reproject_estimate_into: expected contiguous [B,1,H,W] depth and distinct [B,1,H/2/f,W/2/f] estimate buffers")
+    with torch.cuda.device(previous_depth.device):
+        rc = _capi.lib().dvmvs_depth_reproject_estimate_fwd(_ptr(transformation.contiguous()), _ptr(previous_depth), _ptr(full_K.contiguous()),
+                                                            _ptr(half_K.contiguous()), _ptr(estimate),
+                                                            _ptr(estimate_to_clear) if estimate_to_clear is not None else None, int(factor), B, Hf, Wf,
+                                                            _stream(previous_depth))
+    _capi.check(rc, "dvmvs_depth_reproject_estimate_fwd")
+    return estimate
+
+
 def cost_volume_into(image1: Tensor, image2s, Hm: Tensor, kt: Tensor, min_depth: float, max_depth: float, dst: Tensor, variant: int = 0,
                      work_list: Optional[Tensor] = None) -> Tensor:
     """Dot-product cost volume written into ``dst`` [B,D,H,W] (contiguous: for B == 1 a channel slice of a larger buffer is)."""

@@ -29,8 +29,10 @@ extern "C" {
  * (dvmvs_sweep_plan_stats / _select_variant / _work_list / dvmvs_sweep_plan, dvmvs_cost_volume_planned_fwd), the bottleneck convolution
  * (dvmvs_bottleneck_conv_*, dvmvs_partial_sums_bias_act_fwd, dvmvs_lstm_gates_partials_fwd) and two training gradients
  * (dvmvs_upsample2x_bwd, dvmvs_depthwise_conv_bwd).
- * ABI 5 = ABI 4 + the direct convolution of the larger maps and the depth heads (dvmvs_direct_conv_*, dvmvs_conv_head_fwd). */
-#define DVMVS_ABI_VERSION 5
+ * ABI 5 = ABI 4 + the direct convolution of the larger maps and the depth heads (dvmvs_direct_conv_*, dvmvs_conv_head_fwd).
+ * ABI 6 (round 5) = ABI 5 + variant 6 of dvmvs_cost_volume_fwd (the correlate-then-interpolate sweep on the fp32 matrix cores) and the
+ * one-launch re-projection of the frame path (dvmvs_depth_reproject_estimate_fwd); no earlier signature changed. */
+#define DVMVS_ABI_VERSION 6
 #define DVMVS_MAX_MEASUREMENTS 8      /* measurement frames fused per launch */
 #define DVMVS_MAX_DEPTH_LEVELS 256    /* sweep planes per launch */
 
@@ -94,7 +96,10 @@ int dvmvs_sweep_matrices(const float* pose1, const float* const* pose2s, const f
  *               the default one has to split or queue runs of planes, slower on easy pairs -- dvmvs_sweep_select_variant
  *               decides from the matrices); 4 / 5 = configurations 2 / 3 as ONE launch: no second pass, a run that cannot be staged is
  *               gathered inline by the sweep kernel (what dvmvs_sweep_plan returns when its plan queues nothing; also what a NULL
- *               workspace gives).  Each is bit-reproducible; they differ in fp32 summation order.
+ *               workspace gives); 6 = the correlate-then-interpolate sweep on the fp32 matrix cores (csrc/sweep_mfma.hip: the 32-channel dot
+ *               product per measurement CELL on v_mfma_f32_16x16x4_f32, four table look-ups per (pixel, plane, frame); up to 32 channels,
+ *               either layout, any image size, no workspace, no work list, no host plan).  Each is bit-reproducible; they differ in fp32
+ *               summation order.
  *   image2_layout DVMVS_LAYOUT_NCHW, or DVMVS_LAYOUT_NHWC when the MEASUREMENT maps are stored channels-last (a keyframe's
  *               features are reused as measurement features by later frames, so a runner converts them once per
  *               keyframe).  Supported by the LDS-tiled dot-product kernel (C % 4 == 0, H*W >= 4096); image1 and
@@ -299,6 +304,17 @@ int dvmvs_depth_reproject_fwd(const float* transformation, const float* previous
 int dvmvs_depth_reproject_lowres_fwd(const float* transformation, const float* previous_depth, const float* full_K,
                                      const float* half_K, float* zbuffer, float* out_lowres, int lowres_factor,
                                      int B, int full_height, int full_width, dvmvs_stream_t stream);
+
+/*
+ * ABI 6.  The frame path in ONE launch: the ConvLSTM reads only rows / columns 0, f, 2f, ... of the estimate
+ * (fusionnet/run-testing.py:176-189), so the splat goes straight into `estimate` [B,1,Hf/2/f,Wf/2/f] -- bit-identical to
+ * out_lowres of the functions above -- which MUST be all-zero when the call starts.  `estimate_to_clear` (optional, another
+ * buffer of that shape) is zero-filled by the same launch: a caller that alternates between two estimate buffers from frame
+ * to frame zero-fills them once and never launches a clear.
+ */
+int dvmvs_depth_reproject_estimate_fwd(const float* transformation, const float* previous_depth, const float* full_K,
+                                       const float* half_K, float* estimate, float* estimate_to_clear, int lowres_factor,
+                                       int B, int full_height, int full_width, dvmvs_stream_t stream);
 
 /*
  * Frame-path epilogues (not part of the reference's function list; they replace ATen elementwise / copy launches that sit

@@ -734,6 +734,14 @@ def test_state_updates_in_place(ops, dev):
     for _ in range(3):     # repeated use of the same z-buffer: it must come back all-zero every time
         ops.depth_reproject_lowres_into(T, prev.to(dev), fullK.to(dev), halfK.to(dev), zbuffer, estimate, 16)
         assert torch.equal(estimate, low) and float(zbuffer.abs().max()) == 0.0
+    # ABI 6: the frame path's one-launch form -- straight into the 8x10 estimate, two buffers alternating, each launch zero-fills the other one
+    est = [torch.zeros(1, 1, 8, 10, device=dev), torch.full((1, 1, 8, 10), 7.0, device=dev)]
+    for n in range(4):
+        cur, other = est[n % 2], est[1 - n % 2]
+        ops.depth_reproject_estimate_into(T, prev.to(dev), fullK.to(dev), halfK.to(dev), cur, other, 16)
+        assert torch.equal(cur, low) and float(other.abs().max()) == 0.0, n
+    with pytest.raises(ValueError):
+        ops.depth_reproject_estimate_into(T, prev.to(dev), fullK.to(dev), halfK.to(dev), est[0], est[0], 16)
     dst = torch.zeros(1, 1024, 8, 10, device=dev)
     hw = load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"), "hidden_warp")
     h0 = syn.analytic_lstm_inputs()[2]
