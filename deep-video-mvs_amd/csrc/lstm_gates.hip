@@ -42,6 +42,30 @@ __device__ inline void row_stats(const float (&v)[EPL], const bool (&ok)[EPL], f
   *rstd = 1.0f / sqrtf(var + kLnEps);
 }
 
+// Everything after the convolution output of a row is in registers: LayerNorm(g), cell update, LayerNorm(c'), output gate.
+template <int LPR, int EPL>
+__device__ inline void gates_tail(const float (&gi)[EPL], const float (&gf)[EPL], const float (&go)[EPL], const float (&gg)[EPL],
+                                  const float (&cc_)[EPL], const bool (&ok)[EPL], float inv_n, int lane, size_t st_base,
+                                  float* __restrict__ h_next, float* c_next) {
+  float mu, rstd;
+  row_stats<LPR, EPL>(gg, ok, inv_n, &mu, &rstd);
+  float z[EPL];
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) {
+    const float g = celu1((gg[k] - mu) * rstd);
+    z[k] = sigmoidf(gf[k]) * cc_[k] + sigmoidf(gi[k]) * g;
+  }
+  row_stats<LPR, EPL>(z, ok, inv_n, &mu, &rstd);
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) {
+    if (!ok[k]) continue;
+    const int e = lane + k * LPR;
+    const float cn = (z[k] - mu) * rstd;
+    c_next[st_base + e] = cn;
+    h_next[st_base + e] = sigmoidf(go[k]) * celu1(cn);
+  }
+}
+
 template <int LPR, int EPL>
 // c_next may alias c_cur (the frame engine updates its state buffers in place): a row is read completely into registers before
 // anything of it is written, and rows are owned by disjoint lane groups -- hence no __restrict__ on the two state pointers.
@@ -86,23 +110,46 @@ __global__ __launch_bounds__(256) void lstm_gates_fwd_kernel(const float* __rest
       gg[k] += part[cc_base + 3 * gate_stride + es];
     }
   }
-  float mu, rstd;
-  row_stats<LPR, EPL>(gg, ok, inv_n, &mu, &rstd);
-  float z[EPL];
+  gates_tail<LPR, EPL>(gi, gf, go, gg, cc_, ok, inv_n, lane, st_base, h_next, c_next);
+}
+
+// The cell's convolution as K-split partial sums (dvmvs_bottleneck_conv_fwd), rows of 65 .. 128 elements: a workgroup of four waves owns
+// one (batch, channel) row, wave w adds up gate w's partial sums in ascending order (16 splits x 4 gates x 80 elements = 20 KB per row:
+// four waves per row keep 2048 waves' loads in flight instead of 512), the sums meet in LDS and wave 0 finishes the row with the code of
+// lstm_gates_fwd_kernel<64, 2> -- same element-to-lane mapping, same statistics order: bit-identical to "reduce, then gates".
+__global__ __launch_bounds__(256) void lstm_gates_partials_kernel(const float* __restrict__ cc, const float* c_cur, float* __restrict__ h_next,
+                                                                  float* c_next, int B, int hidden, int HW, int n_partials, long long partial_stride) {
+  __shared__ float s_gate[4][128];
+  const int row = blockIdx.x;      // (b, channel)
+  const int gate = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = row / hidden, ch = row - b * hidden;
+  const size_t cc_base = (static_cast<size_t>(b) * 4 * hidden + ch) * HW + static_cast<size_t>(gate) * hidden * HW;
+  const size_t st_base = (static_cast<size_t>(b) * hidden + ch) * HW;
+  float v[2];
+  bool ok[2];
 #pragma unroll
-  for (int k = 0; k < EPL; ++k) {
-    const float g = celu1((gg[k] - mu) * rstd);
-    z[k] = sigmoidf(gf[k]) * cc_[k] + sigmoidf(gi[k]) * g;
+  for (int k = 0; k < 2; ++k) {
+    ok[k] = lane + k * 64 < HW;
+    v[k] = cc[cc_base + (ok[k] ? lane + k * 64 : 0)];
   }
-  row_stats<LPR, EPL>(z, ok, inv_n, &mu, &rstd);
+#pragma unroll 4
+  for (int s = 1; s < n_partials; ++s) {
+    const float* part = cc + static_cast<size_t>(s) * partial_stride;
 #pragma unroll
-  for (int k = 0; k < EPL; ++k) {
-    if (!ok[k]) continue;
-    const int e = lane + k * LPR;
-    const float cn = (z[k] - mu) * rstd;
-    c_next[st_base + e] = cn;
-    h_next[st_base + e] = sigmoidf(go[k]) * celu1(cn);
+    for (int k = 0; k < 2; ++k) v[k] += part[cc_base + (ok[k] ? lane + k * 64 : 0)];
   }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) s_gate[gate][lane + k * 64] = v[k];
+  __syncthreads();
+  if (gate != 0) return;
+  float gi[2], gf[2], go[2], gg[2], cc_[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = lane + k * 64;
+    gi[k] = s_gate[0][e]; gf[k] = s_gate[1][e]; go[k] = s_gate[2][e]; gg[k] = s_gate[3][e];
+    cc_[k] = c_cur[st_base + (ok[k] ? e : 0)];
+  }
+  gates_tail<64, 2>(gi, gf, go, gg, cc_, ok, 1.0f / static_cast<float>(HW), lane, st_base, h_next, c_next);
 }
 
 // Backward: gates are recomputed from (cc, c_cur); LayerNorm backward per row
@@ -228,6 +275,11 @@ extern "C" int dvmvs_lstm_gates_partials_fwd(const float* conv_partials, int n_p
   if (B <= 0 || hidden <= 0 || H <= 0 || W <= 0 || n_partials <= 0) return DVMVS_EINVAL;
   // (K-split partial sums multiply the bytes of a row by n_partials: with one WAVE per LayerNorm row -- dispatch_gates, 512 waves for the
   // cell's 512 channels -- instead of 16 lanes per row (32 workgroups: 30 us over 16 splits, round 4) the separate reduction launch is gone)
+  if (n_partials > 1 && H * W > 64 && H * W <= 128) {
+    hipLaunchKernelGGL(lstm_gates_partials_kernel, dim3(B * hidden), dim3(256), 0, static_cast<hipStream_t>(stream), conv_partials, c_cur, h_next, c_next,
+                       B, hidden, H * W, n_partials, static_cast<long long>(B) * 4 * hidden * H * W);
+    return launch_status();
+  }
   return dispatch_gates<true>(static_cast<hipStream_t>(stream), B * hidden, H * W, conv_partials, c_cur, h_next, c_next, B,
                               hidden, H * W, n_partials, static_cast<long long>(B) * 4 * hidden * H * W);
 }

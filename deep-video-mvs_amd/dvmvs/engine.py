@@ -51,10 +51,15 @@ os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC",
 
 _MAX_MEAS = 8            # DVMVS_MAX_MEASUREMENTS of the C ABI
 # Pinned staging ring = how many frames the host may run ahead of the device (it waits for the slot's previous upload to have executed).
-# TWO: with 8 the host (0.7 ms per step) raced up to 8 graph launches ahead of the device (1.3 ms per frame) and every 10-20 frames one
+# Round 3: with 8 the host (0.7 ms per step) raced up to 8 graph launches ahead of the device (1.3 ms per frame) and every 10-20 frames one
 # frame took 2.5-5 ms instead of 1.3 on the device -- the deeper the queue of launched graphs, the more such stalls (2 / 3 / 8 / 64 slots:
-# 1 / 2 / 4 / 6 of them in 70 frames, tools/step_times_probe.py); with 2 the device runs a steady 1.28 ms per frame.
-_STAGING_SLOTS = int(os.environ.get("DVMVS_STAGING_SLOTS", "2"))
+# 1 / 2 / 4 / 6 of them in 70 frames, tools/step_times_probe.py) -- hence TWO.  Round 5: the one stall that was left (a 5.6-7.4 ms device
+# gap four steps after every full device synchronisation, i.e. inside the timed steps of a short benchmark run: 830-910 instead of
+# 1 160-1 180 frames/s on the driver's command) is the same effect -- a frame's graph launched again while its previous launch (two frames
+# back: frames alternate between two graphs) is still queued or running.  With ONE slot the host is at most one frame ahead, a graph is
+# never in flight twice, and the stall is gone at the same steady-state rate (3 / 2 / 1 slots: 2 / 1 / 0 stalls in 20 steps; 100 steps:
+# 1 239 frames/s): the host's 0.75 ms per step still overlap the device's 0.8 ms frame completely.
+_STAGING_SLOTS = int(os.environ.get("DVMVS_STAGING_SLOTS", "1"))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -420,7 +425,9 @@ class DepthEngine:
         self.plan_frames_ahead = os.environ.get("DVMVS_PLAN_AHEAD", "1") != "0"
         self.planned_frames_used = 0
         self.warm_captured_graphs = os.environ.get("DVMVS_WARM_GRAPHS", "1") != "0"
-        self.warm_graph_launches = max(1, int(os.environ.get("DVMVS_WARM_GRAPH_LAUNCHES", "1")))
+        # launches of every newly captured graph on throw-away results: the runtime finishes setting a graph up over its first launches (a
+        # 5-6 ms device stall was still seen at a graph's third launch, i.e. a few steps into a short run's timed region, with one)
+        self.warm_graph_launches = max(1, int(os.environ.get("DVMVS_WARM_GRAPH_LAUNCHES", "3")))
         # how much of the NEXT keyframe a step computes when the caller announces it (step's next_* arguments): 1 its feature extraction,
         # 2 also its sweep + encoder.  Default 1: with the direct convolution kernels the sweep and the encoder fill the chip on their
         # own, and running them next to the decoder only makes both slower (MI355X, 100 steps: level 0 / 1 / 2 = 827 / 1091 / 999
@@ -721,6 +728,14 @@ class DepthEngine:
         if self._planner is None:
             from concurrent.futures import ThreadPoolExecutor
             self._planner = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dvmvs-plan")
+            # Two Python threads share the interpreter lock: a thread that wants it asks the holder to drop it only after the switch
+            # interval -- 5 ms by default, six frames of device time.  A few steps into every run this thread came back from a graph launch
+            # while the planning thread was mid-block and sat out the full interval (one 5.6-6.5 ms device gap in the first ten steps of every
+            # short run; none with DVMVS_PLAN_AHEAD=0).  0.1 ms bounds the hand-over; DVMVS_SWITCH_INTERVAL overrides (seconds, 0 = leave it).
+            import sys
+            wanted = float(os.environ.get("DVMVS_SWITCH_INTERVAL", "1e-4"))
+            if wanted > 0.0 and sys.getswitchinterval() > wanted:
+                sys.setswitchinterval(wanted)
             self._param_host_ahead = torch.zeros_like(self._param_host)
         no_previous = torch.zeros(self.sequences, dtype=torch.bool)
         inputs = (pose, list(measurement_poses), full_K)
@@ -1102,7 +1117,8 @@ class DepthEngine:
                             if k not in self._graphs:
                                 self._graphs[k] = self._capture((n_meas, kind[1], v, par, have, 0, 0, 0))
                 self.warmup_seconds["graph_capture"] += time.perf_counter() - t_capture
-            fresh = [k for k in self._graphs if k not in known and k != key]
+            # (the graph of THIS frame, when it is new, is warmed like the ones captured ahead: its throw-away launches are undone the same way)
+            fresh = [k for k in self._graphs if k not in known]
             if fresh and self.warm_captured_graphs:
                 # A graph's FIRST launch stalls the device for ~5 ms (its kernel arguments and code are set up then, not at capture):
                 # once per pre-captured graph, i.e. a few steps into every run, whenever a geometry first asks for another sweep
@@ -1115,8 +1131,8 @@ class DepthEngine:
                 t_warm = time.perf_counter()
                 keep = [s[k].clone() for k in ("h", "c", "prev_depth")] if self.is_fusionnet else []
                 keep_set = self._snapshot(cur) if (self.direct and have == 2) else None
-                for _ in range(self.warm_graph_launches):
-                    for k in fresh:
+                for k in fresh:      # back to back per graph: a graph's next launch is queued while its previous one still runs, as in the steady
+                    for _ in range(self.warm_graph_launches):      # state, where the host is up to two frames ahead of the device
                         self._graphs[k].replay()
                 for name, saved in zip(("h", "c", "prev_depth"), keep):
                     s[name].copy_(saved)
