@@ -46,8 +46,10 @@ from dvmvs import utils as _utils
 # resolution), which a depth engine whose recurrent state passes through a discrete z-buffer cannot tolerate (one flipped pixel and the
 # runs diverge).  MIOpen reads this switch when it looks for solvers; with the family off it solves those layers with its GEMM /
 # Winograd / direct kernels, which are deterministic.  (The bottleneck layers do not reach MIOpen at all: csrc/bottleneck_conv.hip.)
-# Set before the first convolution; a caller that exported its own value keeps it.
-os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC", "0")
+# Set when the first DepthEngine is constructed (importing this module changes nothing: a training process that never builds an engine keeps
+# MIOpen's own choice); a caller that exported its own value keeps it.
+_DETERMINISTIC_MIOPEN = ("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC", "0")      # applied by DepthEngine.__init__ (process-wide from then on:
+                                                                                              # MIOpen reads it when it looks for solvers)
 
 _MAX_MEAS = 8            # DVMVS_MAX_MEASUREMENTS of the C ABI
 # Pinned staging ring = how many frames the host may run ahead of the device (it waits for the slot's previous upload to have executed).
@@ -356,6 +358,7 @@ class DepthEngine:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DepthEngine runs on an MI355X; there is no CPU execution path in this package")
+        os.environ.setdefault(*_DETERMINISTIC_MIOPEN)
         prep = (lambda m: fold_batchnorm(m)) if fold_bn else (lambda m: copy.deepcopy(m).eval())
         mods = [feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder]
         mods = [None if m is None else prep(m).to(self.device) for m in mods]

@@ -84,6 +84,33 @@ def _check_warp_grid(warp_grid, height, width):
                          f"got {tuple(warp_grid.shape)}")
 
 
+_WORK_LIST_RINGS = {}      # (device, words) -> [position, [(pinned host buffer, device buffer, event), ...]]
+
+
+def _upload_work_list(host, H, W, n_depth_levels, min_depth, max_depth, variant, device):
+    """The tiled sweep's work list for these host matrices, on ``device``: planned straight into a pinned staging buffer and sent with an
+    asynchronous, stream-ordered copy (a pageable ``.to(device)`` per call was a device synchronisation inside every training step: ADVICE
+    r4).  A small ring of (pinned, device) buffer pairs per device; a pair is reused only after the copy AND the sweep launch that read it
+    have executed (its event is recorded by the next call on the same stream, i.e. behind that launch)."""
+    words = _ops.sweep_work_list_words(host[0].shape[0], H, W, n_depth_levels)
+    key = (str(device), words)
+    ring = _WORK_LIST_RINGS.get(key)
+    if ring is None:
+        ring = _WORK_LIST_RINGS[key] = [0, [(torch.zeros(words, dtype=torch.int32).pin_memory(), torch.zeros(words, dtype=torch.int32, device=device),
+                                             torch.cuda.Event()) for _ in range(4)]]
+    position, slots = ring
+    # the slot used by the PREVIOUS call gets its guard now: everything that call enqueued (copy + sweep) is in front of this record
+    previous = slots[(position - 1) % len(slots)]
+    with torch.cuda.device(device):
+        previous[2].record(torch.cuda.current_stream(device))
+    pinned, on_device, event = slots[position]
+    ring[0] = (position + 1) % len(slots)
+    event.synchronize()      # (three calls back: does not block in practice)
+    _ops.sweep_work_list_host(host[0], host[1], H, W, n_depth_levels, min_depth, max_depth, variant, out=pinned)
+    on_device.copy_(pinned, non_blocking=True)
+    return on_device
+
+
 def cost_volume_fusion(image1, image2s, pose1, pose2s, K, warp_grid, min_depth, max_depth, n_depth_levels, device,
                        dot_product):
     """Mean plane-sweep cost volume [B,D,H,W] of ``image1`` against every measurement frame in ``image2s``.
@@ -101,7 +128,7 @@ def cost_volume_fusion(image1, image2s, pose1, pose2s, K, warp_grid, min_depth, 
     work_list = None
     if host is not None and dot_product and variant in (0, 2, 3, 4, 5) and H * W >= 64 * 64 and SWEEP_WORK_LIST:
         # the tiled sweep's work list, planned on the host copies of the matrices (long workgroups cut into parallel pieces)
-        work_list = _ops.sweep_work_list_host(host[0], host[1], H, W, n_depth_levels, min_depth, max_depth, variant).to(image1.device)
+        work_list = _upload_work_list(host, H, W, n_depth_levels, min_depth, max_depth, variant, image1.device)
     return _ops.cost_volume(image1, image2s, Hm, kt, float(min_depth), float(max_depth), int(n_depth_levels), bool(dot_product), variant, work_list)
 
 
