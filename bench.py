@@ -598,6 +598,10 @@ def train_mode(args, world, rank, device):
     if search:
         os.environ.setdefault("MIOPEN_USER_DB_PATH", userdb)
     torch.backends.cudnn.benchmark = search
+    # the shipped find-db is keyed to ONE MIOpen build (its file name carries the build string); another build ignores it silently and
+    # searches afresh, writing files of its own: what was there before the run is compared with what is there after it
+    db_dir = os.environ.get("MIOPEN_USER_DB_PATH", userdb)
+    db_before = {f: os.path.getsize(os.path.join(db_dir, f)) for f in os.listdir(db_dir)} if os.path.isdir(db_dir) else {}
     model = [m.to(device).train() for m in build_modules()]
     params = [p for m in model for p in m.parameters()]
     reducer = BucketedGradientReducer(params)
@@ -618,13 +622,26 @@ def train_mode(args, world, rank, device):
     mark = region_marker(device) if args.mark_region else None
     elapsed = timed_region(step, max(args.warmup, 1), args.steps, world, device, before=mark, after=mark)
     loss = last["loss"]
+    db_after = {f: os.path.getsize(os.path.join(db_dir, f)) for f in os.listdir(db_dir)} if os.path.isdir(db_dir) else {}
+    new_files = sorted(f for f in db_after if f not in db_before)
+    grown = sorted(f for f in db_after if f in db_before and db_after[f] != db_before[f])
+    if not search:
+        find_db = "not used (MIOpen's immediate mode)"
+    elif new_files:
+        find_db = (f"MISMATCH: this MIOpen build wrote its own find-db ({', '.join(new_files)}) next to the shipped one ({', '.join(sorted(db_before)) or 'none'}): "
+                   "the shipped search results were ignored and the solver search ran during warm-up")
+    elif grown:
+        find_db = f"shipped find-db matched this MIOpen build; the run added entries to {', '.join(grown)}"
+    else:
+        find_db = f"shipped find-db matched this MIOpen build ({', '.join(sorted(db_before))}): the solver search was a look-up"
     if rank == 0:
         print(json.dumps({
             "metric": "fusionnet training sub-sequences/sec (8 frames, 256x256, 64 planes)", "value": world * B * args.steps / elapsed,
             "unit": "subsequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"fusionnet training step, subseq_len={T}, batch={B}/GPU, Adam, L1-inv loss (BASELINE.json configs[4])",
-                       "miopen_solver_search": bool(torch.backends.cudnn.benchmark),
+                       "miopen_solver_search": bool(torch.backends.cudnn.benchmark), "miopen_find_db": find_db,
+                       "pose_algebra": "host, whole sub-sequence per step, one pinned upload",
                        "grad_buckets": len(reducer.buckets), "grad_bytes": sum(f.numel() * 4 for f in reducer.flat),
                        "parallelism": f"data-parallel x{world}, bucketed RCCL all-reduce overlapped with backward"},
             "final_loss": float(loss)}))

@@ -17,9 +17,10 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from dvmvs import pose_algebra as _pose_algebra
 from dvmvs.config import Config
 from dvmvs.pose_algebra import to_host as _host
-from dvmvs.utils import calculate_cost_volume_by_warping, get_warp_grid_for_cost_volume_calculation
+from dvmvs.utils import cost_volume_from_matrices, get_warp_grid_for_cost_volume_calculation
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -48,6 +49,55 @@ def multi_scale_loss(predictions, groundtruth, weights=(1, 1, 1, 1, 1)):
 # ----------------------------------------------------------------------------------------------------------------------
 # forward over one sub-sequence
 # ----------------------------------------------------------------------------------------------------------------------
+_STAGING = {}      # (device, floats) -> [position, [(pinned buffer, event), ...]]
+
+
+def subsequence_matrices(poses, half_K, device):
+    """The small matrices of a whole sub-sequence -- per frame i >= 1 the sweep's K R K^-1 / K t against frame i - 1 (utils.py:51-56) and
+    the ConvLSTM's inverse(pose[i-1]) @ pose[i] (convlstm.py:30) -- evaluated on the host with the reference's fp32 expressions
+    (dvmvs.pose_algebra) and sent to ``device`` as ONE block through pinned memory (the per-frame path made ~20 small synchronous copies per
+    step).  Returns per frame (Hm [B,1,9], kt [B,1,3], (host Hm, host kt), lstm_T [B,4,4]); entry 0 is None.  In "exact" mode (fp64 on
+    the device) there is nothing to batch: the per-frame device ops are used."""
+    n = len(poses)
+    if _pose_algebra._mode(None) != "reference":
+        out = [None]
+        for i in range(1, n):
+            Hm, kt, host = _pose_algebra.sweep_matrices(poses[i], [poses[i - 1]], half_K, device, with_host=True)
+            out.append((Hm, kt, host, _pose_algebra.relative_pose(poses[i - 1], poses[i], device)))
+        return out
+    poses = [_host(p) for p in poses]
+    half_K = _host(half_K)
+    B = poses[0].shape[0]
+    host = [None]
+    for i in range(1, n):
+        Hm, kt = _pose_algebra.sweep_matrices_host(poses[i], [poses[i - 1]], half_K)
+        host.append((Hm.contiguous().float(), kt.contiguous().float(), _pose_algebra.relative_pose_host(poses[i - 1], poses[i]).contiguous().float()))
+    per_frame = B * (9 + 3 + 16)
+    total = per_frame * (n - 1)
+    key = (str(device), total)
+    ring = _STAGING.get(key)
+    if ring is None:
+        ring = _STAGING[key] = [0, [(torch.zeros(total, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(3)]]
+    pinned, event = ring[1][ring[0]]
+    ring[0] = (ring[0] + 1) % len(ring[1])
+    event.synchronize()      # (the copy issued from this buffer three steps ago: does not block in practice)
+    for i in range(1, n):
+        o = (i - 1) * per_frame
+        pinned[o:o + 9 * B].copy_(host[i][0].reshape(-1))
+        pinned[o + 9 * B:o + 12 * B].copy_(host[i][1].reshape(-1))
+        pinned[o + 12 * B:o + 28 * B].copy_(host[i][2].reshape(-1))
+    block = torch.empty(total, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        block.copy_(pinned, non_blocking=True)
+        event.record(torch.cuda.current_stream(device))
+    out = [None]
+    for i in range(1, n):
+        o = (i - 1) * per_frame
+        out.append((block[o:o + 9 * B].view(B, 1, 9), block[o + 9 * B:o + 12 * B].view(B, 1, 3), (host[i][0], host[i][1]),
+                    block[o + 12 * B:o + 28 * B].view(B, 4, 4)))
+    return out
+
+
 def fusionnet_subsequence_loss(model, images, depths, poses, K, warp_grid=None):
     """``model`` = [feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder];
     ``images`` list of [B,3,H,W], ``depths`` list of [B,H,W], ``poses`` list of [B,4,4], ``K`` [B,3,3] (full resolution).
@@ -64,17 +114,19 @@ def fusionnet_subsequence_loss(model, images, depths, poses, K, warp_grid=None):
     if warp_grid is None:
         warp_grid = get_warp_grid_for_cost_volume_calculation(W // 2, H // 2, images[0].device)
 
+    matrices = subsequence_matrices(poses, half_K, images[0].device)      # every frame's small matrices: one upload per step
     feats = [fs(*fe(img)) for img in images]
     loss = 0.0
     state = None
     full_predictions = []
     for i in range(1, len(images)):
         ref, meas = feats[i], feats[i - 1]
-        cost_volume = calculate_cost_volume_by_warping(ref[0], meas[0], poses[i], poses[i - 1], half_K, warp_grid, Config.train_min_depth,
-                                                       Config.train_max_depth, Config.train_n_depth_levels, images[0].device, True)
+        Hm, kt, host, lstm_T = matrices[i]
+        cost_volume = cost_volume_from_matrices(ref[0], [meas[0]], Hm, kt, host, Config.train_min_depth, Config.train_max_depth,
+                                                Config.train_n_depth_levels, True)
         skip0, skip1, skip2, skip3, bottom = enc(ref[0], ref[1], ref[2], ref[3], cost_volume)
         depth_estimation = F.interpolate(depths[i].view(B, 1, H, W), scale_factor=1.0 / 32.0, mode="nearest")
-        state = lstm(bottom, state, poses[i - 1], poses[i], depth_estimation, lstm_K)
+        state = lstm(bottom, state, poses[i - 1], poses[i], depth_estimation, lstm_K, transformation=lstm_T)
         full, half, quarter, one_eight, one_sixteen = dec(images[i], skip0, skip1, skip2, skip3, state[0])
         loss = loss + multi_scale_loss([one_sixteen, one_eight, quarter, half, full], depths[i])
         full_predictions.append(full)
@@ -111,17 +163,19 @@ def forward_pass(images, depths, poses, K, model, is_training):
     lstm_K = K.to(device).clone()
     lstm_K[:, 0:2, :] = lstm_K[:, 0:2, :] / 32.0
     warp_grid = get_warp_grid_for_cost_volume_calculation(W // 2, H // 2, device)
+    matrices = subsequence_matrices(poses, half_K, device)
     feats = [fs(*fe(img)) for img in images]
     meters = [LossMeter() for _ in range(4)]
     l1_meter, huber_meter, l1_inv_meter, l1_rel_meter = meters
     optimizer_loss, predictions, state = 0, None, None
     for i in range(1, len(images)):
         ref, meas = feats[i], feats[i - 1]
-        cost_volume = calculate_cost_volume_by_warping(ref[0], meas[0], poses[i], poses[i - 1], half_K, warp_grid, Config.train_min_depth,
-                                                       Config.train_max_depth, Config.train_n_depth_levels, device, True)
+        Hm, kt, host, lstm_T = matrices[i]
+        cost_volume = cost_volume_from_matrices(ref[0], [meas[0]], Hm, kt, host, Config.train_min_depth, Config.train_max_depth,
+                                                Config.train_n_depth_levels, True)
         skip0, skip1, skip2, skip3, bottom = enc(ref[0], ref[1], ref[2], ref[3], cost_volume)
         depth_estimation = F.interpolate(depths[i].view(B, 1, H, W), scale_factor=1.0 / 32.0, mode="nearest")
-        state = lstm(bottom, state, poses[i - 1], poses[i], depth_estimation, lstm_K)
+        state = lstm(bottom, state, poses[i - 1], poses[i], depth_estimation, lstm_K, transformation=lstm_T)
         full, half, quarter, one_eight, one_sixteen = dec(images[i], skip0, skip1, skip2, skip3, state[0])
         optimizer_loss = optimizer_loss + update_losses(predictions=[one_sixteen, one_eight, quarter, half, full], weights=[1, 1, 1, 1, 1],
                                                         groundtruth=depths[i], is_training=is_training, l1_meter=l1_meter,

@@ -132,6 +132,18 @@ def cost_volume_fusion(image1, image2s, pose1, pose2s, K, warp_grid, min_depth, 
     return _ops.cost_volume(image1, image2s, Hm, kt, float(min_depth), float(max_depth), int(n_depth_levels), bool(dot_product), variant, work_list)
 
 
+def cost_volume_from_matrices(image1, image2s, Hm, kt, host, min_depth, max_depth, n_depth_levels, dot_product=True):
+    """``cost_volume_fusion`` for callers that already hold the sweep matrices (``Hm`` [B,M,9], ``kt`` [B,M,3] on the features' device,
+    ``host`` = their host copies or None): a training step evaluates and uploads the matrices of its whole sub-sequence at once
+    (dvmvs.training).  Same launch, same host-side choice of the sweep configuration and work list."""
+    H, W = image1.shape[2], image1.shape[3]
+    variant = sweep_variant(host, H, W, n_depth_levels, min_depth, max_depth, dot_product)
+    work_list = None
+    if host is not None and dot_product and variant in (0, 2, 3, 4, 5) and H * W >= 64 * 64 and SWEEP_WORK_LIST:
+        work_list = _upload_work_list(host, H, W, n_depth_levels, min_depth, max_depth, variant, image1.device)
+    return _ops.cost_volume(image1, list(image2s), Hm, kt, float(min_depth), float(max_depth), int(n_depth_levels), bool(dot_product), variant, work_list)
+
+
 def calculate_cost_volume_by_warping(image1, image2, pose1, pose2, K, warp_grid, min_depth, max_depth, n_depth_levels,
                                      device, dot_product):
     """Cost volume of a single measurement frame (the M = 1 case of ``cost_volume_fusion``)."""
