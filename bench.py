@@ -347,6 +347,22 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets, force_variant=No
     return sum(per_geometry) / len(per_geometry), algorithmic_bytes, per_geometry, variants
 
 
+def issue_roofline(kernel_s):
+    """Issue-time accounting of the engine's sweep kernel from the newest committed PMC profile (profiles/r*_sweep_issue_pmc.json)."""
+    try:
+        import glob
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sweep_issue_pmc.json")))[-1]
+        pmc = json.load(open(path))
+        name, k = next((n, v) for n, v in pmc["kernels"].items() if n.startswith("sweep_tiled_kernel"))
+        busy = k["issue_busy_us_per_simd"]
+        return {"bound": "instruction_issue", "kernel": name, "issue_busy_us_per_simd": busy, "kernel_us": kernel_s * 1e6,
+                "frac": busy / (kernel_s * 1e6), "unit": "us of instruction issue per SIMD (SQ_ACTIVE_INST_ANY x 4 cycles / 1024 SIMDs / clock)",
+                "clock_ghz": pmc["clock_ghz_during_kernel"], "source": os.path.relpath(path, ROOT),
+                "other_kernels": {n: v["issue_busy_us_per_simd"] for n, v in pmc["kernels"].items() if n != name}}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def count_graph_kernels(graph):
     """Kernel nodes of a captured torch.cuda.CUDAGraph, read from its debug dump (None when the runtime cannot dump)."""
     import re
@@ -809,7 +825,7 @@ def main():
             import glob
             import hashlib
             digest = hashlib.sha256(b"".join(open(os.path.join(ROOT, "deep-video-mvs_amd", "csrc", f), "rb").read()
-                                             for f in ("sweep_tiled.hip", "cost_volume.hip", "plane_sweep.h"))).hexdigest()
+                                             for f in ("sweep_tiled.hip", "cost_volume.hip", "plane_sweep.h", "sweep_sample.h"))).hexdigest()
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cost_volume_pmc.json")), reverse=True):
                 pmc = json.load(open(path))
                 if pmc.get("shape") == [1, M, 32, 128, 160, 64] and pmc.get("kernel_sources_sha256") == digest:
@@ -887,6 +903,10 @@ def main():
             "roofline_lds": {"bound": "lds", "achieved": lds_bytes / kernel_s / 1e12, "peak": LDS_PEAK_TBPS, "unit": "TB/s",
                              "frac": lds_bytes / kernel_s / 1e12 / LDS_PEAK_TBPS, "lds_bytes": lds_bytes,
                              "pattern_floor_us": SWEEP_LDS_PATTERN_FLOOR_US, "frac_of_pattern_floor": SWEEP_LDS_PATTERN_FLOOR_US / (kernel_s * 1e6)},
+            # what the launch's duration is made of (round 5): instruction ISSUE.  Summed over a SIMD's waves, the cycles with an instruction
+            # issuing / executing (SQ_ACTIVE_INST_ANY of the committed PMC profile, index line 0) add up to the waves' lifetime in both sweep
+            # kernels: neither HBM nor LDS bandwidth nor the matrix pipe but the instruction count bounds them
+            "roofline_issue": issue_roofline(kernel_s),
             "roofline_mfma_variant": mfma_variant,
             "roofline_other": other_kernels,
             # what the engine's warm-up costs (outside the timed steps): eager first frames, graph capture, first launches of the graphs

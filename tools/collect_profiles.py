@@ -57,7 +57,7 @@ def main():
         per_line[int(m.group(1))] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write}
     if per_line:
         digest = hashlib.sha256(b"".join(open(os.path.join(ROOT, "deep-video-mvs_amd", "csrc", f), "rb").read()
-                                         for f in ("sweep_tiled.hip", "cost_volume.hip", "plane_sweep.h"))).hexdigest()
+                                         for f in ("sweep_tiled.hip", "cost_volume.hip", "plane_sweep.h", "sweep_sample.h"))).hexdigest()
         mean = lambda key: sum(v[key] for v in per_line.values()) / len(per_line)
         payload = {
             "kernel": "dvmvs::sweep_tiled_kernel + dvmvs::sweep_spill_kernel (one cost-volume op)",
