@@ -302,7 +302,7 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets, force_variant=No
             # exactly what DepthEngine._evaluate_frame_parameters does: configuration (2 / 3, or their single-pass forms 4 / 5 when the
             # plan queues nothing) and work list in one walk
             items = torch.zeros(work_list.numel(), dtype=torch.int32)
-            variant = _ops.sweep_plan_host(host[0], host[1], H, W, D, engine.min_depth, engine.max_depth, 0, items)
+            variant = _ops.sweep_plan_host(host[0], host[1], H, W, D, engine.min_depth, engine.max_depth, 0, items, allow_mfma=getattr(engine, "sweep_mfma", False))
             work_list.copy_(items)
             return variant
         variant = utils.sweep_variant(host, H, W, D, engine.min_depth, engine.max_depth)
@@ -813,7 +813,7 @@ def main():
             m_s, _, m_per, _ = measure_cost_volume_kernel(engine, M, args.kernel_reps, timed, force_variant=6)
             ma_s, _, ma_per, _ = measure_cost_volume_kernel(engine, M, reps_all, all_sets, force_variant=6, rounds=2)
             mfma_variant = {"kernel": "sweep_mfma_kernel (variant 6: tap dots per measurement cell on v_mfma_f32_16x16x4_f32, table look-ups per plane)",
-                            "engine_uses_it": False, "kernel_us_timed_steps": m_s * 1e6, "frac_timed_steps": alg_bytes / m_s / 1e9 / HBM_PEAK_GBPS,
+                            "engine_uses_it": "on the pairs dvmvs_sweep_plan6 takes (roofline.sweep_variants); this leg forces it on every pair", "kernel_us_timed_steps": m_s * 1e6, "frac_timed_steps": alg_bytes / m_s / 1e9 / HBM_PEAK_GBPS,
                             "kernel_us_all_pairs": ma_s * 1e6, "frac_all_pairs": alg_bytes / ma_s / 1e9 / HBM_PEAK_GBPS,
                             "worst_us_all_pairs": max(ma_per) * 1e6, "pairs_where_faster_than_engine_choice": int(sum(1 for x, y in zip(ma_per, a_per) if x < y)),
                             "kernel_us_per_geometry_timed_steps": [round(t * 1e6, 2) for t in m_per]}
@@ -876,7 +876,8 @@ def main():
                        "cyclic_gc": "left on" if args.keep_gc else "disabled during the timed steps (gc.collect + gc.freeze before, re-enabled after), as "
                                     "timeit does; value_gc_on = the same measurement with CPython's collector left on",
                        "parallelism": f"sequence-sharded x{world}, no data-path collective"},
-            "roofline": {"kernel": "sweep_tiled_kernel + sweep_spill_kernel (fused warp + correlation, all planes, all measurement frames)",
+            "roofline": {"kernel": "the engine's sweep per keyframe pair (fused warp + correlation, all planes, all measurement frames): sweep_mfma_kernel where "
+                                   "dvmvs_sweep_plan6 takes the pair, else sweep_tiled_kernel [+ sweep_spill_kernel]",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "sample": "frac / achieved / kernel_us: mean over the keyframe geometries of the timed steps (easy sideways pairs on a short run); "
                                    "all_pairs: every pair of the 285-line keyframe index; whole_index: 25 lines spread over it",
@@ -890,7 +891,8 @@ def main():
                          "sweep_variants": {"2 (default: 3 x 48 KB boxes, 256 threads; two passes)": variants.count(2),
                                             "3 (wide-baseline: 2 x 72 KB boxes, 512 threads; two passes)": variants.count(3),
                                             "4 (default, single pass: the host's plan queues nothing)": variants.count(4),
-                                            "5 (wide-baseline, single pass)": variants.count(5)},
+                                            "5 (wide-baseline, single pass)": variants.count(5),
+                                            "6 (correlate-then-interpolate on the fp32 matrix cores, channels-last maps: dvmvs_sweep_plan6 took the pair)": variants.count(6)},
                          "engine_frames_per_sweep_variant": {str(k): v for k, v in sorted(engine.sweep_variant_counts.items())},
                          "whole_index": whole_index},
             # HBM is not what binds this op (13 MB of algorithmic traffic against 0.69 GFLOP of tap arithmetic and 1.3 GB of LDS

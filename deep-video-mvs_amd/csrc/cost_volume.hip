@@ -117,6 +117,7 @@ int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream);
 bool sweep_mfma_supports(const CostVolumeArgs& a);
 int launch_sweep_mfma(const CostVolumeArgs& a, hipStream_t stream);
 int launch_sweep_mfma_tuning(int which, const CostVolumeArgs& a, hipStream_t stream);
+void sweep_mfma_estimate_host(const float* Hm, const float* kt, int M, int H, int W, int D, double inv_base, double inv_step, double* stats);
 
 // Predicted duration (us) of the sweep + second pass in one configuration from its plan statistics (dvmvs_sweep_plan_stats):
 // base + staged runs of the longest work item (the work list cuts chains to <= 3) + a fixed cost when the second pass is not empty
@@ -240,13 +241,56 @@ extern "C" int dvmvs_sweep_select_variant(const float* Hm_host, const float* kt_
   return dvmvs::sweep_model_us(0, d, B, H, W, D) <= dvmvs::sweep_model_us(1, w, B, H, W, D) ? 2 : 3;
 }
 
+// Work estimate of the correlate-then-interpolate sweep (variant 6) for HOST copies of the matrices (batch item 0): see sweep_mfma.hip.
+extern "C" int dvmvs_sweep_mfma_estimate(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
+                                         double* stats) {
+  if (!Hm_host || !kt_host || !stats || B <= 0 || M <= 0 || H <= 0 || W <= 0 || D <= 0) return DVMVS_EINVAL;
+  if (M > DVMVS_MAX_MEASUREMENTS || D > DVMVS_MAX_DEPTH_LEVELS) return DVMVS_EUNSUPPORTED;
+  if (!(min_depth > 0.0) || !(max_depth > 0.0)) return DVMVS_EINVAL;
+  const double inv_base = 1.0 / max_depth, inv_step = D > 1 ? (1.0 / min_depth - 1.0 / max_depth) / (D - 1) : 0.0;
+  dvmvs::sweep_mfma_estimate_host(Hm_host, kt_host, M, H, W, D, inv_base, inv_step, stats);
+  return 0;
+}
+
 // dvmvs_sweep_select_variant + dvmvs_sweep_work_list in ONE walk over the (tile, chunk) pairs (the per-frame host cost of the sweep
 // plan: ~0.15 ms for an easy pair, ~0.5 ms where both configurations have to be planned): decides the configuration (or takes
 // `variant` = 2 / 3 as the configuration given; 0 = decide), leaves that configuration's work list in `work_list_host` and returns the
 // variant to launch with: 2 / 3 (two passes) or, when the plan queues nothing for the second pass, 4 / 5 (the same configurations as ONE
 // launch -- the empty second pass costs 3-4.5 us of every frame it is launched in, five frames of six on the sample scene).
+namespace dvmvs {
+int sweep_plan_impl(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
+                    int variant, unsigned int* work_list_host, size_t work_list_bytes, bool* easy_out);
+}
+
 extern "C" int dvmvs_sweep_plan(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
                                 int variant, unsigned int* work_list_host, size_t work_list_bytes) {
+  return dvmvs::sweep_plan_impl(Hm_host, kt_host, B, M, H, W, D, min_depth, max_depth, variant, work_list_host, work_list_bytes, nullptr);
+}
+
+extern "C" int dvmvs_sweep_plan6(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
+                                 unsigned int* work_list_host, size_t work_list_bytes) {
+  if (!Hm_host || !kt_host || !work_list_host || work_list_bytes < 2 * sizeof(unsigned int)) return DVMVS_EINVAL;
+  // The estimate first (25 us): tiles per wave = the wave's MFMA + operand work, st[2] = strips beyond the first (magnified footprints),
+  // st[3] = footprints that cannot be bounded (behind the camera).  Below 14 tiles the MFMA sweep is taken whatever the tiled plan says, from 18
+  // on never, in between when the tiled plan is not an easy one -- so the tiled plan and its work list (0.17 ms of the planning thread, which
+  // has one graph launch's time per frame) are only walked when a tiled kernel may run.  Lock-step batches keep the tiled kernel (the
+  // estimate looks at one batch item).
+  double st[4] = {0.0, 0.0, 0.0, 1.0};
+  const bool estimated = B == 1 && dvmvs_sweep_mfma_estimate(Hm_host, kt_host, B, M, H, W, D, min_depth, max_depth, st) == 0;
+  const bool bounded = estimated && st[3] < 0.01 && st[2] < 1.0;
+  if (bounded && st[0] < 14.0) {
+    work_list_host[0] = 0u;      // (an empty list: a tiled launch on it does nothing)
+    work_list_host[1] = 0u;
+    return 6;
+  }
+  bool easy = false;
+  const int tiled = dvmvs::sweep_plan_impl(Hm_host, kt_host, B, M, H, W, D, min_depth, max_depth, 0, work_list_host, work_list_bytes, &easy);
+  if (tiled < 0) return tiled;
+  return bounded && !easy && st[0] < 18.0 ? 6 : tiled;
+}
+
+int dvmvs::sweep_plan_impl(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
+                           int variant, unsigned int* work_list_host, size_t work_list_bytes, bool* easy_out) {
   if (!Hm_host || !kt_host || !work_list_host || B <= 0 || M <= 0 || H <= 0 || W <= 0 || D <= 0) return DVMVS_EINVAL;
   if (M > DVMVS_MAX_MEASUREMENTS || D > DVMVS_MAX_DEPTH_LEVELS) return DVMVS_EUNSUPPORTED;
   if (!(min_depth > 0.0) || !(max_depth > 0.0) || (variant != 0 && variant != 2 && variant != 3)) return DVMVS_EINVAL;
@@ -260,6 +304,7 @@ extern "C" int dvmvs_sweep_plan(const float* Hm_host, const float* kt_host, int 
     // nothing queued for the second pass in this plan: the single-pass launch (no second kernel; should the kernel's own plan
     // disagree, it gathers that run inline)
     const int chosen = d[3] == 0 ? 4 : 2;
+    if (easy_out) *easy_out = dvmvs::sweep_is_easy(d);
     if (variant == 2 || dvmvs::sweep_is_easy(d)) return chosen;
     dvmvs::sweep_plan_stats_host(1, Hm_host, kt_host, B, M, H, W, D, inv_base, inv_step, w);
     if (dvmvs::sweep_model_us(0, d, B, H, W, D) <= dvmvs::sweep_model_us(1, w, B, H, W, D)) return chosen;

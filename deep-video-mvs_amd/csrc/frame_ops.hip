@@ -169,6 +169,31 @@ int launch_bias_act(const float* x, float* dst, long long dst_batch_stride, cons
   return launch_status();
 }
 
+// [B, C, H*W] -> [B, H*W, C] for C <= 64, a multiple of 4: the measurement maps of the correlate-then-interpolate sweep are read one
+// 128-byte line per cell, so a keyframe's features are kept channels-last in the engine's feature cache (one such copy per keyframe:
+// this kernel instead of the contiguous copy the cache made before).  64 pixels x C channels per workgroup through LDS: reads coalesced
+// along the pixels, writes as float4 along the channels.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.y, p0 = blockIdx.x * 64;
+  const float* s = src + static_cast<size_t>(b) * C * HW;
+  float* d = dst + static_cast<size_t>(b) * C * HW;
+  for (int i = threadIdx.x; i < C * 64; i += 256) {
+    const int c = i >> 6, p = i & 63;
+    tile[p][c] = (p0 + p < HW) ? s[static_cast<size_t>(c) * HW + p0 + p] : 0.0f;
+  }
+  __syncthreads();
+  const int quads = C >> 2;
+  for (int i = threadIdx.x; i < quads * 64; i += 256) {
+    const int p = i / quads, c4 = (i - p * quads) * 4;
+    if (p0 + p < HW) {
+      float4 v;
+      v.x = tile[p][c4]; v.y = tile[p][c4 + 1]; v.z = tile[p][c4 + 2]; v.w = tile[p][c4 + 3];
+      *reinterpret_cast<float4*>(d + static_cast<size_t>(p0 + p) * C + c4) = v;
+    }
+  }
+}
+
 }  // namespace dvmvs
 
 extern "C" int dvmvs_bias_act_fwd(const float* x, float* dst, long long dst_batch_stride, const float* bias, const float* residual,
@@ -234,4 +259,14 @@ extern "C" int dvmvs_depthwise_conv_fwd(const float* in, const float* weight, co
   if (activation == 1) DVMVS_DW(5, 1);
   DVMVS_DW(5, 2);
 #undef DVMVS_DW
+}
+
+extern "C" int dvmvs_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, dvmvs_stream_t stream) {
+  using namespace dvmvs;
+  if (!src || !dst || src == dst) return DVMVS_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || B > 65535) return DVMVS_EINVAL;
+  if (C > 64 || C % 4 != 0) return DVMVS_EUNSUPPORTED;
+  const int HW = H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst, C, HW);
+  return launch_status();
 }

@@ -100,8 +100,12 @@ struct SweepSamples {
 };
 
 // FULL: exactly 32 channels (the hot-path shape: no per-channel bounds tests); otherwise any C <= 32 (NHWC: a multiple of 4).
-template <class Cfg, bool NHWC, bool FULL>
-__global__ __launch_bounds__(64, Cfg::WAVES) void sweep_mfma_kernel(CostVolumeArgs a) {
+// GRID2D: one batch item whose groups divide by 8 (the frame engine's case): blockIdx.y is the chunk -- the dispatcher walks x first, so the far
+// chunks, whose boxes hold more cells, start first and the launch's tail is made of the cheap near ones -- and blockIdx.x & 7 the XCD, each of
+// which gets a contiguous range of groups; group -> (row, column) by a host-made reciprocal: no integer division in the wave's prologue
+// (the general decode below costs ~100 scalar instructions of a wave's ~1 900).
+template <class Cfg, bool NHWC, bool FULL, bool GRID2D>
+__global__ __launch_bounds__(64, Cfg::WAVES) void sweep_mfma_kernel(CostVolumeArgs a, unsigned int groups_x_reciprocal) {
   constexpr int GW = Cfg::GW, GH = Cfg::GH, PW = Cfg::PW, CAP = Cfg::CAP, CPW = Cfg::CPW, PITCH = Cfg::PITCH;
   constexpr int WP = PW * CPW;   // planes per wave
   const int C = FULL ? kMfmaSweepChannels : a.C;
@@ -115,13 +119,21 @@ __global__ __launch_bounds__(64, Cfg::WAVES) void sweep_mfma_kernel(CostVolumeAr
   // measurement footprint is fetched into one L2 ----
   const int groups_x = (a.W + GW - 1) / GW, groups_y = (a.H + GH - 1) / GH;
   const int wchunks = (a.D + WP - 1) / WP;
+  int b, item, wchunk, gx, gy;
+  if (GRID2D) {
+    const int g = static_cast<int>(blockIdx.x & 7) * static_cast<int>(gridDim.x >> 3) + static_cast<int>(blockIdx.x >> 3);
+    b = 0;
+    wchunk = static_cast<int>(blockIdx.y);
+    gy = static_cast<int>(__umulhi(static_cast<unsigned int>(g), groups_x_reciprocal));      // g / groups_x for g < 2^16 (checked by the launch)
+    gx = g - gy * groups_x;
+    item = wchunk * static_cast<int>(gridDim.x) + g;
+  } else {
   const int per_b = groups_y * groups_x * wchunks, total = per_b * a.B;
   const int per_xcd = (total + 7) / 8;
-  const int item = static_cast<int>(blockIdx.x & 7) * per_xcd + static_cast<int>(blockIdx.x >> 3);
+  item = static_cast<int>(blockIdx.x & 7) * per_xcd + static_cast<int>(blockIdx.x >> 3);
   if (item >= total) return;
-  const int b = item / per_b;
+  b = item / per_b;
   int rem = item - b * per_b;
-  int wchunk, gx, gy;
   if (Cfg::ORDER == 1 && a.B == 1 && per_xcd * 8 == total && per_xcd % wchunks == 0) {
     // chunk-major within the XCD's range of groups: the far chunks, whose boxes hold more cells, start first; the launch's tail is made of
     // the cheap near chunks
@@ -135,6 +147,7 @@ __global__ __launch_bounds__(64, Cfg::WAVES) void sweep_mfma_kernel(CostVolumeAr
     rem /= wchunks;
     gx = rem % groups_x;
     gy = rem / groups_x;
+  }
   }
   if (Cfg::STAGGER >= 2) {   // a start delay by wave slot (64 * STAGGER_UNIT cycles per slot step)
     constexpr int U = Cfg::STAGGER == 2 ? 8 : Cfg::STAGGER == 3 ? 16 : Cfg::STAGGER == 4 ? 32 : 64;
@@ -203,24 +216,26 @@ __global__ __launch_bounds__(64, Cfg::WAVES) void sweep_mfma_kernel(CostVolumeAr
     for (int k = 0; k < 9; ++k) Hm[k] = Hm_c[m * 9 + k];
     const SweepRay ray = sweep_ray(Hm, xf, yf);
     S.alive = 0u;
+    float4v kd[4];
+    float ix[4], iy[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kd[j] = ktd[m * WP + c * PW + 4 * j + q];
+    sweep_samples<2>(ray, kd, sc, ix, iy);   // clamped to [-1, W] x [-1, H]; NaN -> -1; two planes' chains interleaved
+    __builtin_amdgcn_sched_barrier(0);
+    sweep_samples<2>(ray, kd + 2, sc, ix + 2, iy + 2);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float4v kd = ktd[m * WP + c * PW + 4 * j + q];
-      float ix, iy;
-      sweep_sample(ray, kd.x, kd.y, kd.z, sc, &ix, &iy);   // clamped to [-1, W] x [-1, H]; NaN -> -1
-      const bool al = live & (d_wave + c * PW + 4 * j + q < a.D) & (ix > -1.0f) & (ix < sc.Wf) & (iy > -1.0f) & (iy < sc.Hf);   // (no short-circuit: one basic block)
-      const float fx = floorf(ix), fy = floorf(iy);
+      const bool al = live & (d_wave + c * PW + 4 * j + q < a.D) & (ix[j] > -1.0f) & (ix[j] < sc.Wf) & (iy[j] > -1.0f) & (iy[j] < sc.Hf);   // (no short-circuit: one basic block)
+      const float fx = floorf(ix[j]), fy = floorf(iy[j]);
       S.xy[j] = (static_cast<int>(fx) & 0xffff) | (static_cast<int>(fy) << 16);
-      S.frx[j] = ix - fx;
-      S.fry[j] = iy - fy;
+      S.frx[j] = ix[j] - fx;
+      S.fry[j] = iy[j] - fy;
       S.alive |= al ? (1u << j) : 0u;
     }
   };
 
-  SweepSamples S, Sn;
+  SweepSamples S;
   MFMA_TRACE(tr_first = __builtin_amdgcn_s_memtime();)
-  positions(0, 0, S);
-  MFMA_TRACE(tr_pos += __builtin_amdgcn_s_memtime() - tr_first;)
 
   for (int c = 0; c < CPW; ++c) {
     const int d_block = d_wave + c * PW;
@@ -228,10 +243,11 @@ __global__ __launch_bounds__(64, Cfg::WAVES) void sweep_mfma_kernel(CostVolumeAr
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // sum over frames and taps of w <f1, f2>; plane d_block + 4 j + q
 
     for (int m = 0; m < a.M; ++m) {
-      const bool frame_follows = m + 1 < a.M;
-      const bool has_next = frame_follows || (c + 1 < CPW && d_block + PW < a.D);
-      const int c_next = frame_follows ? c : c + 1, m_next = frame_follows ? m + 1 : 0;
-      bool next_done = false;
+      // (round 5, v2 computed the NEXT frame's positions behind the first operand requests: a second sample set, 13 registers, for nothing --
+      // the launch is bound by instruction issue, not by the round trip it covered)
+      MFMA_TRACE(const unsigned long long tr_p0 = __builtin_amdgcn_s_memtime();)
+      positions(c, m, S);
+      MFMA_TRACE(asm volatile("s_nop 0" :: "v"(S.xy[0]), "v"(S.xy[1]), "v"(S.xy[2]), "v"(S.xy[3])); tr_pos += __builtin_amdgcn_s_memtime() - tr_p0;)
       const __amdgpu_buffer_rsrc_t meas_rsrc = map_resource(as_global(a.image2[m]) + static_cast<size_t>(b) * C * HW, map_bytes);
 
       // ---- passes: the 16 planes as one box; a box of more than SPLIT x CAP cells (diagonal or fast epipolar motion: the box is
@@ -323,14 +339,6 @@ __global__ __launch_bounds__(64, Cfg::WAVES) void sweep_mfma_kernel(CostVolumeAr
           seek(base, n);
           issue(A0);
           issue(A1);
-          if (has_next && !next_done) {
-            // the next (chunk, frame)'s sample positions, in the shadow of the first operand requests
-            MFMA_TRACE(const unsigned long long tr_p0 = __builtin_amdgcn_s_memtime();)
-            positions(c_next, m_next, Sn);
-            next_done = true;
-            MFMA_TRACE(asm volatile("s_nop 0" :: "v"(Sn.xy[0]), "v"(Sn.xy[1]), "v"(Sn.xy[2]), "v"(Sn.xy[3]));)
-            MFMA_TRACE(const unsigned long long tr_p1 = __builtin_amdgcn_s_memtime(); tr_pos += tr_p1 - tr_p0; tr_tiles -= tr_p1 - tr_p0;)
-          }
           for (int t = 0; t < ntiles; t += 2) {
             compute(A0, t);
             issue(A0);
@@ -392,10 +400,6 @@ __global__ __launch_bounds__(64, Cfg::WAVES) void sweep_mfma_kernel(CostVolumeAr
           MFMA_TRACE(asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); tr_look += __builtin_amdgcn_s_memtime() - tr_t1;)
         }
       }
-      if (has_next) {
-        if (!next_done) positions(c_next, m_next, Sn);   // (this frame had nothing to do)
-        S = Sn;
-      }
     }
 
     // sum over frames, then / C, then / M (for power-of-two counts x * 2^-k is x / 2^k exactly: the reference's per-frame / C followed
@@ -430,14 +434,101 @@ __global__ __launch_bounds__(64, Cfg::WAVES) void sweep_mfma_kernel(CostVolumeAr
 #endif
 }
 
+// ---- host-side work estimate ---------------------------------------------------------------------------------------------------
+// What a launch of the shipped configuration will cost, from the HOST copies of the matrices (no HIP call): the kernel's duration follows the
+// number of 16-cell tiles and of passes per wave (section 4.1b of DESIGN.md), and both follow from the sample boxes.  A box is estimated
+// from the group's four corner pixels on the first and last plane of a run (a plane-induced homography maps the group to a convex
+// quadrilateral, the position is monotone along the epipolar line while Z > 0), on every sixth group column of every sixth group row, staggered.
+// stats[0..3]: mean tiles per wave, mean passes per wave, mean strips beyond the first per wave, waves with a corner behind the camera or a
+// non-finite position (their boxes are not estimated: counted as the image-sized worst case) as a fraction.
+#pragma clang fp contract(off)
+template <class Cfg>
+void host_mfma_estimate(const float* Hm, const float* kt, int M, int H, int W, int D, double inv_base, double inv_step, double* stats) {
+  constexpr int GW = Cfg::GW, GH = Cfg::GH, PW = Cfg::PW, CAP = Cfg::CAP;
+  const float Wf = static_cast<float>(W), Hf = static_cast<float>(H), wn = Wf * 0.5f, hn = Hf * 0.5f, Wm1 = static_cast<float>(W - 1), Hm1 = static_cast<float>(H - 1);
+  const int groups_x = (W + GW - 1) / GW, groups_y = (H + GH - 1) / GH, chunks = (D + PW - 1) / PW;
+  double tiles = 0.0, passes = 0.0, extra_strips = 0.0, wild = 0.0;
+  long long waves = 0;
+  // K t / depth per frame and plane, once (this function runs once per keyframe on the engine's planning thread: ~25 us)
+  float ktd[DVMVS_MAX_MEASUREMENTS][DVMVS_MAX_DEPTH_LEVELS][3];
+  for (int d = 0; d < D; ++d) {
+    const float depth = static_cast<float>(1.0 / (inv_base + static_cast<double>(d) * inv_step));
+    for (int m = 0; m < M; ++m)
+      for (int k = 0; k < 3; ++k) ktd[m][d][k] = kt[m * 3 + k] / depth;
+  }
+  SweepRay rays[4];      // the current group's corner rays for the current frame
+  // cells of the box of planes [d0, d1] of frame m for the group whose corner rays are in `rays`; < 0: not estimable
+  auto box_cells = [&](int m, int d0, int d1) -> long long {
+    float lo_x = 1e30f, hi_x = -1e30f, lo_y = 1e30f, hi_y = -1e30f;
+    for (int corner = 0; corner < 8; ++corner) {
+      const SweepRay& r = rays[corner & 3];
+      const float* k = ktd[m][(corner & 4) ? d1 : d0];
+      const float denom = (r.Z0 + k[2]) + 1e-8f;
+      const float u = (r.X0 + k[0]) / denom, v = (r.Y0 + k[1]) / denom;
+      const float ix = ((((u - wn) / wn) + 1.0f) * 0.5f) * Wm1, iy = ((((v - hn) / hn) + 1.0f) * 0.5f) * Hm1;
+      if (!(denom > 1e-6f) || !(ix > -1e6f && ix < 1e6f && iy > -1e6f && iy < 1e6f)) return -1;
+      lo_x = fminf(lo_x, ix); hi_x = fmaxf(hi_x, ix); lo_y = fminf(lo_y, iy); hi_y = fmaxf(hi_y, iy);
+    }
+    if (hi_x <= -1.0f || lo_x >= Wf || hi_y <= -1.0f || lo_y >= Hf) return 0;      // every sample dead: nothing to do
+    const float cx0 = floorf(fmaxf(lo_x, -1.0f)), cx1 = floorf(fminf(hi_x, Wf - 1.0f)) + 1.0f;
+    const float cy0 = floorf(fmaxf(lo_y, -1.0f)), cy1 = floorf(fminf(hi_y, Hf - 1.0f)) + 1.0f;
+    return static_cast<long long>(cx1 - cx0 + 1.0f) * static_cast<long long>(cy1 - cy0 + 1.0f);
+  };
+  auto account = [&](long long cells, double* t, double* s) {
+    if (cells < 0) cells = static_cast<long long>(H) * W / 4;      // (a footprint that cannot be bounded from its corners: a large one)
+    *t += static_cast<double>((cells + 15) / 16);
+    if (cells > CAP) *s += static_cast<double>((cells + CAP - 1) / CAP - 1);
+  };
+  constexpr int stride = 6;      // (36 of 1 280 groups at 160 x 128; strides 4 / 6 / 8 pick within 0.3 us of each other over the 285 pairs: profiles/r05_sweep_selection.md)
+  for (int gy = 1; gy < groups_y; gy += stride)
+    for (int gx = 1 + (stride / 2) * ((gy / stride) % 2); gx < groups_x; gx += stride) {
+      const int x0 = gx * GW, y0 = gy * GH;
+      const float xs[2] = {static_cast<float>(x0), static_cast<float>(x0 + GW - 1 < W - 1 ? x0 + GW - 1 : W - 1)};
+      const float ys[2] = {static_cast<float>(y0), static_cast<float>(y0 + GH - 1 < H - 1 ? y0 + GH - 1 : H - 1)};
+      waves += chunks;
+      for (int m = 0; m < M; ++m) {
+        for (int corner = 0; corner < 4; ++corner) rays[corner] = sweep_ray(Hm + m * 9, xs[corner & 1], ys[corner >> 1]);
+        for (int c = 0; c < chunks; ++c) {
+          const int d0 = c * PW, d1 = (d0 + PW - 1 < D - 1) ? d0 + PW - 1 : D - 1;
+          const long long cells = box_cells(m, d0, d1);
+          if (cells == 0) continue;
+          if (cells < 0) wild += 1.0 / M;
+          if (cells >= 0 && cells <= static_cast<long long>(Cfg::SPLIT) * CAP) {
+            account(cells, &tiles, &extra_strips);
+            passes += 1.0;
+          } else {
+            for (int sub = d0; sub <= d1; sub += 4) {
+              const long long part = box_cells(m, sub, sub + 3 < d1 ? sub + 3 : d1);
+              if (part == 0) continue;
+              account(part, &tiles, &extra_strips);
+              passes += 1.0;
+            }
+          }
+        }
+      }
+    }
+  const double n = waves > 0 ? static_cast<double>(waves) : 1.0;
+  stats[0] = tiles / n; stats[1] = passes / n; stats[2] = extra_strips / n; stats[3] = wild / n;
+}
+#pragma clang fp contract(fast)
+
+void sweep_mfma_estimate_host(const float* Hm, const float* kt, int M, int H, int W, int D, double inv_base, double inv_step, double* stats);
+
 // ---- launch ------------------------------------------------------------------------------------------------------------
 template <class Cfg, bool NHWC, bool FULL>
 int launch_sweep_mfma_layout(const CostVolumeArgs& a, hipStream_t stream) {
   const long long groups_x = (a.W + Cfg::GW - 1) / Cfg::GW, groups_y = (a.H + Cfg::GH - 1) / Cfg::GH;
   const long long total = groups_y * groups_x * ((a.D + Cfg::PW * Cfg::CPW - 1) / (Cfg::PW * Cfg::CPW)) * a.B;
   if (total > (1LL << 30)) return DVMVS_EUNSUPPORTED;
+  const long long groups = groups_x * groups_y, wchunks = (a.D + Cfg::PW * Cfg::CPW - 1) / (Cfg::PW * Cfg::CPW);
+  if (Cfg::ORDER == 1 && a.B == 1 && groups % 8 == 0 && groups < 65536 && wchunks < 65536) {
+    const unsigned int reciprocal = static_cast<unsigned int>(0xffffffffu / static_cast<unsigned int>(groups_x)) + 1u;      // g / groups_x == mulhi(g, r) for g < 2^16
+    hipLaunchKernelGGL((sweep_mfma_kernel<Cfg, NHWC, FULL, true>), dim3(static_cast<unsigned int>(groups), static_cast<unsigned int>(wchunks)), dim3(64),
+                       Cfg::lds_bytes(a.M), stream, a, reciprocal);
+    return launch_status();
+  }
   const unsigned int grid = static_cast<unsigned int>((total + 7) / 8 * 8);
-  hipLaunchKernelGGL((sweep_mfma_kernel<Cfg, NHWC, FULL>), dim3(grid), dim3(64), Cfg::lds_bytes(a.M), stream, a);   // (< 48 KB of LDS: no attribute)
+  hipLaunchKernelGGL((sweep_mfma_kernel<Cfg, NHWC, FULL, false>), dim3(grid), dim3(64), Cfg::lds_bytes(a.M), stream, a, 0u);   // (< 48 KB of LDS: no attribute)
   return launch_status();
 }
 
@@ -458,6 +549,9 @@ bool sweep_mfma_supports(const CostVolumeArgs& a) {
 
 // the shipped configuration
 using MfmaSweepDefault = MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1>;
+void sweep_mfma_estimate_host(const float* Hm, const float* kt, int M, int H, int W, int D, double inv_base, double inv_step, double* stats) {
+  host_mfma_estimate<MfmaSweepDefault>(Hm, kt, M, H, W, D, inv_base, inv_step, stats);
+}
 int launch_sweep_mfma(const CostVolumeArgs& a, hipStream_t stream) {
   if (!sweep_mfma_supports(a)) return DVMVS_EUNSUPPORTED;
   return launch_sweep_mfma_cfg<MfmaSweepDefault>(a, stream);
@@ -491,6 +585,9 @@ int launch_sweep_mfma_tuning(int which, const CostVolumeArgs& a, hipStream_t str
     case 26: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 3, 0, 0, 1>>(a, stream);
     case 27: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 2, 0, 0, 1>>(a, stream);
     case 28: return launch_sweep_mfma_cfg<MfmaSweepConfig<8, 2, 128, 1, 4, 0, 0, 1>>(a, stream);
+    case 29: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 96, 1, 5, 0, 0, 1>>(a, stream);    // 20 waves per CU: 96 registers, 7.9 KB of table
+    case 30: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 112, 1, 5, 0, 0, 1>>(a, stream);
+    case 31: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 5, 0, 0, 1>>(a, stream);
     // ablations of configuration 0 (wrong results; where does the time go)
     case 16: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 1, 0, 1>>(a, stream);   // no operand loads
     case 17: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 2, 0, 1>>(a, stream);   // no MFMAs

@@ -114,6 +114,47 @@ __device__ inline void sweep_sample(const SweepRay& r, float kx, float ky, float
   *iy = fminf(fmaxf(py, -1.0f), s.Hf);
 }
 
+// N samples of one ray at once, stage by stage: per sample exactly the operations of sweep_sample (same rounding), issued so that N
+// independent dependency chains are in flight -- one sample's packed-arithmetic chain is ~20 dependent instructions, each of which the
+// compiler otherwise pads with a wait state (csrc/sweep_mfma.hip: a lane's four planes, two at a time: four at once cost 20 registers
+// more than the kernel has).  k[j] = K t / depth of sample j's plane.
+#pragma clang fp contract(off)
+template <int N>
+__device__ inline void sweep_samples(const SweepRay& r, const float4v* k, const SweepScale& s, float* ix, float* iy) {
+  float denom[N], rcp[N];
+  float2v n[N], q[N], t[N], g[N];
+  const float2v half = {s.wn, s.hn}, rhalf = {s.r_wn, s.r_hn};
+#pragma unroll
+  for (int j = 0; j < N; ++j) denom[j] = (r.Z0 + k[j].z) + 1e-8f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) rcp[j] = __builtin_amdgcn_rcpf(denom[j]);
+#pragma unroll
+  for (int j = 0; j < N; ++j) rcp[j] = fmaf(fmaf(-denom[j], rcp[j], 1.0f), rcp[j], rcp[j]);      // refined_rcp
+#pragma unroll
+  for (int j = 0; j < N; ++j) n[j] = float2v{r.X0, r.Y0} + float2v{k[j].x, k[j].y};
+#pragma unroll
+  for (int j = 0; j < N; ++j) q[j] = n[j] * float2v{rcp[j], rcp[j]};
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+    for (int j = 0; j < N; ++j) q[j] = fma2(fma2(-float2v{denom[j], denom[j]}, q[j], n[j]), float2v{rcp[j], rcp[j]}, q[j]);
+#pragma unroll
+  for (int j = 0; j < N; ++j) t[j] = q[j] - half;
+#pragma unroll
+  for (int j = 0; j < N; ++j) g[j] = t[j] * rhalf;
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+    for (int j = 0; j < N; ++j) g[j] = fma2(fma2(-half, g[j], t[j]), rhalf, g[j]);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const float2v pos = ((g[j] + 1.0f) * 0.5f) * float2v{s.Wm1, s.Hm1};
+    ix[j] = fminf(fmaxf(pos.x, -1.0f), s.Wf);
+    iy[j] = fminf(fmaxf(pos.y, -1.0f), s.Hf);
+  }
+}
+#pragma clang fp contract(fast)
+
 // ---- gather path (no staging): taps straight from global memory ----------------------------------------------------------
 // One plane of one measurement frame for this thread's pixel: sum_c ref[c] * warped[c].  Used for runs of planes whose
 // footprint cannot be staged: by sweep_spill_kernel (second pass) and, when the caller gave no spill workspace, inline.

@@ -62,6 +62,8 @@ _MAX_MEAS = 8            # DVMVS_MAX_MEASUREMENTS of the C ABI
 # never in flight twice, and the stall is gone at the same steady-state rate (3 / 2 / 1 slots: 2 / 1 / 0 stalls in 20 steps; 100 steps:
 # 1 239 frames/s): the host's 0.75 ms per step still overlap the device's 0.8 ms frame completely.
 _STAGING_SLOTS = int(os.environ.get("DVMVS_STAGING_SLOTS", "1"))
+_GRAPH_QUEUE_FILLERS = int(os.environ.get("DVMVS_GRAPH_QUEUE_FILLERS", "1"))
+_SWEEP_FIRST = os.environ.get("DVMVS_SWEEP_FIRST", "0") == "1"      # experiments: the sweep before / after the side-stream fork (None: see _frame_body_direct)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -427,6 +429,7 @@ class DepthEngine:
         self._planner, self._planned, self._param_host_ahead = None, None, None      # see plan_ahead
         self.plan_frames_ahead = os.environ.get("DVMVS_PLAN_AHEAD", "1") != "0"
         self.planned_frames_used = 0
+        self._filler_buffers, self._filler_graphs = None, []
         self.warm_captured_graphs = os.environ.get("DVMVS_WARM_GRAPHS", "1") != "0"
         # launches of every newly captured graph on throw-away results: the runtime finishes setting a graph up over its first launches (a
         # 5-6 ms device stall was still seen at a graph's third launch, i.e. a few steps into a short run's timed region, with one)
@@ -446,6 +449,13 @@ class DepthEngine:
         self.sweep_variant_counts = {}     # frames per sweep configuration (dvmvs_cost_volume_fwd's variant) since construction
         # host-planned work list for the sweep: only where the matrices exist on the host, and one plan per launch (one sequence)
         self.sweep_work_list = bool(_utils.SWEEP_WORK_LIST and self.pose_algebra == "reference" and _utils.COST_VOLUME_VARIANT in (0, 2, 3, 4, 5))
+        # Round 5: the correlate-then-interpolate sweep (variant 6, csrc/sweep_mfma.hip) takes the keyframe pairs on which its estimated work is
+        # small (dvmvs_sweep_plan6: 173 of the sample scene's 285 pairs, 29 us against 33 on the easy ones, 36.5 against 42.0 us over all of them);
+        # it reads one 128-byte line per measurement cell, so the engine then keeps its measurement maps -- the feature cache and the per-frame
+        # buffers -- channels-last (one transposing launch per keyframe in place of the cache's contiguous copy).  DVMVS_SWEEP_MFMA=0: round 4's
+        # all-tiled engine on NCHW maps.
+        self.sweep_mfma = bool(self.direct and self.sweep_work_list and _utils.COST_VOLUME_VARIANT == 0 and os.environ.get("DVMVS_SWEEP_MFMA", "1") != "0")
+        self._tiled_variants = (2, 3, 4, 5, 6) if self.sweep_mfma else (2, 3, 4, 5)
         self.reset()
 
     def conv_plan_report(self):
@@ -533,13 +543,17 @@ class DepthEngine:
         ``clone()`` per keyframe made the first ``cache_size`` frames of every run pay a device allocation each (hipMalloc synchronises:
         a 20-step run measured 1.7 ms per frame where 100 steps measured 1.39)."""
         if self.cache_features and frame_id is not None:
-            if not half.is_contiguous():      # (channels-last engines keep their maps as they are: the sweep reads them as NHWC)
+            if not half.is_contiguous() and not self.sweep_mfma:      # (channels-last engines keep their maps as they are: the sweep reads them as NHWC)
                 self._feature_cache[frame_id] = half
                 while len(self._feature_cache) > self.cache_size:
                     self._feature_slot.pop(self._feature_cache.popitem(last=False)[0], None)
                 return
             if self._feature_pool is None or tuple(self._feature_pool.shape[1:]) != tuple(half.shape):
-                self._feature_pool = torch.empty((self.cache_size + 1,) + tuple(half.shape), device=self.device, dtype=torch.float32)
+                if self.sweep_mfma and half.dim() == 4:      # channels-last entries (what the sweep reads): [n, S, H, W, C] storage, [n, S, C, H, W] view
+                    S_, C_, H_, W_ = half.shape
+                    self._feature_pool = torch.empty((self.cache_size + 1, S_, H_, W_, C_), device=self.device, dtype=torch.float32).permute(0, 1, 4, 2, 3)
+                else:
+                    self._feature_pool = torch.empty((self.cache_size + 1,) + tuple(half.shape), device=self.device, dtype=torch.float32)
                 self._feature_free = list(range(self.cache_size, -1, -1))
                 self._feature_cache.clear()
                 self._feature_slot = {}
@@ -551,8 +565,17 @@ class DepthEngine:
                 slot = self._feature_pool[self._feature_free[-1]]
                 self._feature_slot[frame_id] = self._feature_free.pop()
             if slot.data_ptr() != half.data_ptr():
-                slot.copy_(half)
+                self._store_measurement_map(slot, half)
             self._feature_cache[frame_id] = slot
+
+    @staticmethod
+    def _store_measurement_map(dst, src):
+        """``dst`` = ``src``; an NCHW map into a channels-last buffer through the transposing kernel (torch's strided copy writes 4 bytes per
+        128-byte line)."""
+        if src.stride() == dst.stride() or not (src.is_contiguous() and dst.is_contiguous(memory_format=torch.channels_last) and src.shape[1] % 4 == 0 and src.shape[1] <= 64):
+            dst.copy_(src)      # (the frame path: channels-last into channels-last)
+        else:
+            _ops.nchw_to_nhwc_into(src, dst)
 
     def _allocate_static(self, n_meas):
         d, H, W, S = self.device, self.height, self.width, self.sequences
@@ -591,7 +614,9 @@ class DepthEngine:
                 # buffer that holds the image; frames alternate between the two sets
                 # and, for the deeper look-ahead (the next frame's sweep + encoder as well), of everything the encoder writes
                 # ... and of the 8x10 depth estimate: a frame's splat zero-fills the OTHER set's buffer on the way (no clear launch)
-                keys = ("enc_cat", "dec_cat", "full_in", "lstm_cat", "estimate")
+                if self.sweep_mfma:      # a keyframe's half-resolution features once more, channels-last: what the feature cache keeps (written in-graph)
+                    direct["ref_half_nhwc"] = z(1, 32, H // 2, W // 2).contiguous(memory_format=torch.channels_last)
+                keys = ("enc_cat", "dec_cat", "full_in", "lstm_cat", "estimate") + (("ref_half_nhwc",) if self.sweep_mfma else ())
                 clone = lambda v: [torch.zeros_like(t) for t in v] if isinstance(v, list) else torch.zeros_like(v)
                 direct["sets"] = [dict({k: direct[k] for k in keys}, index=0, meas_feat=[]),
                                   dict({k: clone(direct[k]) for k in keys}, index=1, meas_feat=[])]
@@ -609,13 +634,14 @@ class DepthEngine:
                                 c=z(S, 512, H // 32, W // 32), meas_feat=[], ref_half=ref_half, depth=depth)
             self._ring = [(torch.zeros(total, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(_STAGING_SLOTS)]
             self._param_host = torch.zeros(total, dtype=torch.float32)      # host mirror of the block: a step rewrites only its own regions
+        zm = (lambda: z(S, 32, H // 2, W // 2).contiguous(memory_format=torch.channels_last)) if self.sweep_mfma else (lambda: z(S, 32, H // 2, W // 2))
         while len(self._static["meas_feat"]) < n_meas:
-            self._static["meas_feat"].append(z(S, 32, H // 2, W // 2))
+            self._static["meas_feat"].append(zm())
         if self.direct:
             sets = self._direct_buffers["sets"]
             sets[0]["meas_feat"] = self._static["meas_feat"]
             while len(sets[1]["meas_feat"]) < n_meas:
-                sets[1]["meas_feat"].append(z(S, 32, H // 2, W // 2))
+                sets[1]["meas_feat"].append(zm())
 
     def _sweep_views(self, n_meas, index=0):
         """Hm [S,n_meas,9] and kt [S,n_meas,3] views of the parameter buffer (contiguous prefixes of their regions) of buffer set ``index``."""
@@ -692,7 +718,7 @@ class DepthEngine:
             if self.sweep_work_list:
                 o, n = self._param_offsets["sweep_items" + suffix]
                 variant = _ops.sweep_plan_host(Hm, kt, self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth,
-                                               variant if variant in (2, 3, 4, 5) else 0, mirror.view(torch.int32)[o:o + n])
+                                               variant if variant in (2, 3, 4, 5) else 0, mirror.view(torch.int32)[o:o + n], allow_mfma=self.sweep_mfma)
             elif variant == 0:
                 variant = _utils.sweep_variant((Hm, kt), self.height // 2, self.width // 2, self.n_depth_levels, self.min_depth, self.max_depth)
             return variant
@@ -816,11 +842,11 @@ class DepthEngine:
         sets = self._direct_buffers["sets"]
         cur, nxt = sets[parity], sets[1 - parity]
 
-        def own():
+        def own(sweep_done=False):
             if have < 1:
                 self._reference_features_direct(cur)
             if have < 2:
-                self._sweep_encoder_direct(cur, n_meas, sweep_variant)
+                self._sweep_encoder_direct(cur, n_meas, sweep_variant, sweep_done=sweep_done)
             self._lstm_decoder_direct(cur, has_previous)
 
         def ahead():
@@ -837,15 +863,27 @@ class DepthEngine:
             ahead()
         else:
             main = torch.cuda.current_stream(self.device)
+            # This frame's sweep goes first, alone on the chip, when its features are already there (the steady state of look-ahead level 1):
+            # it fills every CU for its 30 us, and next to the side stream's kernels the workgroups of its second round queue behind them --
+            # the frame lost 60 us with the MFMA sweep (5 120 one-wave workgroups) that way, while the side stream's 0.4 ms of small
+            # kernels overlap the encoder, ConvLSTM and decoder (0.63 ms) just as well when they start 30 us later.
+            sweep_first = have == 1 and _SWEEP_FIRST
+            if sweep_first:
+                self._sweep_direct(cur, n_meas, sweep_variant)
             self._side_stream.wait_stream(main)
             with torch.cuda.stream(self._side_stream):
                 ahead()
-            own()
+            own(sweep_done=sweep_first)
             main.wait_stream(self._side_stream)
 
     def _reference_features_direct(self, buffers):
         """MnasNet taps -> FPN of the reference image of a buffer set, each used output into the front of its encoder concatenation buffer."""
         self._fpn_direct(self.fe(buffers["full_in"][:, 33:36]), [c[:, :32] for c in buffers["enc_cat"]])
+        if self.sweep_mfma:
+            # the copy a later frame's sweep reads as measurement map (one 128-byte line per cell): made here, inside the frame graph, so that
+            # the feature cache's per-keyframe copy stays a plain device copy on the host's side (an eager transposing launch per step cost the
+            # host, which is as busy as the device at this frame rate, 45 us)
+            _ops.nchw_to_nhwc_into(buffers["enc_cat"][0][:, :32], buffers["ref_half_nhwc"])
 
     def _after_features_direct(self, n_meas, has_previous, sweep_variant=0, buffers=None):
         """Everything of a frame behind the feature extraction: sweep, encoder, re-projection, ConvLSTM, decoder."""
@@ -853,17 +891,23 @@ class DepthEngine:
         self._sweep_encoder_direct(buffers, n_meas, sweep_variant)
         self._lstm_decoder_direct(buffers, has_previous)
 
-    def _sweep_encoder_direct(self, buffers, n_meas, sweep_variant=0):
-        """Plane sweep + cost-volume encoder of the frame whose features are in ``buffers``: reads that set's measurement features and
-        sweep parameters, writes its skip connections (into the decoder's concatenation buffers) and its bottleneck map.  Depends on
-        nothing the PREVIOUS frame computes -- no recurrent state, no previous depth -- which is what lets it run a frame ahead."""
+    def _sweep_direct(self, buffers, n_meas, sweep_variant=0):
+        """Plane sweep of the frame whose features are in ``buffers``, into the cost-volume slice of its first encoder concatenation buffer."""
         s = self._static
-        enc_cat, dec_cat = buffers["enc_cat"], buffers["dec_cat"]
+        enc_cat = buffers["enc_cat"]
         Hm, kt = self._sweep_views(n_meas, buffers["index"])
         if self.pose_algebra == "exact":
             Hm, kt = _ops.sweep_matrices(s["pose"], s["meas_pose"][:n_meas], s["half_K"])
         _ops.cost_volume_into(enc_cat[0][:, :32], buffers["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, enc_cat[0][:, 32:], sweep_variant,
                               self._sweep_items(buffers["index"]))
+
+    def _sweep_encoder_direct(self, buffers, n_meas, sweep_variant=0, sweep_done=False):
+        """Plane sweep + cost-volume encoder of the frame whose features are in ``buffers``: reads that set's measurement features and
+        sweep parameters, writes its skip connections (into the decoder's concatenation buffers) and its bottleneck map.  Depends on
+        nothing the PREVIOUS frame computes -- no recurrent state, no previous depth -- which is what lets it run a frame ahead."""
+        enc_cat, dec_cat = buffers["enc_cat"], buffers["dec_cat"]
+        if not sweep_done:
+            self._sweep_direct(buffers, n_meas, sweep_variant)
         # encoder: aggregator output = skip connection, written where the decoder will read it
         enc, dec = self.enc, self.dec
         x = None
@@ -1019,7 +1063,7 @@ class DepthEngine:
                     all(torch.equal(a, _pose_algebra.to_host(b).reshape(-1, 4, 4)) for a, b in zip(ready["measurement_poses"], measurement_poses)):
                 have = 2
         if have >= 1 and self.cache_features:
-            self._remember(frame_id, cur["enc_cat"][0][:, :32])     # (the next frame may use this one as a measurement frame)
+            self._remember(frame_id, cur["ref_half_nhwc"] if self.sweep_mfma else cur["enc_cat"][0][:, :32])     # (the next frame may use this one as a measurement frame)
 
         # ---- this frame's measurement features (not needed when its sweep already ran) ----
         if have < 2:
@@ -1037,7 +1081,7 @@ class DepthEngine:
                 else:
                     half = self._features(img)[0].contiguous()
                     fresh.append((mid, half))
-                target[i].copy_(half)
+                self._store_measurement_map(target[i], half)
             for mid, half in fresh:
                 self._remember(mid, half)
 
@@ -1105,7 +1149,7 @@ class DepthEngine:
                 t_capture = time.perf_counter()
                 self._graphs[key] = self._capture(body)
                 if give:
-                    tiled = (2, 3, 4, 5)      # the sweep's configurations x (two passes, one pass): whichever a later geometry asks for
+                    tiled = self._tiled_variants      # the sweep's configurations x (two passes, one pass) [+ the MFMA sweep]: whichever a later geometry asks for
                     choices = tiled if next_variant in tiled or sweep_variant in tiled else (sweep_variant,)
                     for par in (0, 1):
                         for v in (choices if give < 2 else (0,)):
@@ -1113,9 +1157,9 @@ class DepthEngine:
                                 k = graph_key(par, give, give, v, vn)
                                 if k not in self._graphs:
                                     self._graphs[k] = self._capture((n_meas, kind[1], v, par, give, give, n_meas_next, vn))
-                elif sweep_variant in (2, 3, 4, 5) and have < 2:
+                elif sweep_variant in self._tiled_variants and have < 2:
                     for par in ((0, 1) if self.direct else (0,)):
-                        for v in (2, 3, 4, 5):
+                        for v in self._tiled_variants:
                             k = graph_key(par, have, 0, v, 0)
                             if k not in self._graphs:
                                 self._graphs[k] = self._capture((n_meas, kind[1], v, par, have, 0, 0, 0))
@@ -1164,7 +1208,7 @@ class DepthEngine:
                                             measurement_poses=[to_host(p).reshape(-1, 4, 4).clone() for p in next_measurement_poses])
             self._parity = 1 - parity
         if self.cache_features and frame_id is not None and have < 1:
-            self._remember(frame_id, s["ref_half"])
+            self._remember(frame_id, cur["ref_half_nhwc"] if (self.direct and self.sweep_mfma) else s["ref_half"])
         mark("done")
         return s["depth"]
 
@@ -1223,4 +1267,21 @@ class DepthEngine:
             graph.enable_debug_mode()
         with torch.cuda.graph(graph):
             self._frame_body(*key)
+        if self.direct and key[5] and key[4] >= key[5]:      # a body with a second branch (see _frame_body_direct)
+            for _ in range(_GRAPH_QUEUE_FILLERS):
+                self._capture_queue_filler()
         return graph
+
+    def _capture_queue_filler(self):
+        """A two-branch graph of two tiny kernels, instantiated and never launched (see _GRAPH_QUEUE_FILLERS)."""
+        if self._filler_buffers is None:
+            self._filler_buffers = torch.zeros(2, 64, device=self.device)
+        filler = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(filler):
+            main = torch.cuda.current_stream(self.device)
+            self._side_stream.wait_stream(main)
+            with torch.cuda.stream(self._side_stream):
+                self._filler_buffers[0].add_(1.0)
+            self._filler_buffers[1].add_(1.0)
+            main.wait_stream(self._side_stream)
+        self._filler_graphs.append(filler)

@@ -106,7 +106,8 @@ def sweep_work_list_host(Hm: Tensor, kt: Tensor, H: int, W: int, D: int, min_dep
     return out
 
 
-def sweep_plan_host(Hm: Tensor, kt: Tensor, H: int, W: int, D: int, min_depth: float, max_depth: float, variant: int, out: Tensor) -> int:
+def sweep_plan_host(Hm: Tensor, kt: Tensor, H: int, W: int, D: int, min_depth: float, max_depth: float, variant: int, out: Tensor,
+                    allow_mfma: bool = False) -> int:
     """Configuration choice (``variant`` 0; or 2 / 3 as given) and work list in one walk (dvmvs_sweep_plan): fills ``out`` (an int32 host
     tensor of ``sweep_work_list_words``) and returns the variant to launch with."""
     Hm, kt = Hm.contiguous(), kt.contiguous()
@@ -114,8 +115,13 @@ def sweep_plan_host(Hm: Tensor, kt: Tensor, H: int, W: int, D: int, min_depth: f
         raise ValueError("sweep_plan_host needs the float32 HOST copies of the sweep matrices")
     if out.device.type != "cpu" or out.dtype != torch.int32 or not out.is_contiguous() or out.numel() < sweep_work_list_words(Hm.shape[0], H, W, D):
         raise ValueError("work list buffer must be a contiguous int32 host tensor of sweep_work_list_words entries")
-    chosen = _capi.lib().dvmvs_sweep_plan(Hm.data_ptr(), kt.data_ptr(), Hm.shape[0], Hm.shape[1], int(H), int(W), int(D), float(min_depth),
-                                          float(max_depth), {4: 2, 5: 3}.get(int(variant), int(variant)), out.data_ptr(), out.numel() * 4)
+    if allow_mfma and int(variant) == 0:
+        # ... with variant 6 (the correlate-then-interpolate sweep) as a candidate: for callers with 32-channel channels-last measurement maps
+        chosen = _capi.lib().dvmvs_sweep_plan6(Hm.data_ptr(), kt.data_ptr(), Hm.shape[0], Hm.shape[1], int(H), int(W), int(D), float(min_depth),
+                                               float(max_depth), out.data_ptr(), out.numel() * 4)
+    else:
+        chosen = _capi.lib().dvmvs_sweep_plan(Hm.data_ptr(), kt.data_ptr(), Hm.shape[0], Hm.shape[1], int(H), int(W), int(D), float(min_depth),
+                                              float(max_depth), {4: 2, 5: 3}.get(int(variant), int(variant)), out.data_ptr(), out.numel() * 4)
     if chosen < 0:
         _capi.check(chosen, "dvmvs_sweep_plan")
     return chosen
@@ -889,6 +895,18 @@ def depth_reproject_estimate_into(transformation: Tensor, previous_depth: Tensor
     return estimate
 
 
+def nchw_to_nhwc_into(src: Tensor, dst: Tensor) -> Tensor:
+    """``dst`` (a channels-last [B,C,H,W] tensor) = ``src`` (contiguous NCHW), one HIP launch (dvmvs_nchw_to_nhwc: C <= 64, a multiple of 4)."""
+    _dev_f32("nchw_to_nhwc_into", src, dst)
+    B, C, H, W = src.shape
+    if tuple(dst.shape) != (B, C, H, W) or not src.is_contiguous() or not dst.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("dvmvs::nchw_to_nhwc_into: expected a contiguous NCHW source and a channels-last destination of the same shape")
+    with torch.cuda.device(src.device):
+        rc = _capi.lib().dvmvs_nchw_to_nhwc(_ptr(src), _ptr(dst), B, C, H, W, _stream(src))
+    _capi.check(rc, "dvmvs_nchw_to_nhwc")
+    return dst
+
+
 def cost_volume_into(image1: Tensor, image2s, Hm: Tensor, kt: Tensor, min_depth: float, max_depth: float, dst: Tensor, variant: int = 0,
                      work_list: Optional[Tensor] = None) -> Tensor:
     """Dot-product cost volume written into ``dst`` [B,D,H,W] (contiguous: for B == 1 a channel slice of a larger buffer is)."""
@@ -896,14 +914,15 @@ def cost_volume_into(image1: Tensor, image2s, Hm: Tensor, kt: Tensor, min_depth:
     B, C, H, W = image1.shape
     M, D = len(image2s), dst.shape[1]
     _check_sweep_matrices("cost_volume_into", Hm, kt, B, M)
-    if not (image1.is_contiguous() and dst.is_contiguous() and tuple(dst.shape) == (B, D, H, W) and all(t.is_contiguous() for t in image2s)):
-        raise ValueError("dvmvs::cost_volume_into: expected contiguous NCHW tensors")
+    nhwc = C > 1 and all(t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous() for t in image2s)
+    if not (image1.is_contiguous() and dst.is_contiguous() and tuple(dst.shape) == (B, D, H, W) and (nhwc or all(t.is_contiguous() for t in image2s))):
+        raise ValueError("dvmvs::cost_volume_into: expected contiguous NCHW tensors (measurement maps: all NCHW or all channels-last)")
     workspace, ws_bytes = sweep_workspace(image1.device, B, M, H, W, D) if COST_VOLUME_TWO_PASS else (None, 0)
     items = _work_list_ptr(work_list, image1, B, H, W, D)
     with torch.cuda.device(image1.device):
         rc = _capi.lib().dvmvs_cost_volume_planned_fwd(_ptr(image1), _capi.pointer_array([_ptr(t) for t in image2s]), _ptr(Hm.contiguous()),
                                                        _ptr(kt.contiguous()), _ptr(dst), B, M, C, H, W, D, float(min_depth), float(max_depth), 1, int(variant),
-                                                       _capi.LAYOUT_NCHW, _ptr(workspace) if workspace is not None else None, ws_bytes, items, _stream(image1))
+                                                       _capi.LAYOUT_NHWC if nhwc else _capi.LAYOUT_NCHW, _ptr(workspace) if workspace is not None else None, ws_bytes, items, _stream(image1))
     if rc != 0 and workspace is not None:
         drop_sweep_workspace(image1.device, B, M, H, W, D)
     _capi.check(rc, "dvmvs_cost_volume_planned_fwd")

@@ -152,6 +152,20 @@ size_t dvmvs_sweep_work_list_bytes(int B, int H, int W, int D);
  * (2 / 3, or 4 / 5 = the same configuration without a second pass when the plan queues nothing for it; negative on error). */
 int dvmvs_sweep_plan(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
                      int variant, unsigned int* work_list_host, size_t work_list_bytes);
+/* ABI 6: HOST-side work estimate of variant 6 (the correlate-then-interpolate sweep) for batch item 0 of these matrices, no HIP call:
+ * stats[4] = mean 16-cell tiles per wave, mean passes per wave, mean strips beyond the first per wave, fraction of waves whose footprint
+ * cannot be bounded from its corners (behind-camera / non-finite); sampled on every eighth pixel group.  dvmvs_sweep_plan6 uses it. */
+int dvmvs_sweep_mfma_estimate(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
+                              double* stats);
+/* dvmvs_sweep_plan with variant 6 as a candidate: the tiled sweep's plan as dvmvs_sweep_plan makes it (work list filled in), then the
+ * correlate-then-interpolate sweep takes the pair when its estimated work is small -- no footprint that cannot be bounded, less than one
+ * extra strip per wave, fewer than 14 (easy pairs: nothing queued, <= 3 staged runs per workgroup) / 18 (others) tiles per wave: the rule
+ * that separates the pairs on which it is faster on the sample scene's 285 keyframe pairs (profiles/r05_sweep_selection.md).  Returns 6 or
+ * the tiled variant.  For callers whose measurement maps are channels-last (what variant 6 is fast with) and have 32 channels. */
+int dvmvs_sweep_plan6(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
+                      unsigned int* work_list_host, size_t work_list_bytes);
+/* [B,C,H,W] -> [B,H,W,C] (C <= 64, a multiple of 4), one launch: how a keyframe's features enter a channels-last feature cache. */
+int dvmvs_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, dvmvs_stream_t stream);
 int dvmvs_sweep_work_list(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
                           double min_depth, double max_depth, int configuration, unsigned int* work_list_host, size_t work_list_bytes);
 int dvmvs_cost_volume_planned_fwd(const float* image1, const float* const* image2s, const float* Hm, const float* kt,
