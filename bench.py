@@ -347,18 +347,36 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets, force_variant=No
     return sum(per_geometry) / len(per_geometry), algorithmic_bytes, per_geometry, variants
 
 
-def issue_roofline(kernel_s):
-    """Issue-time accounting of the engine's sweep kernel from the newest committed PMC profile (profiles/r*_sweep_issue_pmc.json)."""
+def finite_or_null(value):
+    """NaN / infinity -> null (legs that were switched off leave NaNs behind; strict JSON has no literal for them)."""
+    if isinstance(value, float):
+        return value if np.isfinite(value) else None
+    if isinstance(value, dict):
+        return {k: finite_or_null(v) for k, v in value.items()}
+    if isinstance(value, (list, tuple)):
+        return [finite_or_null(v) for v in value]
+    return value
+
+
+def issue_roofline(per_geometry, variants):
+    """Issue-time accounting of the engine's sweep kernels from the newest committed PMC profile (profiles/r*_sweep_issue_pmc.json, counted on
+    index line 0): per kernel the instruction-issue time per SIMD against its mean duration on the timed steps that ran it; top level = the
+    kernel most timed steps ran."""
     try:
         import glob
         path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sweep_issue_pmc.json")))[-1]
         pmc = json.load(open(path))
-        name, k = next((n, v) for n, v in pmc["kernels"].items() if n.startswith("sweep_tiled_kernel"))
-        busy = k["issue_busy_us_per_simd"]
-        return {"bound": "instruction_issue", "kernel": name, "issue_busy_us_per_simd": busy, "kernel_us": kernel_s * 1e6,
-                "frac": busy / (kernel_s * 1e6), "unit": "us of instruction issue per SIMD (SQ_ACTIVE_INST_ANY x 4 cycles / 1024 SIMDs / clock)",
-                "clock_ghz": pmc["clock_ghz_during_kernel"], "source": os.path.relpath(path, ROOT),
-                "other_kernels": {n: v["issue_busy_us_per_simd"] for n, v in pmc["kernels"].items() if n != name}}
+        kernels = {}
+        for label, mine in (("sweep_mfma_kernel", lambda v: v == 6), ("sweep_tiled_kernel", lambda v: v != 6)):
+            name, k = next((n, v) for n, v in pmc["kernels"].items() if n.startswith(label))
+            ts = [t for t, v in zip(per_geometry, variants) if mine(v)]
+            mean_us = 1e6 * sum(ts) / len(ts) if ts else None
+            kernels[label] = {"profiled_as": name, "issue_busy_us_per_simd": k["issue_busy_us_per_simd"], "timed_steps": len(ts),
+                              "kernel_us": mean_us, "frac": k["issue_busy_us_per_simd"] / mean_us if mean_us else None}
+        top = max(kernels, key=lambda n: kernels[n]["timed_steps"])
+        return {"bound": "instruction_issue", "kernel": top, **{k: kernels[top][k] for k in ("issue_busy_us_per_simd", "kernel_us", "frac", "timed_steps")},
+                "unit": "us of instruction issue per SIMD (SQ_ACTIVE_INST_ANY x 4 cycles / 1024 SIMDs / clock)",
+                "clock_ghz": pmc["clock_ghz_during_kernel"], "source": os.path.relpath(path, ROOT), "kernels": kernels}
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"}
 
@@ -808,8 +826,8 @@ def main():
             all_pairs = {"pairs": len(a_per), "kernel_us": a_s * 1e6, "frac": alg_bytes / a_s / 1e9 / HBM_PEAK_GBPS, "worst_us": max(a_per) * 1e6,
                          "worst_index_line": all_lines[int(np.argmax(a_per))], "p90_us": float(np.percentile(a_per, 90)) * 1e6,
                          "sweep_variants": {str(v): a_var.count(v) for v in sorted(set(a_var))}}
-            # the correlate-then-interpolate sweep on the fp32 matrix cores (variant 6, csrc/sweep_mfma.hip: built and parity-tested this
-            # round, NOT the engine's choice -- DESIGN.md section 4.1b says why) on the same geometries, same harness
+            # the correlate-then-interpolate sweep on the fp32 matrix cores (variant 6, csrc/sweep_mfma.hip) FORCED on every geometry, same
+            # harness (the engine takes it where dvmvs_sweep_plan6's estimate says so: roofline.sweep_variants)
             m_s, _, m_per, _ = measure_cost_volume_kernel(engine, M, args.kernel_reps, timed, force_variant=6)
             ma_s, _, ma_per, _ = measure_cost_volume_kernel(engine, M, reps_all, all_sets, force_variant=6, rounds=2)
             mfma_variant = {"kernel": "sweep_mfma_kernel (variant 6: tap dots per measurement cell on v_mfma_f32_16x16x4_f32, table look-ups per plane)",
@@ -825,7 +843,7 @@ def main():
             import glob
             import hashlib
             digest = hashlib.sha256(b"".join(open(os.path.join(ROOT, "deep-video-mvs_amd", "csrc", f), "rb").read()
-                                             for f in ("sweep_tiled.hip", "cost_volume.hip", "plane_sweep.h", "sweep_sample.h"))).hexdigest()
+                                             for f in ("sweep_tiled.hip", "sweep_mfma.hip", "cost_volume.hip", "plane_sweep.h", "sweep_sample.h"))).hexdigest()
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cost_volume_pmc.json")), reverse=True):
                 pmc = json.load(open(path))
                 if pmc.get("shape") == [1, M, 32, 128, 160, 64] and pmc.get("kernel_sources_sha256") == digest:
@@ -837,6 +855,9 @@ def main():
         useful_flop = 128 * 160 * 64 * M * (4 * 32 + 4) * 2
         valu_tflops = useful_flop / kernel_s / 1e12
         lds_bytes = 128 * 160 * 64 * M * 4 * 32 * 4
+        # (the LDS accounting below is the TILED formulation's -- the MFMA sweep reads 4 dot products per sample, not 4 x 32 channels: the steps that ran it are left out)
+        tiled_times = [t for t, v in zip(per_geometry, variants) if v != 6]
+        tiled_s = sum(tiled_times) / len(tiled_times) if tiled_times else float("nan")
         other_kernels = None if args.no_roofline_leg else measure_small_kernels(engine)
         launches_per_frame = {}
         try:     # kernel nodes of the captured frame graph (what one replay launches), where the runtime can dump a graph
@@ -902,13 +923,14 @@ def main():
             # the pipe this formulation is actually bound by: 4 taps x 32 channels x 4 B from LDS per (pixel, plane, frame).  "peak" is
             # the ds_read_b128 rate of the chip; "pattern_floor_us" the measured floor of the kernel's own inner pattern (bank conflicts
             # of the tap addresses and the packed FMAs between the reads included)
-            "roofline_lds": {"bound": "lds", "achieved": lds_bytes / kernel_s / 1e12, "peak": LDS_PEAK_TBPS, "unit": "TB/s",
-                             "frac": lds_bytes / kernel_s / 1e12 / LDS_PEAK_TBPS, "lds_bytes": lds_bytes,
-                             "pattern_floor_us": SWEEP_LDS_PATTERN_FLOOR_US, "frac_of_pattern_floor": SWEEP_LDS_PATTERN_FLOOR_US / (kernel_s * 1e6)},
+            "roofline_lds": None if not tiled_times else {
+                "bound": "lds", "kernel": f"sweep_tiled_kernel ({len(tiled_times)} of the {len(per_geometry)} timed steps ran it)", "achieved": lds_bytes / tiled_s / 1e12,
+                "peak": LDS_PEAK_TBPS, "unit": "TB/s", "frac": lds_bytes / tiled_s / 1e12 / LDS_PEAK_TBPS, "lds_bytes": lds_bytes, "kernel_us": tiled_s * 1e6,
+                "pattern_floor_us": SWEEP_LDS_PATTERN_FLOOR_US, "frac_of_pattern_floor": SWEEP_LDS_PATTERN_FLOOR_US / (tiled_s * 1e6)},
             # what the launch's duration is made of (round 5): instruction ISSUE.  Summed over a SIMD's waves, the cycles with an instruction
             # issuing / executing (SQ_ACTIVE_INST_ANY of the committed PMC profile, index line 0) add up to the waves' lifetime in both sweep
             # kernels: neither HBM nor LDS bandwidth nor the matrix pipe but the instruction count bounds them
-            "roofline_issue": issue_roofline(kernel_s),
+            "roofline_issue": issue_roofline(per_geometry, variants) if per_geometry else None,
             "roofline_mfma_variant": mfma_variant,
             "roofline_other": other_kernels,
             # what the engine's warm-up costs (outside the timed steps): eager first frames, graph capture, first launches of the graphs
@@ -979,7 +1001,7 @@ def main():
             result["cpu_baseline"] = None
         if args.stage_times:
             print(f"[bench] final depth mean {depth_mean:.4f}", file=sys.stderr)
-        print(json.dumps(result))
+        print(json.dumps(finite_or_null(result)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

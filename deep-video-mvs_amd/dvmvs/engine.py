@@ -62,8 +62,15 @@ _MAX_MEAS = 8            # DVMVS_MAX_MEASUREMENTS of the C ABI
 # never in flight twice, and the stall is gone at the same steady-state rate (3 / 2 / 1 slots: 2 / 1 / 0 stalls in 20 steps; 100 steps:
 # 1 239 frames/s): the host's 0.75 ms per step still overlap the device's 0.8 ms frame completely.
 _STAGING_SLOTS = int(os.environ.get("DVMVS_STAGING_SLOTS", "1"))
+# hipGraphInstantiate gives a graph with two branches an internal stream for the second one, and the hardware queue behind that stream
+# alternates from one instantiation to the next (two queues, ROCm 7.2).  Consecutive frames replay the graphs of the two buffer sets: when
+# their second branches sit on DIFFERENT queues every frame is 50 us slower (0.855 against 0.805 ms at look-ahead 1, whichever sweep kernel
+# runs) -- and which case a run gets used to depend on how many graphs were captured between the two: even (4 sweep configurations per
+# buffer set) fast, odd (5, with the MFMA sweep) slow.  So after every two-branch capture this many two-kernel filler graphs are
+# instantiated (kept, never launched): all frame graphs end up on the same queue.  DESIGN.md section 4.6; 0 = the runtime's own order.
 _GRAPH_QUEUE_FILLERS = int(os.environ.get("DVMVS_GRAPH_QUEUE_FILLERS", "1"))
-_SWEEP_FIRST = os.environ.get("DVMVS_SWEEP_FIRST", "0") == "1"      # experiments: the sweep before / after the side-stream fork (None: see _frame_body_direct)
+# experiments: "1" = a frame's sweep runs before the side-stream fork instead of next to the side stream's kernels (see _frame_body_direct)
+_SWEEP_FIRST = os.environ.get("DVMVS_SWEEP_FIRST", "0") == "1"
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -863,10 +870,8 @@ class DepthEngine:
             ahead()
         else:
             main = torch.cuda.current_stream(self.device)
-            # This frame's sweep goes first, alone on the chip, when its features are already there (the steady state of look-ahead level 1):
-            # it fills every CU for its 30 us, and next to the side stream's kernels the workgroups of its second round queue behind them --
-            # the frame lost 60 us with the MFMA sweep (5 120 one-wave workgroups) that way, while the side stream's 0.4 ms of small
-            # kernels overlap the encoder, ConvLSTM and decoder (0.63 ms) just as well when they start 30 us later.
+            # (DVMVS_SWEEP_FIRST=1: this frame's sweep alone on the chip before the fork.  Measured with the graphs on one hardware queue:
+            # 0.808 ms per frame against 0.798 with the sweep next to the side stream's kernels, for either sweep kernel -- off.)
             sweep_first = have == 1 and _SWEEP_FIRST
             if sweep_first:
                 self._sweep_direct(cur, n_meas, sweep_variant)
@@ -1242,7 +1247,7 @@ class DepthEngine:
             pools = int(stats.get("reserved_bytes.all.current", 0)) - int(stats.get("allocated_bytes.all.current", 0))
         except Exception:
             pass
-        return {"graphs": len(self._graphs), "graphs_launched_once_at_warmup": self.warmup_graphs_launched,
+        return {"graphs": len(self._graphs), "graphs_launched_once_at_warmup": self.warmup_graphs_launched, "queue_filler_graphs": len(self._filler_graphs),
                 "reserved_minus_allocated_bytes": pools, "warmup_seconds": {k: round(v, 4) for k, v in self.warmup_seconds.items()}}
 
     def refresh_weights(self):

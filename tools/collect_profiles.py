@@ -52,25 +52,26 @@ def main():
         if os.path.exists(stats):
             shutil.copy(stats, os.path.join(dst, f"{rnd}_sweep_kernel_stats_line{m.group(1)}.csv"))
         c = counters(summary)
-        fetch = sum(v.get("FETCH_SIZE", 0.0) for k, v in c.items() if k.startswith("sweep_tiled") or k.startswith("sweep_spill"))
-        write = sum(v.get("WRITE_SIZE", 0.0) for k, v in c.items() if k.startswith("sweep_tiled") or k.startswith("sweep_spill"))
+        fetch = sum(v.get("FETCH_SIZE", 0.0) for k, v in c.items() if k.startswith(("sweep_tiled", "sweep_spill", "sweep_mfma")))
+        write = sum(v.get("WRITE_SIZE", 0.0) for k, v in c.items() if k.startswith(("sweep_tiled", "sweep_spill", "sweep_mfma")))
         per_line[int(m.group(1))] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write}
     if per_line:
         digest = hashlib.sha256(b"".join(open(os.path.join(ROOT, "deep-video-mvs_amd", "csrc", f), "rb").read()
-                                         for f in ("sweep_tiled.hip", "cost_volume.hip", "plane_sweep.h", "sweep_sample.h"))).hexdigest()
+                                         for f in ("sweep_tiled.hip", "sweep_mfma.hip", "cost_volume.hip", "plane_sweep.h", "sweep_sample.h"))).hexdigest()
         mean = lambda key: sum(v[key] for v in per_line.values()) / len(per_line)
         payload = {
-            "kernel": "dvmvs::sweep_tiled_kernel + dvmvs::sweep_spill_kernel (one cost-volume op)",
+            "kernel": "one cost-volume op as the engine launches it: dvmvs::sweep_mfma_kernel where dvmvs_sweep_plan6 takes it, else dvmvs::sweep_tiled_kernel + dvmvs::sweep_spill_kernel",
             "shape": [1, 2, 32, 128, 160, 64], "shape_meaning": "B, M, C, H, W, D",
             "how": "tools/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over tools/cv_microbench.py "
-                   "--variants auto --reps 2 on index lines 153 (easy), 118 (median), 165 (worst); per-dispatch means, both kernels added; KiB",
+                   "--variants engine --layouts nhwc --reps 2 on index lines 153 (easy), 118 (median), 165 (worst); per-dispatch means, both kernels added; KiB",
             "per_index_line": per_line,
             "FETCH_SIZE_KiB": mean("FETCH_SIZE_KiB"), "WRITE_SIZE_KiB": mean("WRITE_SIZE_KiB"),
             "hbm_bytes_per_launch": 1024.0 * (mean("FETCH_SIZE_KiB") + mean("WRITE_SIZE_KiB")),
             "algorithmic_bytes_per_launch": 13107200,
             "kernel_sources_sha256": digest,
-            "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced streams by 2x; this kernel stages with "
-                    "4 B/lane buffer loads, for which the guide gives no calibration: the raw counter is reported (upper bound: FETCH x 2).",
+            "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced streams by 2x; the tiled kernel stages with "
+                    "4 B/lane buffer loads (no calibration in the guide), the MFMA sweep reads its operands with 16 B/lane loads of scattered 128-byte cells, not a "
+                    "coalesced stream: the raw counter is reported (upper bound: FETCH x 2).",
         }
         with open(os.path.join(dst, f"{rnd}_cost_volume_pmc.json"), "w") as f:
             json.dump(payload, f, indent=1)

@@ -58,8 +58,9 @@ def main():
     dev = torch.device("cuda:0")
     lib = load_library(args.lib)
     B, C, H, W, D, M = args.batch, 32, 128, 160, 64, args.m
-    AUTO = -1      # "auto": per geometry the configuration + work list the engine would use (dvmvs_sweep_plan on the host matrices)
-    variants = [AUTO if v == "auto" else int(v) for v in args.variants.split(",")]
+    AUTO = -1      # "auto": per geometry the tiled configuration + work list of dvmvs_sweep_plan on the host matrices
+    ENGINE = -2    # "engine": what DepthEngine launches -- dvmvs_sweep_plan6 (the MFMA sweep where its estimate takes it, else the tiled plan)
+    variants = [AUTO if v == "auto" else ENGINE if v == "engine" else int(v) for v in args.variants.split(",")]
     layouts = args.layouts.split(",")
     feats = [torch.cat([syn.smooth_noise((1, C, H, W), seed=300 + 10 * b + i) for b in range(B)]).to(dev) for i in range(M + 1)]
     feats_cl = [t.contiguous(memory_format=torch.channels_last) for t in feats[1:]]
@@ -82,16 +83,17 @@ def main():
         pose1 = pose_src[ids[0]:ids[0] + 1].repeat(B, 1, 1)
         pose2s = [pose_src[i:i + 1].repeat(B, 1, 1) for i in (ids[1:] * M)[:M]]
         Hm, kt, host = pose_algebra.sweep_matrices(pose1, pose2s, K, dev, "reference", with_host=True)
-        lists, auto_variant = {}, 0
-        if AUTO in variants:
-            from dvmvs.hip import ops as _ops
-            plan = torch.zeros(_ops.sweep_work_list_words(B, H, W, D), dtype=torch.int32)
-            auto_variant = _ops.sweep_plan_host(host[0], host[1], H, W, D, 0.25, 20.0, 0, plan)
-            lists[AUTO] = plan.to(dev)
+        lists, planned = {}, {}
+        for pseudo in (AUTO, ENGINE):
+            if pseudo in variants:
+                from dvmvs.hip import ops as _ops
+                plan = torch.zeros(_ops.sweep_work_list_words(B, H, W, D), dtype=torch.int32)
+                planned[pseudo] = _ops.sweep_plan_host(host[0], host[1], H, W, D, 0.25, 20.0, 0, plan, allow_mfma=pseudo == ENGINE)
+                lists[pseudo] = plan.to(dev)
         if args.work_list:
             from dvmvs.hip import ops as _ops
             for v in variants:
-                if v == AUTO:
+                if v in (AUTO, ENGINE):
                     continue
                 if v in (0, 2, 3) or v >= 32:      # (tuning variants use the 32x8x8 tiling of the default configuration)
                     lists[v] = _ops.sweep_work_list_host(host[0], host[1], H, W, D, 0.25, 20.0, v if v < 32 else 2).to(dev)
@@ -100,7 +102,7 @@ def main():
             meas = feats_cl if layout == "nhwc" else feats[1:]
             img_ptrs = _capi.pointer_array([t.data_ptr() for t in meas])
             rc = lib.dvmvs_cost_volume_planned_fwd(feats[0].data_ptr(), img_ptrs, Hm.data_ptr(), kt.data_ptr(), dst.data_ptr(),
-                                                   B, M, C, H, W, D, 0.25, 20.0, 1, auto_variant if variant == AUTO else variant,
+                                                   B, M, C, H, W, D, 0.25, 20.0, 1, planned.get(variant, variant),
                                                    1 if layout == "nhwc" else 0,
                                                    ws.data_ptr() if ws_bytes else None, ws_bytes,
                                                    lists[variant].data_ptr() if variant in lists else None, torch.cuda.current_stream().cuda_stream)
@@ -134,7 +136,7 @@ def main():
                     torch.cuda.synchronize()
                     best = min(best, s.elapsed_time(e) * 1e3 / args.reps)
                 results[(li, layout, variant)] = (best, err)
-                label = f"auto={auto_variant}" if variant == AUTO else f"{variant:3d}"
+                label = f"auto={planned[variant]}" if variant == AUTO else f"engine={planned[variant]}" if variant == ENGINE else f"{variant:3d}"
                 print(f"line {li:3d} {layout} variant {label}: {best:8.2f} us  {100 * alg_bytes / best / 1e3 / 8000:5.2f} % of 8 TB/s  "
                       f"max|diff vs generic| {err:.2e}", flush=True)
     print("\nmean over geometries (us):")
@@ -143,7 +145,7 @@ def main():
             ts = [v[0] for (li, lo, va), v in results.items() if lo == layout and va == variant]
             es = [v[1] for (li, lo, va), v in results.items() if lo == layout and va == variant]
             if ts:
-                print(f"  {layout} variant {'auto' if variant == AUTO else variant}: mean {sum(ts) / len(ts):8.2f}  min {min(ts):8.2f}  max {max(ts):8.2f}   worst diff {max(es):.2e}")
+                print(f"  {layout} variant {'auto' if variant == AUTO else 'engine' if variant == ENGINE else variant}: mean {sum(ts) / len(ts):8.2f}  min {min(ts):8.2f}  max {max(ts):8.2f}   worst diff {max(es):.2e}")
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         with open(args.out, "w") as f:
