@@ -441,8 +441,9 @@ def secondary_leg(modules, device, args, M, lookahead, steps, warmup, gc_on=Fals
         if cache:
             for k in range(M):
                 engine._half_features(k, images[k % len(images)])
-        elapsed = timed_region(lambda i: run_frame(M + i), warmup, steps, 1, device,
-                               before=None if gc_on else gc_quiet, after=None if gc_on else gc_restore)
+        if not gc_on:
+            gc_quiet()      # (before the warm-up steps, as in the headline leg)
+        elapsed = timed_region(lambda i: run_frame(M + i), warmup, steps, 1, device, after=None if gc_on else gc_restore)
     assert np.isfinite(float(engine._static["depth"].mean()))
     return steps / elapsed, engine
 
@@ -788,8 +789,6 @@ def main():
         def region_start():      # (host time is counted over the timed steps only: warm-up steps run eagerly and capture graphs)
             host_seconds[0], host_seconds[1] = 0.0, 0
             step_events.clear()
-            if not args.keep_gc:
-                gc_quiet()      # (stated in config.cyclic_gc; value_gc_on is the same run with the collector left on)
             if mark is not None:
                 mark()
 
@@ -799,6 +798,11 @@ def main():
             if not args.keep_gc:
                 gc_restore()
 
+        if not args.keep_gc:
+            # (stated in config.cyclic_gc; value_gc_on is the same run with the collector left on.  Before the WARM-UP steps, not between them and
+            # the timed ones: the full collection is a 30-80 ms host pause, and a device that sat idle through it ran the first timed frames
+            # 5 % slower than the last)
+            gc_quiet()
         elapsed = timed_region(lambda i: run_frame(M + i), args.warmup, args.steps, world, device, before=region_start, after=region_end)
         host_ms = 1e3 * host_seconds[0] / max(host_seconds[1], 1)
     depth_mean = float(engine._static["depth"].mean())
@@ -894,7 +898,7 @@ def main():
                        "conv_epilogues_inside_miopen": (lambda rep: f"{sum(1 for r in rep if r[2])} of {len(rep)} dense convolution problems "
                                                         "(bit-identical to convolution + epilogue AND faster at warm-up)")(engine.conv_plan_report()),
                        "weights": "seeded (tests/synthetic.py) + published FPN checkpoint",
-                       "cyclic_gc": "left on" if args.keep_gc else "disabled during the timed steps (gc.collect + gc.freeze before, re-enabled after), as "
+                       "cyclic_gc": "left on" if args.keep_gc else "disabled during the warm-up and timed steps (gc.collect + gc.freeze before the warm-up, re-enabled after the timed steps), as "
                                     "timeit does; value_gc_on = the same measurement with CPython's collector left on",
                        "parallelism": f"sequence-sharded x{world}, no data-path collective"},
             "roofline": {"kernel": "the engine's sweep per keyframe pair (fused warp + correlation, all planes, all measurement frames): sweep_mfma_kernel where "

@@ -1,4 +1,4 @@
-out=gpurun_out/r05_pmc2; mkdir -p $out; export TMPDIR=/tmp; root=$(pwd)
+out=${1:-gpurun_out/r05_pmc3}; mkdir -p $out; export TMPDIR=/tmp; root=$(pwd)
 (cd /tmp && rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_[A-Z0-9_]*" | sort -u > $root/$out/sq_counters.txt)
 groups=(
  "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
