@@ -67,7 +67,7 @@ _STAGING_SLOTS = int(os.environ.get("DVMVS_STAGING_SLOTS", "1"))
 # their second branches sit on DIFFERENT queues every frame is 50 us slower (0.855 against 0.805 ms at look-ahead 1, whichever sweep kernel
 # runs) -- and which case a run gets used to depend on how many graphs were captured between the two: even (4 sweep configurations per
 # buffer set) fast, odd (5, with the MFMA sweep) slow.  So after every two-branch capture this many two-kernel filler graphs are
-# instantiated (kept, never launched): all frame graphs end up on the same queue.  DESIGN.md section 4.6; 0 = the runtime's own order.
+# instantiated (kept, never launched): all frame graphs end up on the same queue.  DESIGN.md section 5; 0 = the runtime's own order.
 _GRAPH_QUEUE_FILLERS = int(os.environ.get("DVMVS_GRAPH_QUEUE_FILLERS", "1"))
 # experiments: "1" = a frame's sweep runs before the side-stream fork instead of next to the side stream's kernels (see _frame_body_direct)
 _SWEEP_FIRST = os.environ.get("DVMVS_SWEEP_FIRST", "0") == "1"

@@ -154,14 +154,17 @@ int dvmvs_sweep_plan(const float* Hm_host, const float* kt_host, int B, int M, i
                      int variant, unsigned int* work_list_host, size_t work_list_bytes);
 /* ABI 6: HOST-side work estimate of variant 6 (the correlate-then-interpolate sweep) for batch item 0 of these matrices, no HIP call:
  * stats[4] = mean 16-cell tiles per wave, mean passes per wave, mean strips beyond the first per wave, fraction of waves whose footprint
- * cannot be bounded from its corners (behind-camera / non-finite); sampled on every eighth pixel group.  dvmvs_sweep_plan6 uses it. */
+ * cannot be bounded from its corners (behind-camera / non-finite); sampled on every sixth pixel group row / column (25 us at 160 x 128 x 64).
+ * dvmvs_sweep_plan6 uses it. */
 int dvmvs_sweep_mfma_estimate(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
                               double* stats);
-/* dvmvs_sweep_plan with variant 6 as a candidate: the tiled sweep's plan as dvmvs_sweep_plan makes it (work list filled in), then the
- * correlate-then-interpolate sweep takes the pair when its estimated work is small -- no footprint that cannot be bounded, less than one
- * extra strip per wave, fewer than 14 (easy pairs: nothing queued, <= 3 staged runs per workgroup) / 18 (others) tiles per wave: the rule
- * that separates the pairs on which it is faster on the sample scene's 285 keyframe pairs (profiles/r05_sweep_selection.md).  Returns 6 or
- * the tiled variant.  For callers whose measurement maps are channels-last (what variant 6 is fast with) and have 32 channels. */
+/* dvmvs_sweep_plan with variant 6 as a candidate.  The estimate runs first: with no footprint that cannot be bounded, less than one extra
+ * strip per wave and fewer than 14 tiles per wave the correlate-then-interpolate sweep takes the pair, the tiled plan is NOT walked and the
+ * work list is left EMPTY (header count 0: a tiled launch on it does nothing) -- returns 6.  Otherwise the tiled sweep's plan is made as
+ * dvmvs_sweep_plan makes it (work list filled in); between 14 and 18 tiles per wave variant 6 is still returned when that plan is not an
+ * easy one (runs queued for the second pass or > 3 staged runs per workgroup), else the tiled variant (2 - 5).  The thresholds separate the
+ * pairs on which variant 6 is faster on the sample scene's 285 keyframe pairs (profiles/r05_sweep_selection.md).  Lock-step batches (B > 1)
+ * always get the tiled plan.  For callers whose measurement maps are channels-last (what variant 6 is fast with) and have 32 channels. */
 int dvmvs_sweep_plan6(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
                       unsigned int* work_list_host, size_t work_list_bytes);
 /* [B,C,H,W] -> [B,H,W,C] (C <= 64, a multiple of 4), one launch: how a keyframe's features enter a channels-last feature cache. */
