@@ -71,6 +71,8 @@ _STAGING_SLOTS = int(os.environ.get("DVMVS_STAGING_SLOTS", "1"))
 _GRAPH_QUEUE_FILLERS = int(os.environ.get("DVMVS_GRAPH_QUEUE_FILLERS", "1"))
 # experiments: "1" = a frame's sweep runs before the side-stream fork instead of next to the side stream's kernels (see _frame_body_direct)
 _SWEEP_FIRST = os.environ.get("DVMVS_SWEEP_FIRST", "0") == "1"
+# a step's input copies as one launch (see DepthEngine._copy); "0" = one runtime copy each
+_BATCH_COPIES = os.environ.get("DVMVS_BATCH_COPIES", "1") != "0"
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -437,6 +439,7 @@ class DepthEngine:
         self.plan_frames_ahead = os.environ.get("DVMVS_PLAN_AHEAD", "1") != "0"
         self.planned_frames_used = 0
         self._filler_buffers, self._filler_graphs = None, []
+        self._copy_queue = None      # a list while step() collects its input copies (see _copy)
         self.warm_captured_graphs = os.environ.get("DVMVS_WARM_GRAPHS", "1") != "0"
         # launches of every newly captured graph on throw-away results: the runtime finishes setting a graph up over its first launches (a
         # 5-6 ms device stall was still seen at a graph's third launch, i.e. a few steps into a short run's timed region, with one)
@@ -572,7 +575,7 @@ class DepthEngine:
                 slot = self._feature_pool[self._feature_free[-1]]
                 self._feature_slot[frame_id] = self._feature_free.pop()
             if slot.data_ptr() != half.data_ptr():
-                self._store_measurement_map(slot, half)
+                self._copy(slot, half)
             self._feature_cache[frame_id] = slot
 
     @staticmethod
@@ -583,6 +586,36 @@ class DepthEngine:
             dst.copy_(src)      # (the frame path: channels-last into channels-last)
         else:
             _ops.nchw_to_nhwc_into(src, dst)
+
+    def _copy(self, dst, src):
+        """``dst`` = ``src`` (see _store_measurement_map).  Inside ``step`` the flat copies -- this keyframe's features into the feature cache,
+        the measurement maps into the sweep's buffers, the images into their homes: four runtime copies of 0.6 - 1 MB in front of every frame graph,
+        5 us each on the device and as much again on the host -- are collected and issued as ONE launch (dvmvs_copy_batch) before the
+        frame's parameters go up.  A copy that touches a range a queued copy writes (or writes one a queued copy reads) flushes the queue first."""
+        queue = self._copy_queue
+        if queue is None or not _BATCH_COPIES or not _ops.batchable(dst, src):
+            self._flush_copies()
+            self._store_measurement_map(dst, src)
+            return
+        nbytes = 4 * dst.numel()
+        d0, s0 = dst.data_ptr(), src.data_ptr()
+        for qd, qs in queue:
+            q0, r0, qn = qd.data_ptr(), qs.data_ptr(), 4 * qd.numel()
+            if (d0 < q0 + qn and q0 < d0 + nbytes) or (s0 < q0 + qn and q0 < s0 + nbytes) or (d0 < r0 + qn and r0 < d0 + nbytes):
+                self._flush_copies()
+                break
+        queue.append((dst, src))
+        if len(queue) == 8:
+            self._flush_copies()
+
+    def _flush_copies(self):
+        queue = self._copy_queue
+        if queue:
+            if len(queue) == 1:
+                queue[0][0].copy_(queue[0][1])
+            else:
+                _ops.copy_batch(queue)
+            queue.clear()
 
     def _allocate_static(self, n_meas):
         d, H, W, S = self.device, self.height, self.width, self.sequences
@@ -1051,68 +1084,78 @@ class DepthEngine:
         parity = self._parity if self.direct else 0
         sets = self._direct_buffers.get("sets")
         cur = sets[parity] if self.direct else None
-        if self.direct:
-            self._direct_buffers["estimate"] = cur["estimate"]      # (diagnostics: the 8x10 depth estimate of the frame this call computes)
+        self._copy_queue = []      # (closed at "inputs copied"; an exception on the way flushes what was queued: see the except clause there)
+        try:
+            if self.direct:
+                self._direct_buffers["estimate"] = cur["estimate"]      # (diagnostics: the 8x10 depth estimate of the frame this call computes)
 
-        # ---- what the previous call prepared for this frame: 0 nothing, 1 its reference features, 2 also its sweep + encoder ----
-        have, ready = 0, self._prefetched
-        # (a frame id alone does not identify an image: the prepared features are taken only for the very tensor that was announced --
-        # same storage, unmodified since; the engine keeps the announced tensor alive, so the address cannot have been reused)
-        if self.direct and frame_id is not None and ready is not None and ready["frame_id"] == frame_id and ready["parity"] == parity and \
-                ready["image"].data_ptr() == reference_image.data_ptr() and ready["image_version"] == reference_image._version and \
-                ready["image"].device == reference_image.device and tuple(ready["image"].stride()) == tuple(reference_image.stride()):
-            have = 1
-            if ready["level"] == 2 and ready["measurement_ids"] == list(measurement_ids) and len(ready["measurement_poses"]) == n_meas and \
-                    torch.equal(ready["full_K"], _pose_algebra.to_host(full_K).reshape(-1, 3, 3)) and \
-                    torch.equal(ready["pose"], _pose_algebra.to_host(reference_pose).reshape(-1, 4, 4)) and \
-                    all(torch.equal(a, _pose_algebra.to_host(b).reshape(-1, 4, 4)) for a, b in zip(ready["measurement_poses"], measurement_poses)):
-                have = 2
-        if have >= 1 and self.cache_features:
-            self._remember(frame_id, cur["ref_half_nhwc"] if self.sweep_mfma else cur["enc_cat"][0][:, :32])     # (the next frame may use this one as a measurement frame)
+            # ---- what the previous call prepared for this frame: 0 nothing, 1 its reference features, 2 also its sweep + encoder ----
+            have, ready = 0, self._prefetched
+            # (a frame id alone does not identify an image: the prepared features are taken only for the very tensor that was announced --
+            # same storage, unmodified since; the engine keeps the announced tensor alive, so the address cannot have been reused)
+            if self.direct and frame_id is not None and ready is not None and ready["frame_id"] == frame_id and ready["parity"] == parity and \
+                    ready["image"].data_ptr() == reference_image.data_ptr() and ready["image_version"] == reference_image._version and \
+                    ready["image"].device == reference_image.device and tuple(ready["image"].stride()) == tuple(reference_image.stride()):
+                have = 1
+                if ready["level"] == 2 and ready["measurement_ids"] == list(measurement_ids) and len(ready["measurement_poses"]) == n_meas and \
+                        torch.equal(ready["full_K"], _pose_algebra.to_host(full_K).reshape(-1, 3, 3)) and \
+                        torch.equal(ready["pose"], _pose_algebra.to_host(reference_pose).reshape(-1, 4, 4)) and \
+                        all(torch.equal(a, _pose_algebra.to_host(b).reshape(-1, 4, 4)) for a, b in zip(ready["measurement_poses"], measurement_poses)):
+                    have = 2
+            if have >= 1 and self.cache_features:
+                self._remember(frame_id, cur["ref_half_nhwc"] if self.sweep_mfma else cur["enc_cat"][0][:, :32])     # (the next frame may use this one as a measurement frame)
 
-        # ---- this frame's measurement features (not needed when its sweep already ran) ----
-        if have < 2:
-            # resolve every measurement frame BEFORE anything is inserted into the cache: an insertion may evict the least
-            # recently used entry, which could be a frame this very call still needs
-            fresh, target = [], (cur["meas_feat"] if self.direct else s["meas_feat"])
-            for i in range(n_meas):
-                img = measurement_images[i] if measurement_images is not None else None
-                mid = measurement_ids[i]
-                if self.cache_features and mid is not None and mid in self._feature_cache:
-                    self._feature_cache.move_to_end(mid)
-                    half = self._feature_cache[mid]
-                elif img is None:
-                    raise ValueError(f"measurement frame {mid} is not cached and no image was given")
-                else:
-                    half = self._features(img)[0].contiguous()
-                    fresh.append((mid, half))
-                self._store_measurement_map(target[i], half)
-            for mid, half in fresh:
-                self._remember(mid, half)
+            # ---- this frame's measurement features (not needed when its sweep already ran) ----
+            if have < 2:
+                # resolve every measurement frame BEFORE anything is inserted into the cache: an insertion may evict the least
+                # recently used entry, which could be a frame this very call still needs
+                fresh, target = [], (cur["meas_feat"] if self.direct else s["meas_feat"])
+                for i in range(n_meas):
+                    img = measurement_images[i] if measurement_images is not None else None
+                    mid = measurement_ids[i]
+                    if self.cache_features and mid is not None and mid in self._feature_cache:
+                        self._feature_cache.move_to_end(mid)
+                        half = self._feature_cache[mid]
+                    elif img is None:
+                        raise ValueError(f"measurement frame {mid} is not cached and no image was given")
+                    else:
+                        half = self._features(img)[0].contiguous()
+                        fresh.append((mid, half))
+                    self._copy(target[i], half)
+                for mid, half in fresh:
+                    self._remember(mid, half)
 
-        # ---- how much of the next frame this call computes ----
-        give, next_frame, n_meas_next = 0, None, 0
-        if self.direct and next_reference_image is not None and self.max_lookahead >= 1:
-            if tuple(next_reference_image.shape) != tuple(reference_image.shape):
-                raise ValueError("next_reference_image must have the reference image's shape")
-            give = 1
-            if self.max_lookahead >= 2 and next_reference_pose is not None and next_measurement_poses is not None and next_measurement_ids is not None and \
-                    next_frame_id is not None and self.pose_algebra == "reference" and self.cache_features and \
-                    1 <= len(next_measurement_poses) <= _MAX_MEAS and len(next_measurement_ids) == len(next_measurement_poses) and \
-                    all(m is not None and (m in self._feature_cache or (m == frame_id and have >= 1)) for m in next_measurement_ids):
-                give, n_meas_next = 2, len(next_measurement_poses)
-                self._allocate_static(n_meas_next)
-                next_frame = (next_reference_pose, list(next_measurement_poses))
-                for i, mid in enumerate(next_measurement_ids):
-                    sets[1 - parity]["meas_feat"][i].copy_(self._feature_cache[mid])
-        if self.direct:
-            if have < 1:
-                cur["full_in"][:, 33:36].copy_(reference_image)
-            if give >= 1:
-                sets[1 - parity]["full_in"][:, 33:36].copy_(next_reference_image)
-            s["image"], s["ref_half"] = cur["full_in"][:, 33:36], cur["enc_cat"][0][:, :32]
-        else:
-            s["image"].copy_(reference_image)
+            # ---- how much of the next frame this call computes ----
+            give, next_frame, n_meas_next = 0, None, 0
+            if self.direct and next_reference_image is not None and self.max_lookahead >= 1:
+                if tuple(next_reference_image.shape) != tuple(reference_image.shape):
+                    raise ValueError("next_reference_image must have the reference image's shape")
+                give = 1
+                if self.max_lookahead >= 2 and next_reference_pose is not None and next_measurement_poses is not None and next_measurement_ids is not None and \
+                        next_frame_id is not None and self.pose_algebra == "reference" and self.cache_features and \
+                        1 <= len(next_measurement_poses) <= _MAX_MEAS and len(next_measurement_ids) == len(next_measurement_poses) and \
+                        all(m is not None and (m in self._feature_cache or (m == frame_id and have >= 1)) for m in next_measurement_ids):
+                    give, n_meas_next = 2, len(next_measurement_poses)
+                    self._allocate_static(n_meas_next)
+                    next_frame = (next_reference_pose, list(next_measurement_poses))
+                    for i, mid in enumerate(next_measurement_ids):
+                        self._copy(sets[1 - parity]["meas_feat"][i], self._feature_cache[mid])
+            if self.direct:
+                if have < 1:
+                    self._copy(cur["full_in"][:, 33:36], reference_image)
+                if give >= 1:
+                    self._copy(sets[1 - parity]["full_in"][:, 33:36], next_reference_image)
+                s["image"], s["ref_half"] = cur["full_in"][:, 33:36], cur["enc_cat"][0][:, :32]
+            else:
+                self._copy(s["image"], reference_image)
+        except BaseException:
+            try:      # (what was queued belongs to cache entries that are already registered: write it before the error leaves)
+                self._flush_copies()
+            finally:
+                self._copy_queue = None
+            raise
+        self._flush_copies()
+        self._copy_queue = None
         mark("inputs copied")
         committed_pose, sweep_variant, next_variant = self._upload_frame_parameters(n_meas, reference_pose, measurement_poses, full_K, index=parity,
                                                                                     own_sweep=have < 2, next_frame=next_frame)

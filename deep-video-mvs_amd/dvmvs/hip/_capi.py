@@ -47,6 +47,7 @@ SIGNATURES = {
     "dvmvs_sweep_plan": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _c_dbl, _c_int, _c_fp, ctypes.c_size_t]),
     "dvmvs_sweep_plan6": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _c_dbl, _c_fp, ctypes.c_size_t]),
     "dvmvs_nchw_to_nhwc": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "dvmvs_copy_batch": (_c_int, [_c_fpp, _c_fpp, ctypes.POINTER(ctypes.c_longlong), _c_int, _c_stream]),
     "dvmvs_sweep_mfma_estimate": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_dbl, _c_dbl, ctypes.POINTER(ctypes.c_double)]),
     "dvmvs_cost_volume_planned_fwd": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fp, _c_fp,
                                                _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

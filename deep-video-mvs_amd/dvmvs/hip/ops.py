@@ -5,6 +5,7 @@ pointers and the current HIP stream to the ``extern "C"`` launcher.  No op synch
 whole frame can be captured into a hipGraph (``torch.cuda.graph``).  Tensors that are not on the GPU are rejected:
 the CPU restatement lives in ``oracle/`` and is test infrastructure only.
 """
+import ctypes
 import os
 from typing import Optional, Sequence, Tuple
 
@@ -893,6 +894,28 @@ def depth_reproject_estimate_into(transformation: Tensor, previous_depth: Tensor
                                                             _stream(previous_depth))
     _capi.check(rc, "dvmvs_depth_reproject_estimate_fwd")
     return estimate
+
+
+def copy_batch(pairs) -> None:
+    """``dst.copy_(src)`` for up to eight (dst, src) pairs of equally laid out dense float32 device tensors in ONE launch (dvmvs_copy_batch).
+    The caller guarantees what the C entry requires: same shape and strides per pair, dense storage, 16-byte aligned, a multiple of 4
+    elements, no overlap between pairs (``batchable`` checks one pair)."""
+    n = len(pairs)
+    srcs, dsts, counts = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_longlong * n)()
+    for j, (dst, src) in enumerate(pairs):
+        srcs[j], dsts[j], counts[j] = src.data_ptr(), dst.data_ptr(), dst.numel()
+    device = pairs[0][0].device
+    with torch.cuda.device(device):
+        rc = _capi.lib().dvmvs_copy_batch(srcs, dsts, counts, n, _stream(pairs[0][0]))
+    _capi.check(rc, "dvmvs_copy_batch")
+
+
+def batchable(dst: Tensor, src: Tensor) -> bool:
+    """Whether ``dst.copy_(src)`` is a flat copy dvmvs_copy_batch can take."""
+    return (dst.is_cuda and src.is_cuda and dst.device == src.device and dst.dtype == torch.float32 and src.dtype == torch.float32
+            and dst.shape == src.shape and dst.numel() % 4 == 0 and dst.numel() > 0 and dst.data_ptr() % 16 == 0 and src.data_ptr() % 16 == 0
+            and ((dst.is_contiguous() and src.is_contiguous())
+                 or (dst.dim() == 4 and dst.is_contiguous(memory_format=torch.channels_last) and src.is_contiguous(memory_format=torch.channels_last))))
 
 
 def nchw_to_nhwc_into(src: Tensor, dst: Tensor) -> Tensor:

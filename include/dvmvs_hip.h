@@ -31,7 +31,8 @@ extern "C" {
  * (dvmvs_upsample2x_bwd, dvmvs_depthwise_conv_bwd).
  * ABI 5 = ABI 4 + the direct convolution of the larger maps and the depth heads (dvmvs_direct_conv_*, dvmvs_conv_head_fwd).
  * ABI 6 (round 5) = ABI 5 + variant 6 of dvmvs_cost_volume_fwd (the correlate-then-interpolate sweep on the fp32 matrix cores) and the
- * one-launch re-projection of the frame path (dvmvs_depth_reproject_estimate_fwd); no earlier signature changed. */
+ * one-launch re-projection of the frame path (dvmvs_depth_reproject_estimate_fwd), dvmvs_sweep_plan6 / dvmvs_sweep_mfma_estimate,
+ * dvmvs_nchw_to_nhwc, dvmvs_copy_batch; no earlier signature changed. */
 #define DVMVS_ABI_VERSION 6
 #define DVMVS_MAX_MEASUREMENTS 8      /* measurement frames fused per launch */
 #define DVMVS_MAX_DEPTH_LEVELS 256    /* sweep planes per launch */
@@ -169,6 +170,10 @@ int dvmvs_sweep_plan6(const float* Hm_host, const float* kt_host, int B, int M, 
                       unsigned int* work_list_host, size_t work_list_bytes);
 /* [B,C,H,W] -> [B,H,W,C] (C <= 64, a multiple of 4), one launch: how a keyframe's features enter a channels-last feature cache. */
 int dvmvs_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, dvmvs_stream_t stream);
+/* n <= 8 contiguous device-to-device copies of n_floats[j] floats (a multiple of 4; 16-byte aligned pointers; host arrays of n entries) in
+ * ONE launch -- the small copies a frame step makes in front of its graph (features into the feature cache, measurement maps and the next
+ * image into the buffers the graph reads).  Ranges must not overlap each other (the copies run concurrently). */
+int dvmvs_copy_batch(const float* const* srcs, float* const* dsts, const long long* n_floats, int n, dvmvs_stream_t stream);
 int dvmvs_sweep_work_list(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
                           double min_depth, double max_depth, int configuration, unsigned int* work_list_host, size_t work_list_bytes);
 int dvmvs_cost_volume_planned_fwd(const float* image1, const float* const* image2s, const float* Hm, const float* kt,

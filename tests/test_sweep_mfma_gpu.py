@@ -89,3 +89,36 @@ def test_ragged_sizes(ops, hip_device, shape):
     exp64 = orc.cost_volume_fusion(*f64(f1, f2s, p1, p2s, K), 0.25, 20.0, D, True)
     assert maxerr(nchw, exp) < 5e-4 * max(1.0, exp.abs().max().item()), shape      # white-noise features (see test_hip_parity)
     as_accurate_as_reference(nchw, exp, exp64)
+
+
+def test_nchw_to_nhwc_and_copy_batch(ops, hip_device):
+    """The two small data-movement entries of the frame path: dvmvs_nchw_to_nhwc (a keyframe's features into the channels-last feature cache)
+    equals torch's channels-last conversion bit for bit, ragged pixel counts and batches included; dvmvs_copy_batch (a step's input copies as
+    one launch) equals copy_ for contiguous and channels-last pairs of different sizes, and refuses what it cannot copy flat."""
+    dev = hip_device
+    g = torch.Generator().manual_seed(5)
+    for shape in [(1, 32, 128, 160), (2, 32, 33, 47), (1, 64, 16, 20), (3, 4, 5, 7)]:
+        src = torch.randn(*shape, generator=g).to(dev)
+        dst = torch.zeros(shape, device=dev).contiguous(memory_format=torch.channels_last)
+        ops.nchw_to_nhwc_into(src, dst)
+        assert torch.equal(dst, src) and torch.equal(dst.permute(0, 2, 3, 1).contiguous(), src.permute(0, 2, 3, 1).contiguous()), shape
+    with pytest.raises((ValueError, RuntimeError)):
+        ops.nchw_to_nhwc_into(torch.zeros(1, 6, 4, 4, device=dev), torch.zeros(1, 6, 4, 4, device=dev).contiguous(memory_format=torch.channels_last))
+    cat = torch.zeros(1, 36, 256, 320, device=dev)
+    pairs = [(torch.zeros(1, 32, 128, 160, device=dev).contiguous(memory_format=torch.channels_last),
+              torch.randn(1, 32, 128, 160, generator=g).to(dev).contiguous(memory_format=torch.channels_last)),
+             (torch.zeros(1, 32, 128, 160, device=dev), torch.randn(1, 32, 128, 160, generator=g).to(dev)),
+             (cat[:, 33:36], torch.randn(1, 3, 256, 320, generator=g).to(dev)),
+             (torch.zeros(8, device=dev), torch.randn(8, generator=g).to(dev)),
+             (torch.zeros(4, 1000, device=dev), torch.randn(4, 1000, generator=g).to(dev))]
+    assert all(ops.batchable(d, s) for d, s in pairs)
+    ops.copy_batch(pairs)
+    for d, s in pairs:
+        assert torch.equal(d, s)
+    assert float(cat[:, :33].abs().max()) == 0.0                       # nothing beyond the slice was written
+    assert not ops.batchable(torch.zeros(2, 36, 8, 8, device=dev)[:, 33:36], torch.zeros(2, 3, 8, 8, device=dev))      # strided batch slice
+    assert not ops.batchable(torch.zeros(6, device=dev), torch.zeros(6, device=dev))                                        # not a multiple of 4
+    assert not ops.batchable(torch.zeros(9, device=dev)[1:], torch.zeros(8, device=dev))                                    # misaligned
+    assert not ops.batchable(torch.zeros(1, 32, 8, 8, device=dev), torch.zeros(1, 32, 8, 8, device=dev).contiguous(memory_format=torch.channels_last))
+    with pytest.raises(RuntimeError):
+        ops.copy_batch([(torch.zeros(9, device=dev)[1:], torch.zeros(8, device=dev))])
