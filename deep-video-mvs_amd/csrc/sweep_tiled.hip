@@ -416,7 +416,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WAVES) void sweep_tiled_kernel(CostVo
 
   // ---- staged runs, software-pipelined over (run, channel pass) stages ----
   constexpr int kPieces = NHWC ? (CAP * QPR + NT - 1) / NT : (CAP + NT - 1) / NT;
-  constexpr int kPreWanted = NHWC ? 2 * Cfg::PRE : Cfg::PRE;
+  // (channels-last quads: twice as many, 16 bytes each -- except in the 512-thread configuration, which is held to 128 registers: with 2 PRE
+  // quads in flight its channels-last instantiations spilled 24 - 28 bytes to scratch; PRE / PRE - 1 fit)
+  constexpr int kPreWanted = !NHWC ? Cfg::PRE : (Cfg::PSPLIT > 1 ? (GATHER ? Cfg::PRE - 1 : Cfg::PRE) : 2 * Cfg::PRE);
   constexpr int kPre = kPreWanted < kPieces ? kPreWanted : kPieces;
   constexpr int kPreRegs = NHWC ? 1 : QPR;   // float4 per piece
   if (first_staged < n_runs) {
