@@ -206,6 +206,11 @@ def test_cost_volume_channels_last_measurement_maps(ops, dev):
         assert all(not t.is_contiguous() for t in cl)
         nhwc = hipcall.cost_volume(ops, f[0].to(dev), cl, p1.to(dev), [p.to(dev) for p in p2s], K.to(dev), 0.25, 20.0, 64, True, 0)
         assert maxerr(nhwc, nchw) < 1e-6
+        # every tiled instantiation reads channels-last maps too (the frame engine keeps its maps channels-last): both LDS configurations,
+        # two-pass and single-pass forms (the wide configuration's channels-last instantiations have their own prefetch depth)
+        for variant in (2, 3, 4, 5):
+            forced = hipcall.cost_volume(ops, f[0].to(dev), cl, p1.to(dev), [p.to(dev) for p in p2s], K.to(dev), 0.25, 20.0, 64, True, variant)
+            assert maxerr(forced, nchw) < 2e-6, (r, variant)
         exp = orc.cost_volume_fusion(f[0][:1], [t[:1] for t in f[1:]], p1[:1], [p[:1] for p in p2s], K[:1], 0.25, 20.0, 64, True)
         exp64 = orc.cost_volume_fusion(*f64(f[0][:1], [t[:1] for t in f[1:]], p1[:1], [p[:1] for p in p2s], K[:1]), 0.25, 20.0, 64, True)
         as_accurate_as_reference(nhwc[:1], exp, exp64, floor=1e-5)
