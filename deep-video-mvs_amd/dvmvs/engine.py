@@ -460,7 +460,7 @@ class DepthEngine:
         # host-planned work list for the sweep: only where the matrices exist on the host, and one plan per launch (one sequence)
         self.sweep_work_list = bool(_utils.SWEEP_WORK_LIST and self.pose_algebra == "reference" and _utils.COST_VOLUME_VARIANT in (0, 2, 3, 4, 5))
         # Round 5: the correlate-then-interpolate sweep (variant 6, csrc/sweep_mfma.hip) takes the keyframe pairs on which its estimated work is
-        # small (dvmvs_sweep_plan6: 173 of the sample scene's 285 pairs, 29 us against 33 on the easy ones, 36.5 against 42.0 us over all of them);
+        # small (dvmvs_sweep_plan6: 176 of the sample scene's 285 pairs, 29 us against 33 on the easy ones, 36.5 against 42.0 us over all of them);
         # it reads one 128-byte line per measurement cell, so the engine then keeps its measurement maps -- the feature cache and the per-frame
         # buffers -- channels-last (one transposing launch per keyframe in place of the cache's contiguous copy).  DVMVS_SWEEP_MFMA=0: round 4's
         # all-tiled engine on NCHW maps.
