@@ -115,7 +115,7 @@ void sweep_plan_stats_host(int configuration, const float* Hm, const float* kt, 
 int launch_sweep_tuning(int which, const CostVolumeArgs& a, hipStream_t stream);
 // sweep_mfma.hip
 bool sweep_mfma_supports(const CostVolumeArgs& a);
-int launch_sweep_mfma(const CostVolumeArgs& a, hipStream_t stream);
+int launch_sweep_mfma(const CostVolumeArgs& a, hipStream_t stream, bool allow_persistent);
 int launch_sweep_mfma_tuning(int which, const CostVolumeArgs& a, hipStream_t stream);
 void sweep_mfma_estimate_host(const float* Hm, const float* kt, int M, int H, int W, int D, double inv_base, double inv_step, double* stats);
 
@@ -169,8 +169,8 @@ extern "C" int dvmvs_cost_volume_planned_fwd(const float* image1, const float* c
                                              float* workspace, size_t workspace_bytes, const unsigned int* work_list, dvmvs_stream_t stream) {
   using namespace dvmvs;
   if (image2_layout != DVMVS_LAYOUT_NCHW && image2_layout != DVMVS_LAYOUT_NHWC) return DVMVS_EINVAL;
-  if (variant < 0 || (variant > 6 && variant < 32) || variant > 255) return DVMVS_EINVAL;
-  if (variant >= 2 && variant <= 6 && !dot_product) return DVMVS_EUNSUPPORTED;
+  if (variant < 0 || (variant > 7 && variant < 32) || variant > 255) return DVMVS_EINVAL;
+  if (variant >= 2 && variant <= 7 && !dot_product) return DVMVS_EUNSUPPORTED;
   const bool single_pass = variant == 4 || variant == 5;      // no second launch: the sweep gathers an unstageable run inline
   if (single_pass) variant -= 2;
   CostVolumeArgs a;
@@ -178,20 +178,20 @@ extern "C" int dvmvs_cost_volume_planned_fwd(const float* image1, const float* c
   if (rc != 0) return rc;
   a.image2_nhwc = image2_layout == DVMVS_LAYOUT_NHWC ? 1 : 0;
   // channels-last measurement maps are understood by the LDS-tiled dot-product kernel only (16-byte channel quads)
-  if (a.image2_nhwc && (!dot_product || variant == 1 || C % 4 != 0 || (H * W < 64 * 64 && variant != 6))) return DVMVS_EUNSUPPORTED;
+  if (a.image2_nhwc && (!dot_product || variant == 1 || C % 4 != 0 || (H * W < 64 * 64 && variant != 6 && variant != 7))) return DVMVS_EUNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // a workspace large enough for the spill list switches the tiled sweep to its two-pass form
   if (!single_pass && workspace != nullptr && workspace_bytes >= dvmvs_cost_volume_workspace_bytes(B, M, H, W, D))
     a.spill = reinterpret_cast<unsigned int*>(workspace);
-  if (variant == 6) {
+  if (variant == 6 || variant == 7) {
     // correlate-then-interpolate sweep on the fp32 matrix cores (sweep_mfma.hip): up to 32 channels, either layout of the measurement
-    // maps, any image size, no workspace, no work list
+    // maps, any image size, no workspace, no work list; 7 = its one-item-per-workgroup form also where the persistent form is eligible
     if (!sweep_mfma_supports(a)) return DVMVS_EUNSUPPORTED;
-    return launch_sweep_mfma(a, s);
+    return launch_sweep_mfma(a, s, variant == 6);
   }
-  if (variant >= 96 && variant < 128) {
+  if ((variant >= 96 && variant < 128) || variant >= 224) {      // tuning configurations of the MFMA sweep: rounds 5 (96 + k) and 6 (224 + k - 32)
     if (!dot_product) return DVMVS_EUNSUPPORTED;
-    return launch_sweep_mfma_tuning(variant - 96, a, s);
+    return launch_sweep_mfma_tuning(variant >= 224 ? variant - 224 + 32 : variant - 96, a, s);
   }
   if (variant >= 32) {
     // tuning configurations for tools/cv_microbench.py; not part of the stable interface

@@ -39,6 +39,7 @@ struct DirectConvArgs {
   const float* packed;   // direct_conv_pack_kernel's layout
   const float* bias;     // [C_out] or null
   float* dst;            // [B, C_out, OH, OW]; batch item b at dst + b * dst_batch_stride, its planes dense
+  float* dst_nhwc;       // null, or a second, channels-last copy of the output [B, OH, OW, C_out] (dense), written in the same epilogue
   long long x_batch_stride, dst_batch_stride;
   int B, C_in, C_out, H, W, OH, OW;
   int act;               // 0 none, 1 ReLU
@@ -374,6 +375,12 @@ __global__ __launch_bounds__(Cfg::NT) void direct_conv_kernel(DirectConvArgs a) 
         for (int r = 0; r < 4; ++r)
           if (ox + r < a.OW) d[r] = v[r];
       }
+      if (a.dst_nhwc) {      // the same values once more, channels-last: lanes 0..15 of a row hold 16 consecutive channels of one pixel (64-byte runs)
+        gfloat_p dn = as_global(a.dst_nhwc) + ((static_cast<size_t>(b) * a.OH + oy) * a.OW + ox) * a.C_out + co;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ox + r < a.OW) dn[static_cast<size_t>(r) * a.C_out] = v[r];
+      }
     }
   }
   DC_TRACE(dump_trace();)
@@ -555,6 +562,13 @@ extern "C" int dvmvs_direct_conv_pack(const float* weight, float* packed, int C_
 extern "C" int dvmvs_direct_conv_fwd(const float* x, long long x_batch_stride, const float* packed, int n_tile, const float* bias, float* dst,
                                      long long dst_batch_stride, int B, int C_in, int H, int W, int C_out, int kernel_size, int stride, int activation,
                                      dvmvs_stream_t stream) {
+  return dvmvs_direct_conv_dual_fwd(x, x_batch_stride, packed, n_tile, bias, dst, dst_batch_stride, nullptr, B, C_in, H, W, C_out, kernel_size, stride, activation,
+                                    stream);
+}
+
+extern "C" int dvmvs_direct_conv_dual_fwd(const float* x, long long x_batch_stride, const float* packed, int n_tile, const float* bias, float* dst,
+                                          long long dst_batch_stride, float* dst_nhwc, int B, int C_in, int H, int W, int C_out, int kernel_size, int stride,
+                                          int activation, dvmvs_stream_t stream) {
   using namespace dvmvs;
   if (!x || !packed || !dst || B <= 0) return DVMVS_EINVAL;
   if (activation != 0 && activation != 1) return DVMVS_EUNSUPPORTED;
@@ -562,7 +576,7 @@ extern "C" int dvmvs_direct_conv_fwd(const float* x, long long x_batch_stride, c
   if (id == 0) return DVMVS_EUNSUPPORTED;
   if (kDcShapes[id - 1].NT != n_tile) return DVMVS_EINVAL;      // the weights were packed for another problem (dvmvs_direct_conv_tile)
   DirectConvArgs a;
-  a.x = x; a.packed = packed; a.bias = bias; a.dst = dst;
+  a.x = x; a.packed = packed; a.bias = bias; a.dst = dst; a.dst_nhwc = dst_nhwc;
   a.B = B; a.C_in = C_in; a.C_out = C_out; a.H = H; a.W = W; a.OH = H / stride; a.OW = W / stride;
   a.x_batch_stride = x_batch_stride ? x_batch_stride : static_cast<long long>(C_in) * H * W;
   a.dst_batch_stride = dst_batch_stride ? dst_batch_stride : static_cast<long long>(C_out) * a.OH * a.OW;

@@ -172,10 +172,27 @@ class FusedConv2d(nn.Module):
                           and tuple(conv.padding) == (k[0] // 2, k[0] // 2) and tuple(conv.dilation) == (1, 1)
                           and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2))
 
-    def forward(self, x, residual=None, residual_mode=0, out=None, activation=None, p0=0.0, p1=0.0, raw=False):
+    def forward(self, x, residual=None, residual_mode=0, out=None, activation=None, p0=0.0, p1=0.0, raw=False, out_nhwc=None):
         """``residual`` (mode 1: same shape, mode 2: half resolution, nearest-up-sampled) is added in the same epilogue; ``out``
         is the destination (default: the convolution's own output buffer); ``activation`` overrides the layer's; ``raw`` returns
-        the convolution output without the epilogue (the consumer applies it: up-sampler, depthwise kernel)."""
+        the convolution output without the epilogue (the consumer applies it: up-sampler, depthwise kernel).  ``out_nhwc``: a second
+        destination that receives the same values channels-last -- in the direct kernel's own epilogue, else by one transposing launch."""
+        if out_nhwc is not None:
+            y = self._forward(x, residual, residual_mode, out, activation, p0, p1, raw, out_nhwc)
+            if y is not None:
+                return y
+            y = self._forward(x, residual, residual_mode, out, activation, p0, p1, raw, None)
+            _ops.nchw_to_nhwc_into(y, out_nhwc)
+            return y
+        return self._forward(x, residual, residual_mode, out, activation, p0, p1, raw, None)
+
+    def _forward(self, x, residual, residual_mode, out, activation, p0, p1, raw, out_nhwc):
+        """``forward``; with ``out_nhwc``: the layer through the dual-destination direct kernel, or None when it does not take the problem."""
+        if out_nhwc is not None:
+            if self.direct_conv and residual is None and x.is_contiguous() and not (raw or self.defer_epilogue):
+                act = self.activation if activation is None else activation
+                return self._direct_forward(x, out, act, p0, p1, False, out_nhwc)
+            return None
         act = self.activation if activation is None else activation
         if (self.defer_epilogue or raw) and (out is not None or residual is not None or (activation is not None and not raw)):
             raise RuntimeError("this layer hands over its RAW convolution output (its consumer applies bias + activation): "
@@ -220,7 +237,7 @@ class FusedConv2d(nn.Module):
             return y
         return _ops.bias_act_into(y, y if out is None else out, self.bias, act, residual, residual_mode if residual is not None else 0, p0, p1)
 
-    def _direct_forward(self, x, out, act, p0, p1, raw):
+    def _direct_forward(self, x, out, act, p0, p1, raw, out_nhwc=None):
         """The layer through csrc/direct_conv.hip, or None when that kernel does not take the problem (then MIOpen as before).  ``raw``:
         the convolution output without bias and activation (the consumer applies them)."""
         k = self.weight.shape
@@ -235,6 +252,8 @@ class FusedConv2d(nn.Module):
         if raw:
             act = _ops.ACTIVATIONS["none"]
         if k[0] == 1 and k[2] == 3 and stride == 1:      # depth head
+            if out_nhwc is not None:
+                return None
             dst = out if out is not None else torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
             return _ops.conv_head_into(x, self.weight, bias, dst, act, p0, p1)
         if act not in (_ops.ACTIVATIONS["none"], _ops.ACTIVATIONS["relu"]):
@@ -251,7 +270,7 @@ class FusedConv2d(nn.Module):
                 return None      # (packed at the next eager call: the first frame of every kind runs eagerly)
             packed = self._direct_packed[tile] = _ops.direct_conv_pack(self.weight.detach(), tile)
         dst = out if out is not None else torch.empty((B, k[0], H // stride, W // stride), device=x.device, dtype=torch.float32)
-        return _ops.direct_conv_into(x, packed, tile, bias, dst, k[0], k[2], stride, act)
+        return _ops.direct_conv_into(x, packed, tile, bias, dst, k[0], k[2], stride, act, dst_nhwc=out_nhwc)
 
     def _bottleneck_for(self, x):
         """The partial-sum buffer for this input shape if the bottleneck kernel takes the problem (else None); packs the weights the
@@ -832,14 +851,22 @@ class DepthEngine:
         return result
 
     # ---- destination-passing frame body (one sequence) ------------------------------------------------------------------
-    def _fpn_direct(self, taps, outs):
+    def _fpn_direct(self, taps, outs, half_nhwc=None):
         """FeaturePyramidNetwork.forward (dvmvs/backbone.py; torchvision's top-down pathway) with the four used outputs written
-        into ``outs`` and the unused 1/32 output (fusionnet/model.py:159-164 drops it) not computed."""
+        into ``outs`` and the unused 1/32 output (fusionnet/model.py:159-164 drops it) not computed.  ``half_nhwc``: the half-resolution
+        output once more, channels-last (what a later frame's MFMA sweep reads as measurement map): written by the smoothing layer's own
+        epilogue (round 6; round 5: a transposing launch behind it, 5 - 16 us of every frame)."""
         fpn = self.fs.fpn
         top = fpn.inner_blocks[-1](taps[-1])
         for level in range(len(taps) - 2, -1, -1):
             top = fpn.inner_blocks[level](taps[level], residual=top, residual_mode=2)
-            fpn.layer_blocks[level](top, out=outs[level])
+            if level == 0 and half_nhwc is not None and isinstance(fpn.layer_blocks[0], FusedConv2d):
+                fpn.layer_blocks[0](top, out=outs[0], out_nhwc=half_nhwc)
+                half_nhwc = None
+            else:
+                fpn.layer_blocks[level](top, out=outs[level])
+        if half_nhwc is not None:
+            _ops.nchw_to_nhwc_into(outs[0], half_nhwc)
 
     def _decoder_block_direct(self, block, x, cat, depth_head, depth_input):
         """DecoderBlock.forward (dvmvs/networks.py) on the concatenation buffer ``cat`` = [up-convolution | skip | up(depth)]; the skip
@@ -916,12 +943,10 @@ class DepthEngine:
 
     def _reference_features_direct(self, buffers):
         """MnasNet taps -> FPN of the reference image of a buffer set, each used output into the front of its encoder concatenation buffer."""
-        self._fpn_direct(self.fe(buffers["full_in"][:, 33:36]), [c[:, :32] for c in buffers["enc_cat"]])
-        if self.sweep_mfma:
-            # the copy a later frame's sweep reads as measurement map (one 128-byte line per cell): made here, inside the frame graph, so that
-            # the feature cache's per-keyframe copy stays a plain device copy on the host's side (an eager transposing launch per step cost the
-            # host, which is as busy as the device at this frame rate, 45 us)
-            _ops.nchw_to_nhwc_into(buffers["enc_cat"][0][:, :32], buffers["ref_half_nhwc"])
+        # (sweep_mfma: the copy a later frame's sweep reads as measurement map -- one 128-byte line per cell -- is made here, inside the frame graph, so
+        # that the feature cache's per-keyframe copy stays a plain device copy on the host's side)
+        self._fpn_direct(self.fe(buffers["full_in"][:, 33:36]), [c[:, :32] for c in buffers["enc_cat"]],
+                         half_nhwc=buffers["ref_half_nhwc"] if self.sweep_mfma else None)
 
     def _after_features_direct(self, n_meas, has_previous, sweep_variant=0, buffers=None):
         """Everything of a frame behind the feature extraction: sweep, encoder, re-projection, ConvLSTM, decoder."""

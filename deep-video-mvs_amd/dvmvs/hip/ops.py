@@ -162,7 +162,7 @@ def _cost_volume_op(image1: Tensor, image2s: Sequence[Tensor], Hm: Tensor, kt: T
     image1 = image1.contiguous()
     # Measurement maps that are already channels-last in memory (the frame engine caches them that way) are passed as NHWC;
     # anything else is made NCHW-contiguous, the reference's layout.
-    nhwc_ok = bool(dot_product) and variant != 1 and C % 4 == 0 and C > 1 and (H * W >= 64 * 64 or (variant == 6 and C <= 32))
+    nhwc_ok = bool(dot_product) and variant != 1 and C % 4 == 0 and C > 1 and (H * W >= 64 * 64 or (variant in (6, 7) and C <= 32))
     nhwc = nhwc_ok and all(t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous() for t in image2s)
     image2s = list(image2s) if nhwc else [t.contiguous() for t in image2s]
     Hm, kt = Hm.contiguous(), kt.contiguous()
@@ -801,9 +801,11 @@ def direct_conv_pack(weight: Tensor, n_tile: int) -> Tensor:
     return packed
 
 
-def direct_conv_into(x: Tensor, packed: Tensor, n_tile: int, bias, dst: Tensor, C_out: int, kernel_size: int, stride: int, activation: int) -> Tensor:
+def direct_conv_into(x: Tensor, packed: Tensor, n_tile: int, bias, dst: Tensor, C_out: int, kernel_size: int, stride: int, activation: int,
+                     dst_nhwc=None) -> Tensor:
     """dst = act(conv2d(x, W, padding = k // 2, stride) + bias) with ``direct_conv_pack``-ed weights; ``dst`` a dense [B,C_out,H/s,W/s]
-    tensor or a channel slice of a concatenation buffer; activation "none" or "relu"."""
+    tensor or a channel slice of a concatenation buffer; activation "none" or "relu".  ``dst_nhwc``: a second destination that receives the
+    same values channels-last ([B,C_out,H/s,W/s] in torch.channels_last memory format), written in the same epilogue."""
     _dev_f32("direct_conv_into", x, packed, dst)
     if x.dim() != 4 or not x.is_contiguous():
         raise ValueError("dvmvs::direct_conv_into: expected a contiguous NCHW input")
@@ -811,11 +813,15 @@ def direct_conv_into(x: Tensor, packed: Tensor, n_tile: int, bias, dst: Tensor, 
     batch_stride = _slice_batch_stride("direct_conv_into", dst, B, int(C_out), H // stride, W // stride)
     if bias is not None and bias.numel() not in (0, C_out):
         raise ValueError(f"dvmvs::direct_conv_into: bias has {bias.numel()} entries for {C_out} channels")
+    if dst_nhwc is not None:
+        _dev_f32("direct_conv_into", dst_nhwc)
+        if tuple(dst_nhwc.shape) != (B, int(C_out), H // stride, W // stride) or not dst_nhwc.is_contiguous(memory_format=torch.channels_last):
+            raise ValueError("dvmvs::direct_conv_into: dst_nhwc must be a dense channels-last tensor of the output's shape")
     with torch.cuda.device(x.device):
-        rc = _capi.lib().dvmvs_direct_conv_fwd(_ptr(x), 0, _ptr(packed), int(n_tile), _ptr(bias) if bias is not None and bias.numel() else None,
-                                               _ptr(dst), batch_stride, B, C_in, H, W, int(C_out), int(kernel_size), int(stride), int(activation),
-                                               _stream(x))
-    _capi.check(rc, "dvmvs_direct_conv_fwd")
+        rc = _capi.lib().dvmvs_direct_conv_dual_fwd(_ptr(x), 0, _ptr(packed), int(n_tile), _ptr(bias) if bias is not None and bias.numel() else None,
+                                                    _ptr(dst), batch_stride, _ptr(dst_nhwc) if dst_nhwc is not None else None, B, C_in, H, W, int(C_out),
+                                                    int(kernel_size), int(stride), int(activation), _stream(x))
+    _capi.check(rc, "dvmvs_direct_conv_dual_fwd")
     return dst
 
 

@@ -32,8 +32,12 @@ extern "C" {
  * ABI 5 = ABI 4 + the direct convolution of the larger maps and the depth heads (dvmvs_direct_conv_*, dvmvs_conv_head_fwd).
  * ABI 6 (round 5) = ABI 5 + variant 6 of dvmvs_cost_volume_fwd (the correlate-then-interpolate sweep on the fp32 matrix cores) and the
  * one-launch re-projection of the frame path (dvmvs_depth_reproject_estimate_fwd), dvmvs_sweep_plan6 / dvmvs_sweep_mfma_estimate,
- * dvmvs_nchw_to_nhwc, dvmvs_copy_batch; no earlier signature changed. */
-#define DVMVS_ABI_VERSION 6
+ * dvmvs_nchw_to_nhwc, dvmvs_copy_batch; no earlier signature changed.
+ * ABI 7 (round 6) = ABI 6 + dvmvs_direct_conv_dual_fwd (the direct convolution with a second, channels-last copy of its output written in the
+ * same epilogue: the frame engine's keyframe features reach the MFMA sweep without a transposing launch); no earlier signature changed.
+ * Variant 6 of dvmvs_cost_volume_fwd runs as one persistent 16-wave workgroup per CU where the problem allows (csrc/sweep_mfma.hip): same
+ * arguments, bit-identical volumes. */
+#define DVMVS_ABI_VERSION 7
 #define DVMVS_MAX_MEASUREMENTS 8      /* measurement frames fused per launch */
 #define DVMVS_MAX_DEPTH_LEVELS 256    /* sweep planes per launch */
 
@@ -99,7 +103,10 @@ int dvmvs_sweep_matrices(const float* pose1, const float* const* pose2s, const f
  *               gathered inline by the sweep kernel (what dvmvs_sweep_plan returns when its plan queues nothing; also what a NULL
  *               workspace gives); 6 = the correlate-then-interpolate sweep on the fp32 matrix cores (csrc/sweep_mfma.hip: the 32-channel dot
  *               product per measurement CELL on v_mfma_f32_16x16x4_f32, four table look-ups per (pixel, plane, frame); up to 32 channels,
- *               either layout, any image size, no workspace, no work list, no host plan).  Each is bit-reproducible; they differ in fp32
+ *               either layout, any image size, no workspace, no work list, no host plan; since round 6 one persistent 16-wave workgroup per CU
+ *               that gives every SIMD the same mix of work, for one batch item with >= 4096 (pixel group, 16-plane chunk) items whose
+ *               K t / depth table fits in LDS, D * M <= 512); 7 = variant 6 as one work item per workgroup for every shape (what 6 falls back
+ *               to; bit-identical to 6: the comparison kernel of tests and bench).  Each is bit-reproducible; they differ in fp32
  *               summation order.
  *   image2_layout DVMVS_LAYOUT_NCHW, or DVMVS_LAYOUT_NHWC when the MEASUREMENT maps are stored channels-last (a keyframe's
  *               features are reused as measurement features by later frames, so a runner converts them once per
@@ -293,6 +300,8 @@ int dvmvs_lstm_gates_partials_fwd(const float* conv_partials, int n_partials, co
  *   dvmvs_direct_conv_fwd           x [B,C_in,H,W] (batch item b at x + b*x_batch_stride, 0 = dense) -> dst [B,C_out,H/stride,W/stride]
  *                                   (batch item b at dst + b*dst_batch_stride, 0 = dense: a channel slice of a concatenation buffer);
  *                                   bias may be NULL; activation 0 none, 1 ReLU; DVMVS_EINVAL when n_tile is not the problem's
+ *   dvmvs_direct_conv_dual_fwd      (ABI 7) the same, and when dst_nhwc is not NULL the same values once more as a dense channels-last map
+ *                                   [B,H/stride,W/stride,C_out] (DVMVS_LAYOUT_NHWC: what variant 6 of the sweep reads one 128-byte line per cell)
  *   dvmvs_conv_head_fwd             3x3, padding 1, ONE output channel: weight [1,C_in,3,3]; dst [B,1,H,W]; bias may be NULL (raw
  *                                   convolution output when also activation == 0); activation / p0 / p1 as dvmvs_bias_act_fwd
  */
@@ -302,6 +311,9 @@ int dvmvs_direct_conv_pack(const float* weight, float* packed, int C_out, int C_
 int dvmvs_direct_conv_fwd(const float* x, long long x_batch_stride, const float* packed, int n_tile, const float* bias, float* dst,
                           long long dst_batch_stride, int B, int C_in, int H, int W, int C_out, int kernel_size, int stride, int activation,
                           dvmvs_stream_t stream);
+int dvmvs_direct_conv_dual_fwd(const float* x, long long x_batch_stride, const float* packed, int n_tile, const float* bias, float* dst,
+                               long long dst_batch_stride, float* dst_nhwc, int B, int C_in, int H, int W, int C_out, int kernel_size, int stride,
+                               int activation, dvmvs_stream_t stream);
 int dvmvs_conv_head_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias, float* dst,
                         long long dst_batch_stride, int B, int C_in, int H, int W, int activation, float p0, float p1, dvmvs_stream_t stream);
 

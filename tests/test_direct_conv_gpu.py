@@ -65,6 +65,39 @@ def test_direct_conv_writes_a_channel_slice_and_is_deterministic():
     assert torch.equal(again, cat[:, 64:128])
 
 
+@pytest.mark.parametrize("shape", [(32, 128, 160, 32, 3, 1), (96, 128, 160, 32, 5, 1), (64, 64, 80, 128, 3, 2), (36, 256, 320, 32, 5, 1), (7, 16, 80, 48, 3, 1)])
+def test_second_channels_last_destination_holds_the_same_bits(shape):
+    """dvmvs_direct_conv_dual_fwd (ABI 7): the epilogue writes its values a second time, channels-last -- how a keyframe's half-resolution FPN
+    features reach the MFMA sweep without a transposing launch.  Equal bit for bit to the NCHW output (a channel slice of a concatenation
+    buffer, as in the engine), batches included; nothing else of the slice's buffer is touched; a destination of the wrong layout is refused."""
+    ops = _ops()
+    C_in, H, W, C_out, k, stride = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C_in * 13 + k)
+    for batch in (1, 2):
+        x = torch.randn(batch, C_in, H, W, generator=g).to(dev)
+        w = (torch.randn(C_out, C_in, k, k, generator=g) / (C_in * k * k) ** 0.5).to(dev)
+        bias = torch.randn(C_out, generator=g).to(dev)
+        n_tile = ops.direct_conv_tile(batch, C_in, H, W, C_out, k, stride)
+        packed = ops.direct_conv_pack(w, n_tile)
+        OH, OW = H // stride, W // stride
+        cat = torch.full((batch, C_out + 5, OH, OW), 7.0, device=dev)
+        plain = torch.empty(batch, C_out, OH, OW, device=dev)
+        nhwc = torch.full((batch, C_out, OH, OW), float("nan"), device=dev).contiguous(memory_format=torch.channels_last)
+        ops.direct_conv_into(x, packed, n_tile, bias, plain, C_out, k, stride, 1)
+        if batch == 1:
+            ops.direct_conv_into(x, packed, n_tile, bias, cat[:, :C_out], C_out, k, stride, 1, dst_nhwc=nhwc)
+            assert torch.equal(cat[:, :C_out], plain) and float((cat[:, C_out:] - 7.0).abs().max()) == 0.0
+        else:
+            both = torch.empty_like(plain)
+            ops.direct_conv_into(x, packed, n_tile, bias, both, C_out, k, stride, 1, dst_nhwc=nhwc)
+            assert torch.equal(both, plain)
+        assert torch.equal(nhwc, plain)                                                     # same values ...
+        assert torch.equal(nhwc.permute(0, 2, 3, 1).contiguous(), plain.permute(0, 2, 3, 1).contiguous())      # ... in channels-last storage
+    with pytest.raises(ValueError):
+        ops.direct_conv_into(x, packed, n_tile, bias, plain, C_out, k, stride, 1, dst_nhwc=torch.empty_like(plain))
+
+
 def test_problems_the_kernel_does_not_take():
     ops = _ops()
     assert ops.direct_conv_tile(1, 512, 16, 20, 256, 3, 1) == 0      # 20 columns: the bottleneck kernel's maps

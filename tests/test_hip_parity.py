@@ -62,8 +62,9 @@ def check_pins(t, z, prefix, atol):
     assert abs(t.double().sum().item() - float(z[f"{prefix}_sum"])) <= 2e-5 * scale
 
 
-VARIANTS = [0, 1, 2, 3, 4, 5, 6]   # 0 automatic, 1 generic, 2 / 3 the two configurations of the LDS-tiled sweep, 4 / 5 the same without a second pass,
-                                   # 6 the correlate-then-interpolate sweep on the fp32 matrix cores (csrc/sweep_mfma.hip)
+VARIANTS = [0, 1, 2, 3, 4, 5, 6, 7]   # 0 automatic, 1 generic, 2 / 3 the two configurations of the LDS-tiled sweep, 4 / 5 the same without a second pass,
+                                      # 6 the correlate-then-interpolate sweep on the fp32 matrix cores (csrc/sweep_mfma.hip; persistent form where
+                                      # eligible), 7 its one-item-per-workgroup form
 
 
 def as_accurate_as_reference(got, ref32, ref64, slack=3.0, floor=2e-6):
@@ -96,7 +97,7 @@ def test_cost_volume_small_goldens(ops, dev, golden_dir, variant, fixture_host_a
     feats = [syn.analytic_features(s, 8, 32, 40) for s in range(4)]
     for tag, (r, ms) in json.loads(str(z["pose_sets"])).items():
         for dot in (True, False):
-            if variant in (2, 3, 4, 5, 6) and not dot:
+            if variant in (2, 3, 4, 5, 6, 7) and not dot:
                 continue
             got = run_cv(ops, dev, feats[0], [feats[1 + i] for i in range(len(ms))], syn.pose(r), [syn.pose(m) for m in ms], K,
                          0.25, 20.0, 16, dot, variant)
@@ -157,7 +158,7 @@ def test_cost_volume_ragged_shapes_and_batches(ops, dev, shape, variant):
     K = torch.cat([syn.scaled_K(syn.full_K(), 320.0 / W) * torch.tensor([1.0 + 0.01 * b]) for b in range(B)])
     K[:, 2, 2] = 1.0
     for dot in (True, False):
-        if variant in (2, 3, 4, 5, 6) and not dot:
+        if variant in (2, 3, 4, 5, 6, 7) and not dot:
             continue
         got = run_cv(ops, dev, f1, f2s, p1, p2s, K, 0.25, 20.0, D, dot, variant)
         exp = orc.cost_volume_fusion(f1, f2s, p1, p2s, K, 0.25, 20.0, D, dot)

@@ -70,10 +70,13 @@ def test_strong_magnification_uses_strips(ops, hip_device, forward):
     as_accurate_as_reference(nchw, exp, exp64, floor=1e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 33, 47, 10, 3), (1, 32, 61, 83, 37, 2), (1, 32, 128, 160, 19, 1), (2, 24, 30, 42, 16, 2), (1, 32, 256, 320, 16, 1)])
+@pytest.mark.parametrize("shape", [(2, 32, 33, 47, 10, 3), (1, 32, 61, 83, 37, 2), (1, 32, 128, 160, 19, 1), (2, 24, 30, 42, 16, 2), (1, 32, 256, 320, 16, 1),
+                                   (1, 32, 130, 162, 61, 3), (1, 28, 124, 157, 130, 2), (1, 32, 128, 160, 64, 8)])
 def test_ragged_sizes(ops, hip_device, shape):
     """Image sizes that are not multiples of the 4 x 4 pixel group, plane counts that are not multiples of 16, batches with their own
-    poses, a channel count below 32 (zero-padded operands), the full-resolution size (boxes of more than 2^16 cells possible)."""
+    poses, a channel count below 32 (zero-padded operands), the full-resolution size (boxes of more than 2^16 cells possible).  The last four
+    shapes run the persistent form (round 6: >= 4096 work items, one batch item): group rows that are no multiple of 16 (XCD row sets with slots
+    beyond the image), ragged plane counts, 9 chunks per group, the maximum of 8 measurement frames."""
     dev = hip_device
     B, C, H, W, D, M = shape
     g = torch.Generator().manual_seed(B * 1000 + C * 100 + H)
@@ -89,6 +92,32 @@ def test_ragged_sizes(ops, hip_device, shape):
     exp64 = orc.cost_volume_fusion(*f64(f1, f2s, p1, p2s, K), 0.25, 20.0, D, True)
     assert maxerr(nchw, exp) < 5e-4 * max(1.0, exp.abs().max().item()), shape      # white-noise features (see test_hip_parity)
     as_accurate_as_reference(nchw, exp, exp64)
+
+
+@pytest.mark.parametrize("case", [(0, 128, 160, 64, 2), (118, 128, 160, 64, 2), (170, 128, 160, 64, 2), (202, 128, 160, 64, 1), (40, 132, 172, 50, 3), (9, 256, 320, 64, 2)])
+def test_persistent_form_is_bit_identical_to_one_item_per_workgroup(ops, hip_device, case):
+    """Variant 6 on these shapes is ONE persistent 16-wave workgroup per CU: own items by enumeration, the tail as quarter items (4 of an item's 16
+    planes) pulled through an LDS queue.  Which wave computes what must not change a bit: equal to variant 7 (one item per workgroup, no quarters)
+    on easy, wide-baseline, forward-motion and ragged geometries, both layouts, every output element written (NaN-prefilled destination)."""
+    dev = hip_device
+    line, H, W, D, M = case
+    K = syn.scaled_K(syn.full_K(), 320.0 / W)
+    r, ms = syn.keyframe_index_lines(2)[line]
+    ms = (list(ms) + [r - 5])[:M]
+    f = [syn.smooth_noise((1, 32, H, W), seed=700 + i).to(dev) for i in range(M + 1)]
+    p1, p2s = syn.pose(r), [syn.pose(m) for m in ms]
+    from dvmvs import pose_algebra
+    Hm, kt = pose_algebra.sweep_matrices(p1, p2s, K, dev, "reference")
+    for meas in (f[1:], [t.contiguous(memory_format=torch.channels_last) for t in f[1:]]):
+        outs = []
+        for variant in (6, 7):
+            dst = torch.full((1, D, H, W), float("nan"), device=dev)
+            ops.cost_volume_into(f[0], meas, Hm, kt, 0.25, 20.0, dst, variant)
+            assert not torch.isnan(dst).any(), (case, variant)
+            outs.append(dst)
+        assert torch.equal(outs[0], outs[1]), case
+    generic = hipcall.cost_volume(ops, f[0], f[1:], p1, p2s, K, 0.25, 20.0, D, True, 1)
+    assert maxerr(outs[0], generic) < 3e-5, case
 
 
 def test_nchw_to_nhwc_and_copy_batch(ops, hip_device):

@@ -86,6 +86,49 @@ def main():
         row("fastest 5 %", order[:len(order) // 20])
         for c in range(4):
             row(f"chunk {c}", chunk == c)
+        # ---- per SIMD (round 6: where does a SIMD idle?) ----
+        simd_index = np.unique(simd_key, return_inverse=True)[1]
+        n_simd = simd_index.max() + 1
+        s_waves = np.bincount(simd_index, minlength=n_simd)
+        s_tiles = np.bincount(simd_index, weights=ntiles, minlength=n_simd)
+        s_occupied = np.bincount(simd_index, weights=dur, minlength=n_simd)      # sum of its waves' lifetimes
+        s_first = np.full(n_simd, np.inf)
+        s_last = np.zeros(n_simd)
+        np.minimum.at(s_first, simd_index, start)
+        np.maximum.at(s_last, simd_index, end)
+        # time with at least one wave resident, and mean number of resident waves while any is
+        s_covered = np.zeros(n_simd)
+        for k in range(n_simd):
+            sel = np.nonzero(simd_index == k)[0]
+            order_k = sel[np.argsort(start[sel])]
+            cur_s, cur_e, total = None, None, 0.0
+            for i in order_k:
+                if cur_s is None:
+                    cur_s, cur_e = start[i], end[i]
+                elif start[i] <= cur_e:
+                    cur_e = max(cur_e, end[i])
+                else:
+                    total += cur_e - cur_s
+                    cur_s, cur_e = start[i], end[i]
+            s_covered[k] = total + (cur_e - cur_s if cur_s is not None else 0.0)
+        span = end.max()
+        print(f"  per SIMD ({n_simd} SIMDs): waves per SIMD histogram " + ", ".join(f"{k}: {int((s_waves == k).sum())}" for k in range(int(s_waves.min()), int(s_waves.max()) + 1)))
+        print(f"    tiles per SIMD: min {s_tiles.min():.0f} mean {s_tiles.mean():.1f} max {s_tiles.max():.0f}; sum of wave lifetimes per SIMD: min {s_occupied.min():.1f} mean {s_occupied.mean():.1f} "
+              f"max {s_occupied.max():.1f} us")
+        print(f"    last wave of a SIMD ends: p10 {np.percentile(s_last, 10):.1f} p50 {np.percentile(s_last, 50):.1f} p90 {np.percentile(s_last, 90):.1f} max {s_last.max():.1f} us "
+              f"(launch span {span:.1f}); SIMD has no wave resident for {np.mean(span - s_covered):.1f} us on average ({100 * np.mean(span - s_covered) / span:.0f} % of the span), "
+              f"worst {np.max(span - s_covered):.1f}, best {np.min(span - s_covered):.1f}")
+        print(f"    mean resident waves per SIMD while any is resident: {np.mean(s_occupied / np.maximum(s_covered, 1e-9)):.2f}")
+        for k in range(int(s_waves.min()), int(s_waves.max()) + 1):
+            m = s_waves == k
+            if m.any():
+                print(f"    SIMDs with {k} waves ({int(m.sum()):4d}): last end mean {s_last[m].mean():5.1f} max {s_last[m].max():5.1f} us; tiles {s_tiles[m].mean():5.1f}; wave lifetime mean "
+                      f"{(s_occupied[m] / k).mean():5.2f} us")
+        cc = np.corrcoef(s_waves, s_last)[0, 1], np.corrcoef(s_tiles, s_last)[0, 1]
+        print(f"    correlation of a SIMD's last end with its wave count {cc[0]:.2f}, with its tile count {cc[1]:.2f}")
+        edges = np.arange(0.0, span + 2.0, 2.0)
+        alive = [(np.minimum(end, hi) - np.maximum(start, lo)).clip(min=0).sum() / (hi - lo) for lo, hi in zip(edges[:-1], edges[1:])]
+        print("    resident waves on the chip per 2 us bin: " + " ".join(f"{a:.0f}" for a in alive))
         q = np.percentile(start, [50, 75, 90, 100])
         print(f"  start times p50 {q[0]:.1f} p75 {q[1]:.1f} p90 {q[2]:.1f} max {q[3]:.1f} us; end times p50 {np.percentile(end, 50):.1f} p90 {np.percentile(end, 90):.1f} max {end.max():.1f} us")
 
