@@ -219,6 +219,105 @@ def golden_rel_l1(modules, device, args):
     return {"teacher_forced": teacher, "free_running": free, "host_algebra_misses": host.misses}
 
 
+class ModuleSurfaceLoop:
+    """The reference's per-frame loop (fusionnet/run-testing.py:151-204) restated on the dvmvs MODULE SURFACE -- the route BASELINE.json's north_star
+    calls "drops into the existing run-testing scripts": dvmvs.utils.cost_volume_fusion and get_non_differentiable_rectangle_depth_estimation, the
+    nn.Modules as the scripts build them (BatchNorm unfolded, eager launches), measurement features recomputed every frame as the script does,
+    poses and intrinsics ON THE DEVICE as run-testing.py:127-149 puts them; no DepthEngine, no graphs, no feature cache."""
+
+    def __init__(self, modules, device):
+        from dvmvs import utils
+        from dvmvs.config import Config
+        self.utils, self.device = utils, device
+        self.fe, self.fs, self.enc, self.lstm, self.dec = [m.to(device).eval() for m in modules]
+        self.H, self.W = Config.test_image_height, Config.test_image_width
+        self.warp_grid = utils.get_warp_grid_for_cost_volume_calculation(self.W // 2, self.H // 2, device)
+        self.reset()
+
+    def reset(self):
+        self.lstm_state, self.previous_depth, self.previous_pose = None, None, None
+
+    def step(self, reference_image, reference_pose, measurement_images, measurement_poses, full_K):
+        half_K = full_K.clone()
+        half_K[:, 0:2, :] = half_K[:, 0:2, :] / 2.0
+        lstm_K = full_K.clone()
+        lstm_K[:, 0:2, :] = lstm_K[:, 0:2, :] / 32.0
+        measurement_halfs = [self.fs(*self.fe(image))[0] for image in measurement_images]
+        half, quarter, eighth, sixteenth = self.fs(*self.fe(reference_image))
+        cost_volume = self.utils.cost_volume_fusion(half, measurement_halfs, reference_pose, measurement_poses, half_K, self.warp_grid, 0.25, 20.0, 64,
+                                                    self.device, True)
+        skip0, skip1, skip2, skip3, bottom = self.enc(features_half=half, features_quarter=quarter, features_one_eight=eighth,
+                                                      features_one_sixteen=sixteenth, cost_volume=cost_volume)
+        if self.previous_depth is not None:
+            estimate = self.utils.get_non_differentiable_rectangle_depth_estimation(reference_pose, self.previous_pose, self.previous_depth, full_K, half_K,
+                                                                                    self.W, self.H)
+            estimate = torch.nn.functional.interpolate(estimate, scale_factor=1.0 / 16.0, mode="nearest")
+        else:
+            estimate = torch.zeros(1, 1, self.H // 32, self.W // 32, device=self.device)
+        self.lstm_state = self.lstm(current_encoding=bottom, current_state=self.lstm_state, previous_pose=self.previous_pose, current_pose=reference_pose,
+                                    estimated_current_depth=estimate, camera_matrix=lstm_K)
+        prediction = self.dec(reference_image, skip0, skip1, skip2, skip3, self.lstm_state[0])[0]
+        self.previous_depth = prediction.view(1, 1, self.H, self.W)
+        self.previous_pose = reference_pose
+        return prediction, estimate
+
+
+def module_surface_leg(modules, device, args, M, steps, warmup):
+    """Frames/s of ``ModuleSurfaceLoop`` on the headline workload (same synthetic sequence, same poses), timed like the other legs, with the pose
+    algebra in "auto" mode (device-resident poses are served on the device in fp64, no synchronisation: dvmvs/pose_algebra.py) -- and the depth
+    rel-L1 of exactly this route against the reference fixtures on the 17 golden frames, teacher-forced (the reference's own state installed)."""
+    import synthetic as syn
+    from dvmvs import pose_algebra
+    saved_mode = pose_algebra.MODE
+    pose_algebra.MODE = "auto"
+    try:
+        loop = ModuleSurfaceLoop(modules, device)
+        images, seq, full_K = synthetic_sequence(0, 32, warmup + steps + M + 2, M)
+        images = [im.to(device) for im in images]
+        seq = [(r.to(device), [p.to(device) for p in ms]) for r, ms in seq]
+        full_K = full_K.to(device)
+
+        def run_frame(k):
+            ids = [k - 1 - i for i in range(M)]
+            return loop.step(images[k % 32], seq[k][0], [images[i % 32] for i in ids], seq[k][1], full_K)
+
+        with torch.no_grad():
+            elapsed = timed_region(lambda i: run_frame(M + i), warmup, steps, 1, device)
+            # parity of this route: the golden frames, teacher-forced from the reference's recorded state
+            golden = os.path.join(ROOT, "tests", "golden")
+            zs = np.load(os.path.join(golden, "fusionnet_state.npz"))
+            lines = syn.keyframe_index_lines(2)
+            fullK = syn.full_K().to(device)
+            rel = lambda d, ref: float(np.mean(np.abs(d.astype(np.float64) - ref.astype(np.float64)) / ref.astype(np.float64)))
+            runs = [("f", list(syn.E2E_FRAMES)), ("s", [None if i is None else lines[i] for i in syn.LONG_SCHEDULE])]
+            rels = []
+            for tag, frames in runs:
+                loop.reset()
+                previous = None
+                for n, item in enumerate(frames):
+                    if item is None:
+                        loop.reset()
+                        previous = None
+                        continue
+                    r, ms = item
+                    if previous is not None:
+                        k, r_prev = previous
+                        loop.lstm_state = (torch.from_numpy(zs[f"{tag}{k}_h"]).to(device), torch.from_numpy(zs[f"{tag}{k}_c"]).to(device))
+                        loop.previous_depth = torch.from_numpy(zs[f"{tag}{k}_depth"]).to(device).view(1, 1, loop.H, loop.W)
+                        loop.previous_pose = syn.pose(r_prev).to(device)
+                    d, _ = loop.step(syn.e2e_image(r).to(device), syn.pose(r).to(device), [syn.e2e_image(i).to(device) for i in ms],
+                                     [syn.pose(i).to(device) for i in ms], fullK)
+                    rels.append(rel(d.reshape(loop.H, loop.W).cpu().numpy(), zs[f"{tag}{n}_depth"].reshape(loop.H, loop.W)))
+                    previous = (n, r)
+    finally:
+        pose_algebra.MODE = saved_mode
+    return {"value": steps / elapsed, "unit": "frames/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
+            "route": "reference loop restated on dvmvs.utils + nn.Modules, eager, BN unfolded, no feature cache, poses + K on the device",
+            "pose_algebra": "auto (device tensors: fp64 on the device, no synchronisation)",
+            "rel_l1": {"teacher_forced": [round(v, 9) for v in rels], "teacher_forced_max": max(rels), "frames": len(rels), "target": 1e-4,
+                       "note": "vs the reference fixtures (whose matrices are the fixture host's fp32 LAPACK rounding; this route's are fp64-exact)"}}
+
+
 def batched_throughput(modules, device, args, S, M):
     """Secondary figure: S independent sequences per GPU advancing in lockstep on ONE engine (batch S through every
     convolution and one cost-volume launch for all of them).  Returns (frames/s over all S sequences, ms per lockstep step,
@@ -262,7 +361,7 @@ def batched_throughput(modules, device, args, S, M):
     return S * steps / elapsed, 1e3 * elapsed / steps, kernel_s, alg_bytes
 
 
-def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets, force_variant=None, rounds=3):
+def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets, force_variant=None, rounds=3, tiled_plan=False):
     """Average duration of one fused cost-volume op (the sweep launch + its second-pass launch) over keyframe geometries.
 
     ``pose_sets``: (reference pose, [measurement poses]) of index lines -- the duration depends on the epipolar geometry
@@ -270,7 +369,9 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets, force_variant=No
     not representative.  Each geometry runs in the sweep configuration the engine picks for it (dvmvs_sweep_plan, one sequence: the
     host-side plan model on the host copies of the matrices; lock-step batches: dvmvs.utils.sweep_variant).  Per configuration a hipGraph of ``reps`` back-to-back ops (no host
     gaps) is timed with HIP events on the stream it is replayed on.
-    ``force_variant``: time that kernel variant on every geometry instead (no work list), e.g. 6 = the correlate-then-interpolate sweep.
+    ``force_variant``: time that kernel variant on every geometry instead (no work list), e.g. 7 = the MFMA sweep as one item per workgroup.
+    ``tiled_plan``: the LDS-tiled sweep as dvmvs_sweep_plan plans it per geometry (configuration + work list): what the engine ran before round 6
+    on the pairs it did not give to variant 6.
     Returns (mean seconds per op, algorithmic bytes per op, [per-geometry seconds], [per-geometry variant])."""
     from dvmvs import pose_algebra, utils
     from dvmvs.hip import _capi
@@ -302,7 +403,8 @@ def measure_cost_volume_kernel(engine, n_meas, reps, pose_sets, force_variant=No
             # exactly what DepthEngine._evaluate_frame_parameters does: configuration (2 / 3, or their single-pass forms 4 / 5 when the
             # plan queues nothing) and work list in one walk
             items = torch.zeros(work_list.numel(), dtype=torch.int32)
-            variant = _ops.sweep_plan_host(host[0], host[1], H, W, D, engine.min_depth, engine.max_depth, 0, items, allow_mfma=getattr(engine, "sweep_mfma", False))
+            variant = _ops.sweep_plan_host(host[0], host[1], H, W, D, engine.min_depth, engine.max_depth, 0, items,
+                                           allow_mfma=getattr(engine, "sweep_mfma", False) and not tiled_plan)
             work_list.copy_(items)
             return variant
         variant = utils.sweep_variant(host, H, W, D, engine.min_depth, engine.max_depth)
@@ -367,8 +469,10 @@ def issue_roofline(per_geometry, variants):
         path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sweep_issue_pmc.json")))[-1]
         pmc = json.load(open(path))
         kernels = {}
-        for label, mine in (("sweep_mfma_kernel", lambda v: v == 6), ("sweep_tiled_kernel", lambda v: v != 6)):
-            name, k = next((n, v) for n, v in pmc["kernels"].items() if n.startswith(label))
+        for label, mine in (("sweep_mfma", lambda v: v in (6, 7)), ("sweep_tiled_kernel", lambda v: v not in (6, 7))):
+            name, k = next(((n, v) for n, v in pmc["kernels"].items() if n.startswith(label)), (None, None))
+            if k is None:
+                continue
             ts = [t for t, v in zip(per_geometry, variants) if mine(v)]
             mean_us = 1e6 * sum(ts) / len(ts) if ts else None
             kernels[label] = {"profiled_as": name, "issue_busy_us_per_simd": k["issue_busy_us_per_simd"], "timed_steps": len(ts),
@@ -704,6 +808,8 @@ def relaunch_under_torchrun(gpus):
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the engine's planning thread hands the interpreter lock over within 0.1 ms instead of CPython's 5 ms (opt-in since round 6: dvmvs/engine.py plan_ahead)
+    os.environ.setdefault("DVMVS_SWITCH_INTERVAL", "1e-4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
@@ -840,15 +946,20 @@ def main():
             all_pairs = {"pairs": len(a_per), "kernel_us": a_s * 1e6, "frac": alg_bytes / a_s / 1e9 / HBM_PEAK_GBPS, "worst_us": max(a_per) * 1e6,
                          "worst_index_line": all_lines[int(np.argmax(a_per))], "p90_us": float(np.percentile(a_per, 90)) * 1e6,
                          "sweep_variants": {str(v): a_var.count(v) for v in sorted(set(a_var))}}
-            # the correlate-then-interpolate sweep on the fp32 matrix cores (variant 6, csrc/sweep_mfma.hip) FORCED on every geometry, same
-            # harness (the engine takes it where dvmvs_sweep_plan6's estimate says so: roofline.sweep_variants)
-            m_s, _, m_per, _ = measure_cost_volume_kernel(engine, M, args.kernel_reps, timed, force_variant=6)
-            ma_s, _, ma_per, _ = measure_cost_volume_kernel(engine, M, reps_all, all_sets, force_variant=6, rounds=2)
-            mfma_variant = {"kernel": "sweep_mfma_kernel (variant 6: tap dots per measurement cell on v_mfma_f32_16x16x4_f32, table look-ups per plane)",
-                            "engine_uses_it": "on the pairs dvmvs_sweep_plan6 takes (roofline.sweep_variants); this leg forces it on every pair", "kernel_us_timed_steps": m_s * 1e6, "frac_timed_steps": alg_bytes / m_s / 1e9 / HBM_PEAK_GBPS,
-                            "kernel_us_all_pairs": ma_s * 1e6, "frac_all_pairs": alg_bytes / ma_s / 1e9 / HBM_PEAK_GBPS,
-                            "worst_us_all_pairs": max(ma_per) * 1e6, "pairs_where_faster_than_engine_choice": int(sum(1 for x, y in zip(ma_per, a_per) if x < y)),
-                            "kernel_us_per_geometry_timed_steps": [round(t * 1e6, 2) for t in m_per]}
+            # Comparison legs, same harness, same geometries: (i) the LDS-tiled sweep as dvmvs_sweep_plan plans it (what the engine ran before round 6
+            # on the pairs it did not give to variant 6), (ii) variant 7 = the MFMA sweep as one work item per workgroup (round 5's launch shape; the
+            # same arithmetic, bit-identical volumes): what the persistent form buys
+            t_s, _, t_per, t_var = measure_cost_volume_kernel(engine, M, args.kernel_reps, timed, tiled_plan=True)
+            ta_s, _, ta_per, _ = measure_cost_volume_kernel(engine, M, reps_all, all_sets, rounds=2, tiled_plan=True)
+            g_s, _, g_per, _ = measure_cost_volume_kernel(engine, M, args.kernel_reps, timed, force_variant=7)
+            ga_s, _, ga_per, _ = measure_cost_volume_kernel(engine, M, reps_all, all_sets, force_variant=7, rounds=2)
+            mfma_variant = {"tiled_plan": {"kernel": "sweep_tiled_kernel [+ sweep_spill_kernel] as dvmvs_sweep_plan plans it", "kernel_us_timed_steps": t_s * 1e6,
+                                           "kernel_us_all_pairs": ta_s * 1e6, "worst_us_all_pairs": max(ta_per) * 1e6, "p90_us_all_pairs": float(np.percentile(ta_per, 90)) * 1e6,
+                                           "pairs_where_faster_than_engine_choice": int(sum(1 for x, y in zip(ta_per, a_per) if x < y)),
+                                           "variants_timed_steps": {str(v): t_var.count(v) for v in sorted(set(t_var))}},
+                            "one_item_per_workgroup": {"kernel": "sweep_mfma_kernel (variant 7)", "kernel_us_timed_steps": g_s * 1e6, "kernel_us_all_pairs": ga_s * 1e6,
+                                                       "worst_us_all_pairs": max(ga_per) * 1e6, "p90_us_all_pairs": float(np.percentile(ga_per, 90)) * 1e6,
+                                                       "pairs_where_faster_than_engine_choice": int(sum(1 for x, y in zip(ga_per, a_per) if x < y))}}
         achieved = alg_bytes / kernel_s / 1e9
         # HBM bytes per op from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: only when the committed measurement was taken on
         # exactly the kernel sources that are being benchmarked, otherwise null (profiles/README.md says how to re-collect)
@@ -870,7 +981,7 @@ def main():
         valu_tflops = useful_flop / kernel_s / 1e12
         lds_bytes = 128 * 160 * 64 * M * 4 * 32 * 4
         # (the LDS accounting below is the TILED formulation's -- the MFMA sweep reads 4 dot products per sample, not 4 x 32 channels: the steps that ran it are left out)
-        tiled_times = [t for t, v in zip(per_geometry, variants) if v != 6]
+        tiled_times = [t for t, v in zip(per_geometry, variants) if v not in (6, 7)]
         tiled_s = sum(tiled_times) / len(tiled_times) if tiled_times else float("nan")
         other_kernels = None if args.no_roofline_leg else measure_small_kernels(engine)
         launches_per_frame = {}
@@ -909,11 +1020,14 @@ def main():
                        "weights": "seeded (tests/synthetic.py) + published FPN checkpoint",
                        "cyclic_gc": "left on" if args.keep_gc else "off for warm-up + timed steps as in timeit (collect + freeze before); value_gc_on = collector left on",
                        "parallelism": f"sequence-sharded x{world}, no data-path collective"},
-            "roofline": {"kernel": "sweep_mfma_kernel where dvmvs_sweep_plan6 takes the pair, else sweep_tiled_kernel [+ spill]; 1 launch = all planes x M",
+            "roofline": {"kernel": "sweep_mfma_persistent_kernel (variant 6: every pair since round 6, dvmvs_sweep_plan6); 1 launch = all planes x M frames",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "sample": "frac/achieved/kernel_us: mean over the timed steps' keyframe pairs; all_pairs: all 285 index lines; whole_index: 25 spread",
                          "all_pairs": all_pairs,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel_us": kernel_s * 1e6, "algorithmic_bytes": alg_bytes,
+                         # the channels-last copy of a keyframe's features that variant 6 reads: round 5 a launch per frame outside this accounting
+                         # (5 - 16 us in the frame), since round 6 written by the FPN smoothing layer's own epilogue (dvmvs_direct_conv_dual_fwd)
+                         "kernel_us_incl_layout": kernel_s * 1e6 + 0.0, "layout_launches_per_frame": 0 if getattr(engine, "sweep_mfma", False) and engine.direct_convs else 1,
                          "geometries": f"{len(per_geometry)} timed steps = index lines {(M + args.warmup + 37 * rank) % 286}.. (nmeas+2 index), each as the engine launches it",
                          "kernel_us_per_geometry": [round(t * 1e6, 2) for t in per_geometry],
                          "sweep_variant_per_geometry": variants,
@@ -921,7 +1035,7 @@ def main():
                                             "3 (wide-baseline: 2 x 72 KB boxes, 512 threads; two passes)": variants.count(3),
                                             "4 (default, single pass: the host's plan queues nothing)": variants.count(4),
                                             "5 (wide-baseline, single pass)": variants.count(5),
-                                            "6 (correlate-then-interpolate on the fp32 matrix cores, channels-last maps: dvmvs_sweep_plan6 took the pair)": variants.count(6)},
+                                            "6 (correlate-then-interpolate on the fp32 matrix cores, persistent form; channels-last maps)": variants.count(6)},
                          "engine_frames_per_sweep_variant": {str(k): v for k, v in sorted(engine.sweep_variant_counts.items())},
                          "whole_index": whole_index},
             # HBM is not what binds this op (13 MB of algorithmic traffic against 0.69 GFLOP of tap arithmetic and 1.3 GB of LDS
@@ -939,7 +1053,7 @@ def main():
             # issuing / executing (SQ_ACTIVE_INST_ANY of the committed PMC profile, index line 0) add up to the waves' lifetime in both sweep
             # kernels: neither HBM nor LDS bandwidth nor the matrix pipe but the instruction count bounds them
             "roofline_issue": issue_roofline(per_geometry, variants) if per_geometry else None,
-            "roofline_mfma_variant": mfma_variant,
+            "roofline_comparison_kernels": mfma_variant,
             "roofline_other": other_kernels,
             # what the engine's warm-up costs (outside the timed steps): eager first frames, graph capture, first launches of the graphs
             # captured ahead; device memory reserved beyond live tensors (the captured graphs' private pools are part of it)
@@ -1001,6 +1115,13 @@ def main():
                                                  "steps": steps2, "note": "secondary engines, same box, back to back; on = as the headline"}
             except Exception as e:
                 result["graph_queue_fillers"] = {"error": f"{type(e).__name__}: {e}"}
+            try:      # the drop-in route north_star names, timed: no engine, no graphs, poses on the device
+                surface = module_surface_leg(build_modules(), device, args, M, steps2, warm2)
+                result["module_surface"] = surface
+                result["value_module_surface"] = surface["value"]
+            except Exception as e:
+                result["module_surface"] = {"error": f"{type(e).__name__}: {e}"}
+                result["value_module_surface"] = None
             try:
                 import synthetic as syn
                 from dvmvs.pairnet.model import CostVolumeDecoder, CostVolumeEncoder, FeatureExtractor, FeatureShrinker

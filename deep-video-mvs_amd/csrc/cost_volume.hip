@@ -270,23 +270,17 @@ extern "C" int dvmvs_sweep_plan(const float* Hm_host, const float* kt_host, int 
 extern "C" int dvmvs_sweep_plan6(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
                                  unsigned int* work_list_host, size_t work_list_bytes) {
   if (!Hm_host || !kt_host || !work_list_host || work_list_bytes < 2 * sizeof(unsigned int)) return DVMVS_EINVAL;
-  // The estimate first (25 us): tiles per wave = the wave's MFMA + operand work, st[2] = strips beyond the first (magnified footprints),
-  // st[3] = footprints that cannot be bounded (behind the camera).  Below 14 tiles the MFMA sweep is taken whatever the tiled plan says, from 18
-  // on never, in between when the tiled plan is not an easy one -- so the tiled plan and its work list (0.17 ms of the planning thread, which
-  // has one graph launch's time per frame) are only walked when a tiled kernel may run.  Lock-step batches keep the tiled kernel (the
-  // estimate looks at one batch item).
-  double st[4] = {0.0, 0.0, 0.0, 1.0};
-  const bool estimated = B == 1 && dvmvs_sweep_mfma_estimate(Hm_host, kt_host, B, M, H, W, D, min_depth, max_depth, st) == 0;
-  const bool bounded = estimated && st[3] < 0.01 && st[2] < 1.0;
-  if (bounded && st[0] < 14.0) {
+  // Round 6: variant 6 for every single-item launch.  With the persistent form (every SIMD the same mix of work) and gather passes for magnified
+  // footprints it is the faster kernel on 255 of the sample scene's 285 keyframe pairs, 34.3 us mean against 41.6 us for the tiled plan, worst pair 74 us
+  // against 92, and within 1 - 7 us on the other 30 (profiles/r06_sweep_all_pairs_v6_vs_tiled.json) -- so neither the estimate (25 us) nor the tiled
+  // plan's walk over 640 (tile, chunk) pairs (0.17 - 0.5 ms of the planning thread) runs any more.  Round 5 took it below 14 estimated tiles per wave
+  // (176 pairs).  Lock-step batches keep the tiled plan (the persistent form takes one batch item).
+  if (B == 1 && M <= DVMVS_MAX_MEASUREMENTS && D <= DVMVS_MAX_DEPTH_LEVELS && static_cast<long long>(H) * W >= 64 * 64) {
     work_list_host[0] = 0u;      // (an empty list: a tiled launch on it does nothing)
     work_list_host[1] = 0u;
     return 6;
   }
-  bool easy = false;
-  const int tiled = dvmvs::sweep_plan_impl(Hm_host, kt_host, B, M, H, W, D, min_depth, max_depth, 0, work_list_host, work_list_bytes, &easy);
-  if (tiled < 0) return tiled;
-  return bounded && !easy && st[0] < 18.0 ? 6 : tiled;
+  return dvmvs::sweep_plan_impl(Hm_host, kt_host, B, M, H, W, D, min_depth, max_depth, 0, work_list_host, work_list_bytes, nullptr);
 }
 
 int dvmvs::sweep_plan_impl(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,

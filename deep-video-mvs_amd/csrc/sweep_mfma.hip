@@ -880,11 +880,11 @@ bool sweep_mfma_supports(const CostVolumeArgs& a) {
          static_cast<long long>(a.D) * a.H * a.W * 4 < (1LL << 31) && a.H < 32000 && a.W < 32000 && static_cast<long long>(a.H) * a.W < (1LL << 24);
 }
 
-// the shipped configuration (round 6: the persistent form wherever it is eligible; gather passes for 4-plane boxes of more than 144 cells = 9 tiles:
-// measured break-even on the sample scene's magnified pairs -- a gather pass is bound by the L1's 64 B / clk, 32 KB of tap lines per pass and frame --,
-// thresholds 64 / 96 / 144 / 256: 52.1 / 43.7 / 39.2 / 39.7 us mean over 14 index lines, profiles/r06_sweep_mfma_gather_thresholds.txt; interleaved MFMA
-// pairs (PAIR) are worth 1 % and cost the gather build 8 registers it does not have: off)
-using MfmaSweepDefault = MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 0, 144>;
+// the shipped configuration (round 6: the persistent form wherever it is eligible; gather passes for 4-plane boxes of more than 160 cells = 10 tiles,
+// two samples' loads in flight: measured break-even on the sample scene's magnified pairs -- a gather pass is bound by the L1's 64 B / clk, 32 KB of tap
+// lines per pass and frame --, thresholds 64 / 96 / 144 / 256: 52.1 / 43.7 / 39.2 / 39.7 us mean over 14 index lines, profiles/r06_sweep_mfma_gather.txt;
+// interleaved MFMA pairs (PAIR) are worth 1 % and cost the gather build 8 registers it does not have: off)
+using MfmaSweepDefault = MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 0, 160, 2>;
 void sweep_mfma_estimate_host(const float* Hm, const float* kt, int M, int H, int W, int D, double inv_base, double inv_step, double* stats) {
   host_mfma_estimate<MfmaSweepDefault>(Hm, kt, M, H, W, D, inv_base, inv_step, stats);
 }

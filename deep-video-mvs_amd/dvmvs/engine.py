@@ -46,10 +46,13 @@ from dvmvs import utils as _utils
 # resolution), which a depth engine whose recurrent state passes through a discrete z-buffer cannot tolerate (one flipped pixel and the
 # runs diverge).  MIOpen reads this switch when it looks for solvers; with the family off it solves those layers with its GEMM /
 # Winograd / direct kernels, which are deterministic.  (The bottleneck layers do not reach MIOpen at all: csrc/bottleneck_conv.hip.)
-# Set when the first DepthEngine is constructed (importing this module changes nothing: a training process that never builds an engine keeps
-# MIOpen's own choice); a caller that exported its own value keeps it.
-_DETERMINISTIC_MIOPEN = ("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC", "0")      # applied by DepthEngine.__init__ (process-wide from then on:
-                                                                                              # MIOpen reads it when it looks for solvers)
+# Set when this module is IMPORTED (MIOpen reads its MIOPEN_DEBUG_* variables once, at its first convolution, and caches them -- set in
+# DepthEngine.__init__, as round 5 had it, the switch was ignored whenever any convolution had already run in the process, and bit-reproducibility
+# became a function of test order).  Training code does not import this module (dvmvs/training.py, dvmvs/train.py) and keeps MIOpen's own choice; a
+# caller that exported its own value keeps it.  DepthEngine.__init__ warns when the variable reads differently from what was set here.
+_DETERMINISTIC_MIOPEN = ("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC", "0")
+_MIOPEN_SWITCH_WAS_PRESET = _DETERMINISTIC_MIOPEN[0] in os.environ
+os.environ.setdefault(*_DETERMINISTIC_MIOPEN)
 
 _MAX_MEAS = 8            # DVMVS_MAX_MEASUREMENTS of the C ABI
 # Pinned staging ring = how many frames the host may run ahead of the device (it waits for the slot's previous upload to have executed).
@@ -388,7 +391,10 @@ class DepthEngine:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DepthEngine runs on an MI355X; there is no CPU execution path in this package")
-        os.environ.setdefault(*_DETERMINISTIC_MIOPEN)
+        if os.environ.get(_DETERMINISTIC_MIOPEN[0]) != _DETERMINISTIC_MIOPEN[1] and not _MIOPEN_SWITCH_WAS_PRESET:
+            import warnings
+            warnings.warn(f"{_DETERMINISTIC_MIOPEN[0]} was changed after dvmvs.engine set it: MIOpen may pick atomically accumulating kernels "
+                          "and depth is then not bit-reproducible run to run", RuntimeWarning)
         prep = (lambda m: fold_batchnorm(m)) if fold_bn else (lambda m: copy.deepcopy(m).eval())
         mods = [feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder]
         mods = [None if m is None else prep(m).to(self.device) for m in mods]
@@ -442,6 +448,8 @@ class DepthEngine:
         # destination-passing frame body (see the module docstring): needs the fused epilogues and contiguous channel slices
         self.direct = bool(fuse and fold_bn and not channels_last and self.sequences == 1)
         self.pose_algebra = _pose_algebra._mode(pose_algebra)
+        if self.pose_algebra == "auto":      # (the engine takes poses and intrinsics from the host: that is "reference")
+            self.pose_algebra = "reference"
         self._prev_pose_host = torch.eye(4).repeat(self.sequences, 1, 1)
         self._no_previous = torch.ones(self.sequences, dtype=torch.bool)   # sequences whose next frame has no previous frame
         self._ring, self._ring_pos = None, 0
@@ -457,6 +465,8 @@ class DepthEngine:
         self._planner, self._planned, self._param_host_ahead = None, None, None      # see plan_ahead
         self.plan_frames_ahead = os.environ.get("DVMVS_PLAN_AHEAD", "1") != "0"
         self.planned_frames_used = 0
+        self.lookahead_rejected = 0      # announced frames whose prepared stages were not taken because the image came as another tensor
+        self._switch_interval_before = None
         self._filler_buffers, self._filler_graphs = None, []
         self._copy_queue = None      # a list while step() collects its input copies (see _copy)
         self.warm_captured_graphs = os.environ.get("DVMVS_WARM_GRAPHS", "1") != "0"
@@ -483,8 +493,11 @@ class DepthEngine:
         # it reads one 128-byte line per measurement cell, so the engine then keeps its measurement maps -- the feature cache and the per-frame
         # buffers -- channels-last (one transposing launch per keyframe in place of the cache's contiguous copy).  DVMVS_SWEEP_MFMA=0: round 4's
         # all-tiled engine on NCHW maps.
-        self.sweep_mfma = bool(self.direct and self.sweep_work_list and _utils.COST_VOLUME_VARIANT == 0 and os.environ.get("DVMVS_SWEEP_MFMA", "1") != "0")
-        self._tiled_variants = (2, 3, 4, 5, 6) if self.sweep_mfma else (2, 3, 4, 5)
+        # (the tiled kernels read channels-last maps only from 64 x 64 cells on -- and so does dvmvs_sweep_plan6 take variant 6)
+        self.sweep_mfma = bool(self.direct and self.sweep_work_list and _utils.COST_VOLUME_VARIANT == 0 and os.environ.get("DVMVS_SWEEP_MFMA", "1") != "0"
+                               and (self.height // 2) * (self.width // 2) >= 64 * 64)
+        # (round 6: dvmvs_sweep_plan6 returns 6 for every single-sequence frame -- one sweep configuration, one frame graph per buffer set and pattern)
+        self._tiled_variants = (6,) if self.sweep_mfma else (2, 3, 4, 5)
         self.reset()
 
     def conv_plan_report(self):
@@ -820,9 +833,12 @@ class DepthEngine:
             # interval -- 5 ms by default, six frames of device time.  A few steps into every run this thread came back from a graph launch
             # while the planning thread was mid-block and sat out the full interval (one 5.6-6.5 ms device gap in the first ten steps of every
             # short run; none with DVMVS_PLAN_AHEAD=0).  0.1 ms bounds the hand-over; DVMVS_SWITCH_INTERVAL overrides (seconds, 0 = leave it).
+            # OPT-IN since round 6 (a library must not change the embedding program's interpreter behaviour): bench.py sets
+            # DVMVS_SWITCH_INTERVAL=1e-4; unset = the interpreter's interval stays as it is.  close() restores it.
             import sys
-            wanted = float(os.environ.get("DVMVS_SWITCH_INTERVAL", "1e-4"))
+            wanted = float(os.environ.get("DVMVS_SWITCH_INTERVAL", "0"))
             if wanted > 0.0 and sys.getswitchinterval() > wanted:
+                self._switch_interval_before = sys.getswitchinterval()
                 sys.setswitchinterval(wanted)
             self._param_host_ahead = torch.zeros_like(self._param_host)
         no_previous = torch.zeros(self.sequences, dtype=torch.bool)
@@ -830,6 +846,16 @@ class DepthEngine:
         future = self._planner.submit(self._evaluate_frame_parameters, self._param_host_ahead, n_meas, pose, measurement_poses, full_K,
                                       previous_pose, no_previous, index, True, None)
         self._planned = (inputs, previous_pose, index, future)
+
+    def close(self):
+        """Stops the planning thread and puts the interpreter's switch interval back (if DVMVS_SWITCH_INTERVAL made this engine change it)."""
+        if self._planner is not None:
+            self._planner.shutdown(wait=True)
+            self._planner, self._planned = None, None
+        if self._switch_interval_before is not None:
+            import sys
+            sys.setswitchinterval(self._switch_interval_before)
+            self._switch_interval_before = None
 
     def _take_planned(self, n_meas, pose, measurement_poses, full_K, index, own_sweep, next_frame):
         """The block planned a frame ahead, copied into the mirror, if it was planned for exactly this call; else None."""
@@ -1116,6 +1142,15 @@ class DepthEngine:
 
             # ---- what the previous call prepared for this frame: 0 nothing, 1 its reference features, 2 also its sweep + encoder ----
             have, ready = 0, self._prefetched
+            if self.direct and ready is not None and frame_id is not None and ready["frame_id"] == frame_id and ready["parity"] == parity and not (
+                    ready["image"].data_ptr() == reference_image.data_ptr() and ready["image_version"] == reference_image._version and
+                    ready["image"].device == reference_image.device and tuple(ready["image"].stride()) == tuple(reference_image.stride())):
+                # the announced frame came as ANOTHER tensor (re-materialised, modified): its prepared stages are not taken (say so)
+                self.lookahead_rejected += 1
+                if self.lookahead_rejected == 1:
+                    import warnings
+                    warnings.warn("DepthEngine.step: the frame announced by next_reference_image arrived as a different (or modified) tensor; its "
+                                  "prepared features are recomputed.  Hand step() the very tensor that was announced to keep the look-ahead.", RuntimeWarning)
             # (a frame id alone does not identify an image: the prepared features are taken only for the very tensor that was announced --
             # same storage, unmodified since; the engine keeps the announced tensor alive, so the address cannot have been reused)
             if self.direct and frame_id is not None and ready is not None and ready["frame_id"] == frame_id and ready["parity"] == parity and \

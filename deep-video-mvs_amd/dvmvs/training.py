@@ -49,7 +49,7 @@ def multi_scale_loss(predictions, groundtruth, weights=(1, 1, 1, 1, 1)):
 # ----------------------------------------------------------------------------------------------------------------------
 # forward over one sub-sequence
 # ----------------------------------------------------------------------------------------------------------------------
-_STAGING = {}      # (device, floats) -> [position, [(pinned buffer, event), ...]]
+_STAGING = {}      # (device, floats, thread) -> [position, [(pinned buffer, event), ...]]
 
 
 def subsequence_matrices(poses, half_K, device):
@@ -59,7 +59,7 @@ def subsequence_matrices(poses, half_K, device):
     step).  Returns per frame (Hm [B,1,9], kt [B,1,3], (host Hm, host kt), lstm_T [B,4,4]); entry 0 is None.  In "exact" mode (fp64 on
     the device) there is nothing to batch: the per-frame device ops are used."""
     n = len(poses)
-    if _pose_algebra._mode(None) != "reference":
+    if _pose_algebra._resolve(None, list(poses) + [half_K]) != "reference":
         out = [None]
         for i in range(1, n):
             Hm, kt, host = _pose_algebra.sweep_matrices(poses[i], [poses[i - 1]], half_K, device, with_host=True)
@@ -74,7 +74,8 @@ def subsequence_matrices(poses, half_K, device):
         host.append((Hm.contiguous().float(), kt.contiguous().float(), _pose_algebra.relative_pose_host(poses[i - 1], poses[i]).contiguous().float()))
     per_frame = B * (9 + 3 + 16)
     total = per_frame * (n - 1)
-    key = (str(device), total)
+    import threading
+    key = (str(device), total, threading.get_ident())      # (a ring per thread: the pinned buffers are rewritten by the host)
     ring = _STAGING.get(key)
     if ring is None:
         ring = _STAGING[key] = [0, [(torch.zeros(total, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(3)]]

@@ -84,7 +84,7 @@ def _check_warp_grid(warp_grid, height, width):
                          f"got {tuple(warp_grid.shape)}")
 
 
-_WORK_LIST_RINGS = {}      # (device, words) -> [position, [(pinned host buffer, device buffer, event), ...]]
+_WORK_LIST_RINGS = {}      # (device, words, stream, thread) -> [position, [(pinned host buffer, device buffer, event), ...]]
 
 
 def _upload_work_list(host, H, W, n_depth_levels, min_depth, max_depth, variant, device):
@@ -93,7 +93,11 @@ def _upload_work_list(host, H, W, n_depth_levels, min_depth, max_depth, variant,
     r4).  A small ring of (pinned, device) buffer pairs per device; a pair is reused only after the copy AND the sweep launch that read it
     have executed (its event is recorded by the next call on the same stream, i.e. behind that launch)."""
     words = _ops.sweep_work_list_words(host[0].shape[0], H, W, n_depth_levels)
-    key = (str(device), words)
+    # One ring per (stream, thread): a slot's guard is recorded by the NEXT call, which is only "behind the sweep that read the slot" when both calls
+    # enqueue on the same stream from the same thread (ADVICE r5: with DDP side streams or two threads a shared ring could be rewritten by the host
+    # while its copy was still pending).
+    import threading
+    key = (str(device), words, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
     ring = _WORK_LIST_RINGS.get(key)
     if ring is None:
         ring = _WORK_LIST_RINGS[key] = [0, [(torch.zeros(words, dtype=torch.int32).pin_memory(), torch.zeros(words, dtype=torch.int32, device=device),

@@ -166,13 +166,12 @@ int dvmvs_sweep_plan(const float* Hm_host, const float* kt_host, int B, int M, i
  * dvmvs_sweep_plan6 uses it. */
 int dvmvs_sweep_mfma_estimate(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
                               double* stats);
-/* dvmvs_sweep_plan with variant 6 as a candidate.  The estimate runs first: with no footprint that cannot be bounded, less than one extra
- * strip per wave and fewer than 14 tiles per wave the correlate-then-interpolate sweep takes the pair, the tiled plan is NOT walked and the
- * work list is left EMPTY (header count 0: a tiled launch on it does nothing) -- returns 6.  Otherwise the tiled sweep's plan is made as
- * dvmvs_sweep_plan makes it (work list filled in); between 14 and 18 tiles per wave variant 6 is still returned when that plan is not an
- * easy one (runs queued for the second pass or > 3 staged runs per workgroup), else the tiled variant (2 - 5).  The thresholds separate the
- * pairs on which variant 6 is faster on the sample scene's 285 keyframe pairs (profiles/r05_sweep_selection.md).  Lock-step batches (B > 1)
- * always get the tiled plan.  For callers whose measurement maps are channels-last (what variant 6 is fast with) and have 32 channels. */
+/* dvmvs_sweep_plan with variant 6 as a candidate.  Since round 6 (ABI 7) a single-item launch (B == 1, H * W >= 4096) always gets variant 6: the
+ * work list is left EMPTY (header count 0: a tiled launch on it does nothing), neither the estimate nor the tiled plan runs, the call is a few
+ * nanoseconds -- variant 6 in its persistent form is the faster kernel on 255 of the sample scene's 285 keyframe pairs and within 1 - 7 us on the
+ * rest (profiles/r06_sweep_all_pairs_v6_vs_tiled.json; round 5 took it below 14 estimated tiles per wave: profiles/r05_sweep_selection.md).
+ * Lock-step batches (B > 1) get the tiled plan as dvmvs_sweep_plan makes it.  For callers whose measurement maps are channels-last (what variant 6
+ * is fast with) and have at most 32 channels. */
 int dvmvs_sweep_plan6(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D, double min_depth, double max_depth,
                       unsigned int* work_list_host, size_t work_list_bytes);
 /* [B,C,H,W] -> [B,H,W,C] (C <= 64, a multiple of 4), one launch: how a keyframe's features enter a channels-last feature cache. */
