@@ -262,7 +262,7 @@ class ModuleSurfaceLoop:
         return prediction, estimate
 
 
-def module_surface_leg(modules, device, args, M, steps, warmup):
+def module_surface_leg(modules, device, args, M, steps, warmup, accelerated=False):
     """Frames/s of ``ModuleSurfaceLoop`` on the headline workload (same synthetic sequence, same poses), timed like the other legs, with the pose
     algebra in "auto" mode (device-resident poses are served on the device in fp64, no synchronisation: dvmvs/pose_algebra.py) -- and the depth
     rel-L1 of exactly this route against the reference fixtures on the 17 golden frames, teacher-forced (the reference's own state installed)."""
@@ -271,6 +271,9 @@ def module_surface_leg(modules, device, args, M, steps, warmup):
     saved_mode = pose_algebra.MODE
     pose_algebra.MODE = "auto"
     try:
+        if accelerated:      # the same loop with ONE added line: dvmvs.engine.accelerate (BN folded, fused epilogues, MFMA convolution kernels; no graphs)
+            from dvmvs.engine import accelerate
+            modules = accelerate(*[m.to(device) for m in modules])
         loop = ModuleSurfaceLoop(modules, device)
         images, seq, full_K = synthetic_sequence(0, 32, warmup + steps + M + 2, M)
         images = [im.to(device) for im in images]
@@ -302,7 +305,8 @@ def module_surface_leg(modules, device, args, M, steps, warmup):
                     r, ms = item
                     if previous is not None:
                         k, r_prev = previous
-                        loop.lstm_state = (torch.from_numpy(zs[f"{tag}{k}_h"]).to(device), torch.from_numpy(zs[f"{tag}{k}_c"]).to(device))
+                        state_shape = (1, 512, loop.H // 32, loop.W // 32)
+                        loop.lstm_state = (torch.from_numpy(zs[f"{tag}{k}_h"]).to(device).reshape(state_shape), torch.from_numpy(zs[f"{tag}{k}_c"]).to(device).reshape(state_shape))
                         loop.previous_depth = torch.from_numpy(zs[f"{tag}{k}_depth"]).to(device).view(1, 1, loop.H, loop.W)
                         loop.previous_pose = syn.pose(r_prev).to(device)
                     d, _ = loop.step(syn.e2e_image(r).to(device), syn.pose(r).to(device), [syn.e2e_image(i).to(device) for i in ms],
@@ -312,7 +316,8 @@ def module_surface_leg(modules, device, args, M, steps, warmup):
     finally:
         pose_algebra.MODE = saved_mode
     return {"value": steps / elapsed, "unit": "frames/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
-            "route": "reference loop restated on dvmvs.utils + nn.Modules, eager, BN unfolded, no feature cache, poses + K on the device",
+            "route": ("reference loop on dvmvs.utils + accelerate(modules): BN folded, fused epilogues, MFMA convs; eager, no graphs, no feature cache" if accelerated else
+                      "reference loop restated on dvmvs.utils + nn.Modules, eager, BN unfolded, no feature cache, poses + K on the device"),
             "pose_algebra": "auto (device tensors: fp64 on the device, no synchronisation)",
             "rel_l1": {"teacher_forced": [round(v, 9) for v in rels], "teacher_forced_max": max(rels), "frames": len(rels), "target": 1e-4,
                        "note": "vs the reference fixtures (whose matrices are the fixture host's fp32 LAPACK rounding; this route's are fp64-exact)"}}
@@ -762,7 +767,7 @@ def train_mode(args, world, rank, device):
     all_poses = torch.from_numpy(syn.sample_poses()).float()
     # poses stay on the host (read by the host-side pose algebra only, dvmvs.pose_algebra)
     poses = [torch.stack([all_poses[(40 * b + 3 * i + 7 * rank) % len(all_poses)] for b in range(B)]) for i in range(T)]
-    K = torch.cat([syn.full_K(width=W, height=H)] * B).to(device)
+    K = torch.cat([syn.full_K(width=W, height=H)] * B)      # (host, like the poses: round 6 -- a device K was copied back once per step, a synchronisation)
     last = {}
 
     def step(_):
@@ -904,6 +909,7 @@ def main():
 
         def region_start():      # (host time is counted over the timed steps only: warm-up steps run eagerly and capture graphs)
             host_seconds[0], host_seconds[1] = 0.0, 0
+            engine.ring_wait_seconds = 0.0
             step_events.clear()
             if mark is not None:
                 mark()
@@ -921,6 +927,7 @@ def main():
             gc_quiet()
         elapsed = timed_region(lambda i: run_frame(M + i), args.warmup, args.steps, world, device, before=region_start, after=region_end)
         host_ms = 1e3 * host_seconds[0] / max(host_seconds[1], 1)
+        host_wait_ms = 1e3 * engine.ring_wait_seconds / max(host_seconds[1], 1)
     depth_mean = float(engine._static["depth"].mean())
     assert np.isfinite(depth_mean), "non-finite depth"
 
@@ -1007,6 +1014,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             # host time per step inside engine.step (asynchronous to the GPU: it matters only where it exceeds ms_per_step)
             "host_ms_per_step": host_ms,
+            # ... of which the step WAITED for the device at the one-slot staging ring (the host is allowed one frame ahead), and the rest: the work
+            # (parameter block, copies, hipGraphLaunch of the frame graph).  A host faster than the device shows as wait, not as a smaller total.
+            "host_wait_for_device_ms_per_step": host_wait_ms, "host_work_ms_per_step": host_ms - host_wait_ms,
             "device_ms_between_step_ends": [round(step_events[i - 1].elapsed_time(step_events[i]), 3) for i in range(1, len(step_events))],
             # (strings of the line stay below 120 characters: the driver's record truncates longer ones)
             "config": {"workload": f"fusionnet inference, 1 synthetic sequence/GPU, sample-scene keyframe poses, 320x256x64 planes, M={M}, batch 1 (configs[2])",
@@ -1119,6 +1129,9 @@ def main():
                 surface = module_surface_leg(build_modules(), device, args, M, steps2, warm2)
                 result["module_surface"] = surface
                 result["value_module_surface"] = surface["value"]
+                fast = module_surface_leg(build_modules(), device, args, M, steps2, warm2, accelerated=True)
+                result["module_surface_accelerated"] = fast
+                result["value_module_surface_accelerated"] = fast["value"]
             except Exception as e:
                 result["module_surface"] = {"error": f"{type(e).__name__}: {e}"}
                 result["value_module_surface"] = None

@@ -370,6 +370,26 @@ def fuse_epilogues(module):
     return module
 
 
+def accelerate(*modules, direct_convs=True, bottleneck_convs=True):
+    """Inference copies of the network modules for the reference's OWN per-frame loop (fusionnet/run-testing.py:151-204, pairnet alike) -- one added
+    line in the script, ``feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder = accelerate(...)`` after the
+    checkpoints are loaded: same call signatures and return values as the modules, with eval-mode BatchNorm folded into the convolutions, bias +
+    activation in the convolution's epilogue, and the dense 3x3 / 5x5 layers and the bottleneck layers on the MFMA kernels of csrc/direct_conv.hip /
+    csrc/bottleneck_conv.hip -- what DepthEngine runs per layer, without its frame-level machinery (no graphs, no feature cache, no look-ahead, no
+    destination passing).  The originals are left untouched; ``None`` entries (pairnet has no LSTM) pass through.  Eval-mode inference only."""
+    out = []
+    for m in modules:
+        if m is None:
+            out.append(None)
+            continue
+        fast = fuse_epilogues(fold_batchnorm(m))
+        for sub in fast.modules():
+            if isinstance(sub, FusedConv2d):
+                sub.direct_conv, sub.bottleneck = bool(direct_convs), bool(bottleneck_convs)
+        out.append(fast)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # frame engine
 # ----------------------------------------------------------------------------------------------------------------------
@@ -465,6 +485,7 @@ class DepthEngine:
         self._planner, self._planned, self._param_host_ahead = None, None, None      # see plan_ahead
         self.plan_frames_ahead = os.environ.get("DVMVS_PLAN_AHEAD", "1") != "0"
         self.planned_frames_used = 0
+        self.ring_wait_seconds = 0.0     # time step() spent waiting for the device at the staging ring (NOT host work: bench.py subtracts it)
         self.lookahead_rejected = 0      # announced frames whose prepared stages were not taken because the image came as another tensor
         self._switch_interval_before = None
         self._filler_buffers, self._filler_graphs = None, []
@@ -655,18 +676,7 @@ class DepthEngine:
         if self._static is None:
             # the frame's small matrices: one device buffer (one upload per frame), fixed offsets so that captured graphs keep
             # pointing at the right place; Hm / kt are sized for the ABI's maximum number of measurement frames
-            items = _ops.sweep_work_list_words(S, H // 2, W // 2, self.n_depth_levels)
-            sizes = [("Hm", S * _MAX_MEAS * 9), ("kt", S * _MAX_MEAS * 3), ("reproject_T", S * 16), ("lstm_T", S * 16),
-                     ("full_K", S * 9), ("half_K", S * 9), ("lstm_K", S * 9), ("pose", S * 16), ("prev_pose", S * 16),
-                     ("meas_pose", _MAX_MEAS * S * 16),
-                     # the sweep's work list (32-bit words, planned on the host per frame: dvmvs_sweep_work_list) rides in the same upload
-                     ("sweep_items", items),
-                     # the sweep parameters of the OTHER buffer set (look-ahead: the next frame's sweep runs during this frame)
-                     ("Hm1", S * _MAX_MEAS * 9), ("kt1", S * _MAX_MEAS * 3), ("sweep_items1", items)]
-            self._param_offsets, total = {}, 0
-            for name, n in sizes:
-                self._param_offsets[name] = (total, n)
-                total += n
+            self._param_offsets, total = self._parameter_layout(S, H, W, self.n_depth_levels)
             params = z(total)
             view = lambda name, *shape: params[self._param_offsets[name][0]:self._param_offsets[name][0] + self._param_offsets[name][1]].view(*shape)
             direct = {}
@@ -715,6 +725,24 @@ class DepthEngine:
             while len(sets[1]["meas_feat"]) < n_meas:
                 sets[1]["meas_feat"].append(zm())
 
+    @staticmethod
+    def _parameter_layout(S, H, W, n_depth_levels):
+        """({name: (offset, floats)}, total floats) of the frame's parameter block: one device buffer, one upload per frame, fixed offsets so that
+        captured graphs keep pointing at the right place; Hm / kt are sized for the ABI's maximum number of measurement frames."""
+        items = _ops.sweep_work_list_words(S, H // 2, W // 2, n_depth_levels)
+        sizes = [("Hm", S * _MAX_MEAS * 9), ("kt", S * _MAX_MEAS * 3), ("reproject_T", S * 16), ("lstm_T", S * 16),
+                 ("full_K", S * 9), ("half_K", S * 9), ("lstm_K", S * 9), ("pose", S * 16), ("prev_pose", S * 16),
+                 ("meas_pose", _MAX_MEAS * S * 16),
+                 # the sweep's work list (32-bit words, planned on the host per frame: dvmvs_sweep_work_list) rides in the same upload
+                 ("sweep_items", items),
+                 # the sweep parameters of the OTHER buffer set (look-ahead: the next frame's sweep runs during this frame)
+                 ("Hm1", S * _MAX_MEAS * 9), ("kt1", S * _MAX_MEAS * 3), ("sweep_items1", items)]
+        offsets, total = {}, 0
+        for name, n in sizes:
+            offsets[name] = (total, n)
+            total += n
+        return offsets, total
+
     def _sweep_views(self, n_meas, index=0):
         """Hm [S,n_meas,9] and kt [S,n_meas,3] views of the parameter buffer (contiguous prefixes of their regions) of buffer set ``index``."""
         S, p = self.sequences, self._static["params"]
@@ -750,7 +778,9 @@ class DepthEngine:
         mirror = self._param_host
         staging, event = self._ring[self._ring_pos]
         self._ring_pos = (self._ring_pos + 1) % len(self._ring)
-        event.synchronize()
+        t_wait = time.perf_counter()
+        event.synchronize()      # (one staging slot: the host runs at most one frame ahead of the device, so in steady state this is where a step waits for it)
+        self.ring_wait_seconds += time.perf_counter() - t_wait
         staging.copy_(mirror)
         with torch.cuda.device(self.device):     # the ring guard must be recorded on the engine's device, whichever is current
             self._static["params"].copy_(staging, non_blocking=True)

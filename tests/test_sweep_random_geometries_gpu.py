@@ -1,0 +1,127 @@
+"""Geometries that are NOT the sample scene's: 200 random relative poses -- forward motion 0 .. 0.3 m, sideways / vertical motion,
+rotations up to 15 degrees about a random axis, focal lengths +- 30 % -- at the BASELINE shape (32 x 128 x 160, 64 planes, M = 2).
+
+Since round 6 ``dvmvs_sweep_plan6`` gives every single-item launch to variant 6 (the correlate-then-interpolate sweep in its persistent form with
+gather passes, csrc/sweep_mfma.hip) instead of choosing between it and the LDS-tiled sweep from thresholds fitted to one scene.  What is checked:
+* parity on every geometry: variant 6 against the reference-order generic kernel (summation-order round-off), no unwritten element, and
+  bit-identical to its one-item-per-workgroup form (variant 7);
+* regret of "always variant 6": its duration against the tiled plan's (configuration + work list as dvmvs_sweep_plan makes them) on the same
+  geometry -- never more than 1.3 x + 3 us (the bound the verdict asked of the selector), and the mean over all geometries not above the tiled one's.
+Semantics under test: /root/reference/dvmvs/utils.py:45-107."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+B, C, H, W, D, M = 1, 32, 128, 160, 64, 2
+
+
+def random_geometry(rng):
+    """(reference pose, [measurement poses], half-resolution K): the reference camera somewhere in the sample scene, each measurement camera a random
+    rigid motion away from it, the intrinsics of the sample scene with the focal lengths scaled by 0.7 .. 1.3."""
+    ref = torch.from_numpy(syn.sample_poses()[int(rng.integers(0, 300))]).float().unsqueeze(0)
+    K = syn.scaled_K(syn.full_K(), 2.0).clone()
+    K[:, 0, 0] *= float(rng.uniform(0.7, 1.3))
+    K[:, 1, 1] *= float(rng.uniform(0.7, 1.3))
+    meas = []
+    for _ in range(M):
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        angle = math.radians(float(rng.uniform(0.0, 15.0)))
+        kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        R = np.eye(3) + math.sin(angle) * kx + (1 - math.cos(angle)) * (kx @ kx)
+        step = np.eye(4)
+        step[:3, :3] = R
+        step[:3, 3] = [rng.uniform(-0.2, 0.2), rng.uniform(-0.1, 0.1), rng.uniform(-0.3, 0.3)]      # (camera frame: x right, y down, z forward)
+        meas.append(ref @ torch.from_numpy(step).float().unsqueeze(0))
+    return ref, meas, K
+
+
+def test_variant_6_on_random_geometries_parity_and_regret(hip_device):
+    from dvmvs import pose_algebra
+    from dvmvs.hip import _capi, ops
+    dev = hip_device
+    lib = _capi.lib()
+    rng = np.random.default_rng(20260601)
+    f1 = syn.smooth_noise((B, C, H, W), seed=900).to(dev)
+    meas = [syn.smooth_noise((B, C, H, W), seed=901 + i).to(dev).contiguous(memory_format=torch.channels_last) for i in range(M)]
+    img_ptrs = _capi.pointer_array([t.data_ptr() for t in meas])
+    meas_nchw = [t.contiguous() for t in meas]      # (the generic reference-order kernel reads NCHW maps)
+    img_ptrs_nchw = _capi.pointer_array([t.data_ptr() for t in meas_nchw])
+    workspace, ws_bytes = ops.sweep_workspace(dev, B, M, H, W, D)
+    words = ops.sweep_work_list_words(B, H, W, D)
+    out = torch.empty(B, D, H, W, device=dev)
+    Hm_d, kt_d = torch.zeros(B, M, 9, device=dev), torch.zeros(B, M, 3, device=dev)
+    items_d = torch.zeros(words, dtype=torch.int32, device=dev)
+
+    def launch(variant, with_list):
+        rc = lib.dvmvs_cost_volume_planned_fwd(f1.data_ptr(), img_ptrs_nchw if variant == 1 else img_ptrs, Hm_d.data_ptr(), kt_d.data_ptr(), out.data_ptr(),
+                                               B, M, C, H, W, D, 0.25, 20.0, 1, variant, _capi.LAYOUT_NCHW if variant == 1 else _capi.LAYOUT_NHWC,
+                                               workspace.data_ptr(), ws_bytes, items_d.data_ptr() if with_list else None,
+                                               torch.cuda.current_stream().cuda_stream)      # (the capture stream while a graph is being captured)
+        _capi.check(rc, "dvmvs_cost_volume_planned_fwd")
+
+    graphs = {}
+
+    def microseconds(variant, with_list, reps=5):
+        key = (variant, with_list)
+        if key not in graphs:
+            launch(variant, with_list)
+            torch.cuda.synchronize()
+            graphs[key] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graphs[key]):
+                for _ in range(reps):
+                    launch(variant, with_list)
+        g = graphs[key]
+        g.replay()
+        torch.cuda.synchronize()
+        best = float("inf")
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b) * 1e3 / reps)
+        return best
+
+    t6, tt, worst_ratio, checked = [], [], (0.0, None), 0
+    for trial in range(200):
+        ref, ms, K = random_geometry(rng)
+        Hm, kt = pose_algebra.sweep_matrices_host(ref, ms, K)
+        Hm_d.copy_(Hm)
+        kt_d.copy_(kt)
+        plan = torch.zeros(words, dtype=torch.int32)
+        assert ops.sweep_plan_host(Hm, kt, H, W, D, 0.25, 20.0, 0, plan.clone(), allow_mfma=True) == 6      # what the engine launches
+        tiled = ops.sweep_plan_host(Hm, kt, H, W, D, 0.25, 20.0, 0, plan)                                  # the tiled plan of the same geometry
+        assert tiled in (2, 3, 4, 5)
+        items_d.copy_(plan)
+        # ---- parity ----
+        out.fill_(float("nan"))
+        launch(6, False)
+        six = out.clone()
+        assert not torch.isnan(six).any(), trial
+        if trial % 4 == 0:      # (the generic kernel takes 100 - 200 us: every fourth geometry)
+            launch(1, False)
+            assert float((six - out).abs().max()) < 3e-5, trial
+            out.fill_(float("nan"))
+            launch(7, False)
+            assert torch.equal(six, out), trial
+            checked += 1
+        # ---- regret ----
+        a, b = microseconds(6, False), microseconds(tiled, True)
+        t6.append(a)
+        tt.append(b)
+        if a / b > worst_ratio[0]:
+            worst_ratio = (a / b, trial)
+        assert a <= 1.3 * b + 3.0, (trial, a, b)
+    t6, tt = np.array(t6), np.array(tt)
+    print(f"\n200 random geometries: variant 6 mean {t6.mean():.1f} us (p90 {np.percentile(t6, 90):.1f}, worst {t6.max():.1f}); tiled plan mean {tt.mean():.1f} us "
+          f"(p90 {np.percentile(tt, 90):.1f}, worst {tt.max():.1f}); worst ratio {worst_ratio[0]:.2f} (trial {worst_ratio[1]}); variant 6 faster on "
+          f"{int((t6 < tt).sum())}; parity-checked {checked}")
+    assert t6.mean() <= tt.mean()
