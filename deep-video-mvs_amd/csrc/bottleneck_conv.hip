@@ -113,8 +113,50 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
   // Weights of CH groups of 16 input channels (9 float4 each) are requested in one straight-line burst and consumed group by group:
   // the wave waits for the first nine loads only (the compiler counts the newer ones: s_waitcnt vmcnt(9 * (CH - 1))) while the rest
   // arrive behind 180 MFMAs per group.  The product launches CH = 1 (see launch_bottleneck_conv for the measurement).
-  for (int g0 = 0; g0 < groups; g0 += CH) {
-    float4v w[CH][9];
+  if constexpr (CH == 0) {
+    // Rolling double buffer (round 6): the nine requests of group g + 1 are issued BEFORE the 180 MFMAs of group g and waited for behind them --
+    // two register sets that swap roles, the loop unrolled by two, the request behind the last group issued out of range (no traffic, no
+    // condition around a request: the compiler's s_waitcnt placement then waits for exactly the older nine).  Round 4's bursts (CH = 1 / 2 / 4
+    // groups requested together, consumed together) left a wave waiting for its weights at the head of every group with only the other wave of
+    // its SIMD to cover it: 34.1 us for the ConvLSTM layer = 56 % of the MFMA rate.  Same MFMAs in the same order: bit-identical partial sums.
+    const unsigned int packed_bytes = static_cast<unsigned int>(sizeof(float4v)) * static_cast<unsigned int>(a.n_tiles) * static_cast<unsigned int>(a.C_in / 16) * (9u * 64u);
+    const __amdgpu_buffer_rsrc_t w_resource = __builtin_amdgcn_make_buffer_rsrc((void*)as_global(a.packed), 0, static_cast<int>(packed_bytes), 0x00020000);
+    const unsigned int w_base = static_cast<unsigned int>(sizeof(float4v)) * ((static_cast<unsigned int>(n_tile) * static_cast<unsigned int>(a.C_in / 16) +
+                                                                               static_cast<unsigned int>(c0 / 16)) * (9u * 64u) + static_cast<unsigned int>(lane));
+    auto request_taps = [&](float4v (&w)[9], int g) {
+      const unsigned int vo = g < groups ? w_base + static_cast<unsigned int>(g) * (9u * 64u * 16u) : 0x80000000u;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        w[t] = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(w_resource, static_cast<int>(vo + (g < groups ? static_cast<unsigned int>(t) * (64u * 16u) : 0u)), 0, 0));
+    };
+    auto consume = [&](const float4v (&w)[9], int g) {
+      const float* xc = xs + g * 16 * PLANE;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int toff = (t / 3) * PW + (t % 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int pt = 0; pt < kBcPT; ++pt)
+            acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][j], xc[j * 4 * PLANE + pix[pt] + toff], acc[pt], 0, 0, 0);
+        }
+      }
+    };
+    float4v wa[9], wb[9];
+    request_taps(wa, 0);
+    for (int g = 0; g < groups; g += 2) {
+      request_taps(wb, g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(wa, g);
+      __builtin_amdgcn_sched_barrier(0);
+      request_taps(wa, g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < groups) consume(wb, g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else
+  for (int g0 = 0; g0 < groups; g0 += (CH > 0 ? CH : 1)) {
+    float4v w[CH > 0 ? CH : 1][9];
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -196,8 +238,9 @@ int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
   const int groups = a.cs / 16;      // tools-only build: DVMVS_BC_CH=1|2|4 forces the request burst (tools/lstm_conv_probe.py)
   if (const char* ch = getenv("DVMVS_BC_CH")) {
     const int c = atoi(ch);
-    if (c == 1 || groups % c == 0) {
-      if (c == 1) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1>), grid, block, lds, stream, a);
+    if (c == 0 || c == 1 || groups % c == 0) {
+      if (c == 0) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 0>), grid, block, lds, stream, a);
+      else if (c == 1) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1>), grid, block, lds, stream, a);
       else if (c == 2) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 2>), grid, block, lds, stream, a);
       else hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 4>), grid, block, lds, stream, a);
       return launch_status();

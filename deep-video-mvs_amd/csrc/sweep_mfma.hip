@@ -66,7 +66,7 @@ __device__ inline ccfloat_p as_constant(const float* p) { return (ccfloat_p)p; }
 
 // GW x GH = 16 reference pixels per wave; CAP = cells of the dot table; CPW = chunks of 16 planes a wave works through one after the
 // other (same pixels: the reference features stay in registers); WAVES = waves per SIMD the register allocation is held to.
-template <int GW_, int GH_, int CAP_, int CPW_, int WAVES_, int ABLATE_ = 0, int STAGGER_ = 0, int ORDER_ = 0, int WPB_ = 1, int NBUF_ = 2, int PAIR_ = 0, int GATHER_ = 0, int GATHER_UNROLL_ = 1>
+template <int GW_, int GH_, int CAP_, int CPW_, int WAVES_, int ABLATE_ = 0, int STAGGER_ = 0, int ORDER_ = 0, int WPB_ = 1, int NBUF_ = 2, int PAIR_ = 0, int GATHER_ = 0, int GATHER_UNROLL_ = 1, int QUARTER_ = 1>
 struct MfmaSweepConfig {
   static constexpr int GW = GW_, GH = GH_, CAP = CAP_, CPW = CPW_, WAVES = WAVES_;
   // Round 6.  WPB: waves per workgroup.  One-wave workgroups (round 5) are handed to the SIMDs of a CU unevenly -- 4 to 7 of a launch's waves per SIMD
@@ -80,6 +80,8 @@ struct MfmaSweepConfig {
   // table -- under magnification (forward motion onto near planes) the box of 16 pixels x 4 planes is mostly empty: up to 50 tiles for 256 taps, and
   // one such item alone used to last 100 us.  The gather costs what ~6 tiles cost, whatever the footprint.
   static constexpr int GATHER = GATHER_, GATHER_UNROLL = GATHER_UNROLL_;      // (samples of a gather pass whose loads are in flight together)
+  static constexpr int QUARTER = QUARTER_;      // persistent form: the last four queue entries of a workgroup are handed out as quarter items (else whole)
+  static_assert(GATHER == 0 || GATHER >= 2 * CAP_, "quarter items and whole items must take the same path per sample: see sweep_mfma_item");
   static constexpr int STAGGER = STAGGER_;             // 1: s_setprio by wave slot (waves of a SIMD leave lockstep: one's MFMA phase beside another's VALU phase)
   static constexpr int ORDER = ORDER_;                 // 1: within an XCD far chunks (more tiles) first
   static constexpr int ABLATE = ABLATE_;               // tools only (timing experiments, wrong results): 1 no operand loads, 2 no MFMAs, 4 no interpolation
@@ -179,13 +181,22 @@ __device__ __forceinline__ void sweep_mfma_item(const CostVolumeArgs& a, int b, 
     S.alive = 0u;
     float4v kd[4];
     float ix[4], iy[4];
+    if (quarter < 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) kd[j] = ktd[m * ktd_stride + c * PW + 4 * j + q];
-    sweep_samples<2>(ray, kd, sc, ix, iy);   // clamped to [-1, W] x [-1, H]; NaN -> -1; two planes' chains interleaved
-    __builtin_amdgcn_sched_barrier(0);
-    sweep_samples<2>(ray, kd + 2, sc, ix + 2, iy + 2);
-    // (a quarter item evaluates all four samples as well: how its planes are processed -- table or gather -- is decided from the box of all 16 planes,
-    // exactly as the whole item decides it, so that a sample's arithmetic does not depend on who computes it)
+      for (int j = 0; j < 4; ++j) kd[j] = ktd[m * ktd_stride + c * PW + 4 * j + q];
+      sweep_samples<2>(ray, kd, sc, ix, iy);   // clamped to [-1, W] x [-1, H]; NaN -> -1; two planes' chains interleaved
+      __builtin_amdgcn_sched_barrier(0);
+      sweep_samples<2>(ray, kd + 2, sc, ix + 2, iy + 2);
+    } else {      // one sample per lane; the other three are dead (-1: outside the image)
+      kd[0] = ktd[m * ktd_stride + c * PW + 4 * quarter + q];
+      float tx, ty;
+      sweep_samples<1>(ray, kd, sc, &tx, &ty);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ix[j] = j == quarter ? tx : -1.0f;
+        iy[j] = j == quarter ? ty : -1.0f;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool al = live & (d_wave + c * PW + 4 * j + q < a.D) & (ix[j] > -1.0f) & (ix[j] < sc.Wf) & (iy[j] > -1.0f) & (iy[j] < sc.Hf);   // (no short-circuit: one basic block)
@@ -216,24 +227,10 @@ __device__ __forceinline__ void sweep_mfma_item(const CostVolumeArgs& a, int b, 
       // ---- passes: the 16 planes as one box; a box of more than SPLIT x CAP cells (diagonal or fast epipolar motion: the box is
       // mostly empty) is redone per 4 planes.  A box is processed in STRIPS of CAP cells of its row-major index space: one strip
       // almost always; several under strong magnification, where a tap simply belongs to the strip that holds its cell ----
-      int n_pass = 1;
-      bool split = false;      // the item's 16-plane box exceeds SPLIT x CAP cells: its planes are processed 4 at a time, each pass through the table or as a gather
-      if (quarter >= 0) {
-        // a quarter item: the whole item's decision first (box of all alive samples), then only pass `quarter` of the four
-        int lo = 0x7fff7fff, hi = static_cast<int>(0x80008000u);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if ((S.alive >> j) & 1u) {
-            lo = pk_min_i16(lo, S.xy[j]);
-            hi = pk_max_i16(hi, S.xy[j]);
-          }
-        const int hi_u = wave_reduce_pk_i16<true>(hi);
-        if (hi_u == static_cast<int>(0x80008000u)) continue;
-        const int lo_u = wave_reduce_pk_i16<false>(lo);
-        const int bw16 = static_cast<short>(hi_u & 0xffff) + 1 - static_cast<short>(lo_u & 0xffff) + 1, bh16 = (hi_u >> 16) + 1 - (lo_u >> 16) + 1;
-        split = bw16 * bh16 > Cfg::SPLIT * CAP;
-        n_pass = 4;
-      }
+      // A quarter item is pass `quarter` of the four 4-plane passes.  Whether a 4-plane pass goes through the table or is gathered depends on ITS box
+      // alone (more than GATHER cells: gather), and GATHER >= SPLIT x CAP, so a whole item that fits one 16-plane pass (<= SPLIT x CAP cells, hence every
+      // 4-plane sub-box too) and its quarter items take the same path for every sample: a sample's arithmetic does not depend on who computes it.
+      int n_pass = quarter < 0 ? 1 : 4;
       for (int s = quarter < 0 ? 0 : quarter; s < (quarter < 0 ? n_pass : quarter + 1); ++s) {
         const int jlo = n_pass == 1 ? 0 : s, jhi = n_pass == 1 ? 4 : s + 1;
         MFMA_TRACE(const unsigned long long tr_b0 = __builtin_amdgcn_s_memtime();)
@@ -254,11 +251,10 @@ __device__ __forceinline__ void sweep_mfma_item(const CostVolumeArgs& a, int b, 
         const int bw = static_cast<short>(hi_u & 0xffff) + 1 - x_lo + 1, bh = (hi_u >> 16) + 1 - y_lo + 1, cells = bw * bh;
         if (n_pass == 1 && cells > Cfg::SPLIT * CAP) {
           n_pass = 4;
-          split = true;
           s = -1;
           continue;
         }
-        if (Cfg::GATHER > 0 && split && cells > Cfg::GATHER) {
+        if (Cfg::GATHER > 0 && n_pass == 4 && cells > Cfg::GATHER) {
           // ---- gather pass: no table.  The four lanes (p, 0..3) of a pixel hold its four samples of this pass (planes 4 s + q) and one channel
           // octet each (f1v: channels 8 q ..): every lane takes ITS octet of all four samples of its pixel -- positions through the wave's LDS slice,
           // 4 taps x 8 channels per sample from the map (two 16-byte loads per tap when it is channels-last), per tap the dot with f1v, the taps
@@ -281,8 +277,9 @@ __device__ __forceinline__ void sweep_mfma_item(const CostVolumeArgs& a, int b, 
           float* P = T + 256;      // [pixel][sample q'][octet q]: behind the 64 sample records
           const unsigned int cell_b = NHWC ? static_cast<unsigned int>(C) * 4u : 4u, row_b = static_cast<unsigned int>(a.W) * cell_b;
           const unsigned int octet_b = NHWC ? 32u * q : 8u * q * plane_bytes;
-#pragma unroll Cfg::GATHER_UNROLL
-          for (int qq = 0; qq < 4; ++qq) {      // (not fully unrolled: 8 - 32 operand registers in flight per sample are what the kernel has left)
+          constexpr int kGatherUnroll = NHWC ? Cfg::GATHER_UNROLL : 1;
+#pragma unroll kGatherUnroll
+          for (int qq = 0; qq < 4; ++qq) {      // (not fully unrolled: 8 - 32 operand registers in flight per sample are what the kernel has left; NCHW maps: one)
             const float4v smp = X[p * 4 + qq];
             const int xy = __builtin_bit_cast(int, smp.x);
             const int x0 = static_cast<short>(xy & 0xffff), y0 = xy >> 16;
@@ -668,7 +665,7 @@ __global__ __launch_bounds__(1024, 4) void sweep_mfma_persistent_kernel(CostVolu
     const int full_rounds = g_space / lists, left_items = (g_space - full_rounds * lists) * chunks;
     const int n_full = chunks * full_rounds;
     const int n_end = n_full + (left_items + lists - 1) / lists;
-    const int entries = 4 * (n_end - 4), quartered = min(entries, 4), whole = entries - quartered;
+    const int entries = 4 * (n_end - 4), quartered = Cfg::QUARTER ? min(entries, 4) : 0, whole = entries - quartered;
     int l_, n, quarter = -1;
     if (handed < 0) {
       l_ = 4 * wg_in_xcd + (wave & 3);
@@ -880,11 +877,12 @@ bool sweep_mfma_supports(const CostVolumeArgs& a) {
          static_cast<long long>(a.D) * a.H * a.W * 4 < (1LL << 31) && a.H < 32000 && a.W < 32000 && static_cast<long long>(a.H) * a.W < (1LL << 24);
 }
 
-// the shipped configuration (round 6: the persistent form wherever it is eligible; gather passes for 4-plane boxes of more than 160 cells = 10 tiles,
-// two samples' loads in flight: measured break-even on the sample scene's magnified pairs -- a gather pass is bound by the L1's 64 B / clk, 32 KB of tap
-// lines per pass and frame --, thresholds 64 / 96 / 144 / 256: 52.1 / 43.7 / 39.2 / 39.7 us mean over 14 index lines, profiles/r06_sweep_mfma_gather.txt;
-// interleaved MFMA pairs (PAIR) are worth 1 % and cost the gather build 8 registers it does not have: off)
-using MfmaSweepDefault = MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 0, 160, 2>;
+// the shipped configuration (round 6: the persistent form wherever it is eligible; gather passes for 4-plane boxes of more than 256 cells = 16 tiles,
+// two samples' loads in flight.  Measured on the sample scene's magnified pairs -- a gather pass is bound by the L1's 64 B / clk, 32 KB of tap lines per
+// pass and frame --, thresholds 64 / 96 / 144 / 256: 52.1 / 43.7 / 39.2 / 39.7 us mean over 14 index lines (profiles/r06_sweep_mfma_gather.txt); 256 =
+// SPLIT x CAP is the smallest threshold for which whole and quarter items agree on every sample's path without evaluating each other's boxes.
+// Interleaved MFMA pairs (PAIR) are worth 1 % and cost the gather build 8 registers it does not have: off)
+using MfmaSweepDefault = MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 0, 256, 2>;
 void sweep_mfma_estimate_host(const float* Hm, const float* kt, int M, int H, int W, int D, double inv_base, double inv_step, double* stats) {
   host_mfma_estimate<MfmaSweepDefault>(Hm, kt, M, H, W, D, inv_base, inv_step, stats);
 }
@@ -947,15 +945,10 @@ int launch_sweep_mfma_tuning(int which, const CostVolumeArgs& a, hipStream_t str
     case 43: return sweep_mfma_persistent_eligible<MfmaSweepConfig<4, 4, 128, 1, 4>>(a) ? launch_sweep_mfma_persistent_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 0>>(a, stream) : DVMVS_EUNSUPPORTED;
     case 44: return sweep_mfma_persistent_eligible<MfmaSweepConfig<4, 4, 128, 1, 4>>(a) ? launch_sweep_mfma_persistent_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 1>>(a, stream) : DVMVS_EUNSUPPORTED;
     // gather passes (thresholds in cells of a 4-plane box), persistent form
-    case 45: return sweep_mfma_persistent_eligible<MfmaSweepConfig<4, 4, 128, 1, 4>>(a) ? launch_sweep_mfma_persistent_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 1, 64>>(a, stream) : DVMVS_EUNSUPPORTED;
-    case 46: return sweep_mfma_persistent_eligible<MfmaSweepConfig<4, 4, 128, 1, 4>>(a) ? launch_sweep_mfma_persistent_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 1, 96>>(a, stream) : DVMVS_EUNSUPPORTED;
-    case 47: return sweep_mfma_persistent_eligible<MfmaSweepConfig<4, 4, 128, 1, 4>>(a) ? launch_sweep_mfma_persistent_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 1, 144>>(a, stream) : DVMVS_EUNSUPPORTED;
+    case 54: return sweep_mfma_persistent_eligible<MfmaSweepConfig<4, 4, 128, 1, 4>>(a) ? launch_sweep_mfma_persistent_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 0, 256, 2, 0>>(a, stream) : DVMVS_EUNSUPPORTED;      // no quarter items
+    case 55: return sweep_mfma_persistent_eligible<MfmaSweepConfig<4, 4, 128, 1, 4>>(a) ? launch_sweep_mfma_persistent_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 0, 256, 2, 1>>(a, stream) : DVMVS_EUNSUPPORTED;      // = shipped
+    case 56: return sweep_mfma_persistent_eligible<MfmaSweepConfig<4, 4, 128, 1, 4>>(a) ? launch_sweep_mfma_persistent_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 0, 0, 1, 1>>(a, stream) : DVMVS_EUNSUPPORTED;        // no gather passes
     case 48: return sweep_mfma_persistent_eligible<MfmaSweepConfig<4, 4, 128, 1, 4>>(a) ? launch_sweep_mfma_persistent_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 1, 256>>(a, stream) : DVMVS_EUNSUPPORTED;
-    case 49: return launch_sweep_mfma_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 1, 96>>(a, stream);      // one item per workgroup, gather passes
-    case 51: return sweep_mfma_persistent_eligible<MfmaSweepConfig<4, 4, 128, 1, 4>>(a) ? launch_sweep_mfma_persistent_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 0, 144, 2>>(a, stream) : DVMVS_EUNSUPPORTED;
-    case 52: return sweep_mfma_persistent_eligible<MfmaSweepConfig<4, 4, 128, 1, 4>>(a) ? launch_sweep_mfma_persistent_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 0, 192, 2>>(a, stream) : DVMVS_EUNSUPPORTED;
-    case 53: return sweep_mfma_persistent_eligible<MfmaSweepConfig<4, 4, 128, 1, 4>>(a) ? launch_sweep_mfma_persistent_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 0, 112, 2>>(a, stream) : DVMVS_EUNSUPPORTED;
-    case 50: return sweep_mfma_persistent_eligible<MfmaSweepConfig<4, 4, 128, 1, 4>>(a) ? launch_sweep_mfma_persistent_cfg<MfmaSweepConfig<4, 4, 128, 1, 4, 0, 0, 1, 1, 2, 0, 96>>(a, stream) : DVMVS_EUNSUPPORTED;
     default: return DVMVS_EINVAL;
   }
 }
