@@ -60,7 +60,7 @@ def main():
                                          for f in ("sweep_tiled.hip", "sweep_mfma.hip", "cost_volume.hip", "plane_sweep.h", "sweep_sample.h"))).hexdigest()
         mean = lambda key: sum(v[key] for v in per_line.values()) / len(per_line)
         payload = {
-            "kernel": "one cost-volume op as the engine launches it: dvmvs::sweep_mfma_kernel where dvmvs_sweep_plan6 takes it, else dvmvs::sweep_tiled_kernel + dvmvs::sweep_spill_kernel",
+            "kernel": "one cost-volume op as the engine launches it: dvmvs::sweep_mfma_persistent_kernel (variant 6: every single-sequence frame since round 6, dvmvs_sweep_plan6)",
             "shape": [1, 2, 32, 128, 160, 64], "shape_meaning": "B, M, C, H, W, D",
             "how": "tools/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over tools/cv_microbench.py "
                    "--variants engine --layouts nhwc --reps 2 on index lines 153 (easy), 118 (median), 165 (worst); per-dispatch means, both kernels added; KiB",
@@ -69,9 +69,10 @@ def main():
             "hbm_bytes_per_launch": 1024.0 * (mean("FETCH_SIZE_KiB") + mean("WRITE_SIZE_KiB")),
             "algorithmic_bytes_per_launch": 13107200,
             "kernel_sources_sha256": digest,
-            "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced streams by 2x; the tiled kernel stages with "
-                    "4 B/lane buffer loads (no calibration in the guide), the MFMA sweep reads its operands with 16 B/lane loads of scattered 128-byte cells, not a "
-                    "coalesced stream: the raw counter is reported (upper bound: FETCH x 2).",
+            "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced streams by 2x; the MFMA sweep reads its operands with "
+                    "16 B/lane loads of scattered 128-byte cells, not a coalesced stream (no calibration in the guide): the raw counter is reported (upper bound: FETCH x 2). "
+                    "Round 6: FETCH rose from 6.6 MB (round 5: XCD-contiguous image bands) to 12 MB -- every XCD now owns four 4-row strips spread over the image "
+                    "(point-symmetric row sets: the load balance of DESIGN.md section 4.1c), so each measurement map is fetched into more L2s; 12 MB is 1.5 us at 8 TB/s.",
         }
         with open(os.path.join(dst, f"{rnd}_cost_volume_pmc.json"), "w") as f:
             json.dump(payload, f, indent=1)
