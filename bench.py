@@ -262,7 +262,7 @@ class ModuleSurfaceLoop:
         return prediction, estimate
 
 
-def module_surface_leg(modules, device, args, M, steps, warmup, accelerated=False):
+def module_surface_leg(modules, device, args, M, steps, warmup, accelerated=False, graphs=False):
     """Frames/s of ``ModuleSurfaceLoop`` on the headline workload (same synthetic sequence, same poses), timed like the other legs, with the pose
     algebra in "auto" mode (device-resident poses are served on the device in fp64, no synchronisation: dvmvs/pose_algebra.py) -- and the depth
     rel-L1 of exactly this route against the reference fixtures on the 17 golden frames, teacher-forced (the reference's own state installed)."""
@@ -273,7 +273,7 @@ def module_surface_leg(modules, device, args, M, steps, warmup, accelerated=Fals
     try:
         if accelerated:      # the same loop with ONE added line: dvmvs.engine.accelerate (BN folded, fused epilogues, MFMA convolution kernels; no graphs)
             from dvmvs.engine import accelerate
-            modules = accelerate(*[m.to(device) for m in modules])
+            modules = accelerate(*[m.to(device) for m in modules], graphs=graphs)
         loop = ModuleSurfaceLoop(modules, device)
         images, seq, full_K = synthetic_sequence(0, 32, warmup + steps + M + 2, M)
         images = [im.to(device) for im in images]
@@ -316,7 +316,8 @@ def module_surface_leg(modules, device, args, M, steps, warmup, accelerated=Fals
     finally:
         pose_algebra.MODE = saved_mode
     return {"value": steps / elapsed, "unit": "frames/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
-            "route": ("reference loop on dvmvs.utils + accelerate(modules): BN folded, fused epilogues, MFMA convs; eager, no graphs, no feature cache" if accelerated else
+            "route": ("reference loop on dvmvs.utils + accelerate(modules, graphs=True): as accelerate() + one hipGraph replay per module call; no feature cache" if graphs else
+                      "reference loop on dvmvs.utils + accelerate(modules): BN folded, fused epilogues, MFMA convs; eager, no graphs, no feature cache" if accelerated else
                       "reference loop restated on dvmvs.utils + nn.Modules, eager, BN unfolded, no feature cache, poses + K on the device"),
             "pose_algebra": "auto (device tensors: fp64 on the device, no synchronisation)",
             "rel_l1": {"teacher_forced": [round(v, 9) for v in rels], "teacher_forced_max": max(rels), "frames": len(rels), "target": 1e-4,
@@ -1132,6 +1133,9 @@ def main():
                 fast = module_surface_leg(build_modules(), device, args, M, steps2, warm2, accelerated=True)
                 result["module_surface_accelerated"] = fast
                 result["value_module_surface_accelerated"] = fast["value"]
+                graphed = module_surface_leg(build_modules(), device, args, M, steps2, max(warm2, 6), accelerated=True, graphs=True)
+                result["module_surface_accelerated_graphs"] = graphed
+                result["value_module_surface_accelerated_graphs"] = graphed["value"]
             except Exception as e:
                 result["module_surface"] = {"error": f"{type(e).__name__}: {e}"}
                 result["value_module_surface"] = None

@@ -370,13 +370,87 @@ def fuse_epilogues(module):
     return module
 
 
-def accelerate(*modules, direct_convs=True, bottleneck_convs=True):
+class GraphedModule(nn.Module):
+    """An inference module whose forward is replayed as ONE hipGraph per input signature (shapes of its tensor arguments): the first call with a
+    signature runs eagerly (MIOpen picks its solvers, the MFMA kernels pack their weights), the second captures, later ones copy the arguments into
+    the graph's static input buffers (one batched launch: dvmvs_copy_batch) and replay.  Positional and keyword TENSOR arguments only (that is what the
+    reference's loop passes to its modules).  Outputs are the graph's static output buffers -- valid until the next call with the same signature --
+    or fresh copies of them (``clone_outputs``: for modules whose results of several calls are alive at once, e.g. the feature shrinker of a loop that
+    computes the measurement frames' and the reference frame's features one after the other).  Same kernels on the same inputs as the wrapped
+    module: bit-identical results."""
+
+    def __init__(self, module, clone_outputs=False):
+        super().__init__()
+        self.module, self.clone_outputs = module, clone_outputs
+        self._seen, self._graphs = set(), {}
+
+    def forward(self, *args, **kwargs):
+        names = sorted(kwargs)
+        tensors = list(args) + [kwargs[k] for k in names]
+        if torch.is_grad_enabled() or not all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors) or torch.cuda.is_current_stream_capturing():
+            return self.module(*args, **kwargs)
+        key = (len(args), tuple(names)) + tuple((tuple(t.shape), t.dtype) for t in tensors)
+        entry = self._graphs.get(key)
+        if entry is None:
+            if key not in self._seen:      # first sight: eager (warm-up)
+                self._seen.add(key)
+                return self.module(*args, **kwargs)
+            static_in = [torch.empty_like(t, memory_format=torch.contiguous_format) for t in tensors]
+            for d, t in zip(static_in, tensors):
+                d.copy_(t)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.module(*static_in[:len(args)], **dict(zip(names, static_in[len(args):])))
+            entry = self._graphs[key] = (graph, static_in, out)
+        graph, static_in, out = entry
+        pending = []
+        for d, t in zip(static_in, tensors):
+            if t.data_ptr() == d.data_ptr():
+                continue
+            if _ops.batchable(d, t):
+                pending.append((d, t))
+                if len(pending) == 8:
+                    _ops.copy_batch(pending)
+                    pending = []
+            else:
+                d.copy_(t)
+        if len(pending) == 1:
+            pending[0][0].copy_(pending[0][1])
+        elif pending:
+            _ops.copy_batch(pending)
+        graph.replay()
+        if not self.clone_outputs:
+            return out
+        return self._clone(out)
+
+    @staticmethod
+    def _clone(out):
+        if isinstance(out, torch.Tensor):
+            return out.clone()
+        flat = [t for t in out if isinstance(t, torch.Tensor)]
+        fresh = [torch.empty_like(t) for t in flat]
+        pairs = [(d, t) for d, t in zip(fresh, flat)]
+        if all(_ops.batchable(d, t) for d, t in pairs) and 1 < len(pairs) <= 8:
+            _ops.copy_batch(pairs)
+        else:
+            for d, t in pairs:
+                d.copy_(t)
+        it = iter(fresh)
+        return type(out)(next(it) if isinstance(t, torch.Tensor) else t for t in out)
+
+
+def accelerate(*modules, direct_convs=True, bottleneck_convs=True, graphs=False):
     """Inference copies of the network modules for the reference's OWN per-frame loop (fusionnet/run-testing.py:151-204, pairnet alike) -- one added
     line in the script, ``feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder = accelerate(...)`` after the
     checkpoints are loaded: same call signatures and return values as the modules, with eval-mode BatchNorm folded into the convolutions, bias +
     activation in the convolution's epilogue, and the dense 3x3 / 5x5 layers and the bottleneck layers on the MFMA kernels of csrc/direct_conv.hip /
     csrc/bottleneck_conv.hip -- what DepthEngine runs per layer, without its frame-level machinery (no graphs, no feature cache, no look-ahead, no
-    destination passing).  The originals are left untouched; ``None`` entries (pairnet has no LSTM) pass through.  Eval-mode inference only."""
+    destination passing).  The originals are left untouched; ``None`` entries (pairnet has no LSTM) pass through.  Eval-mode inference only.
+    ``graphs=True``: every module except the LSTM fusion (a handful of launches, None-able arguments) is additionally wrapped in a ``GraphedModule``
+    -- its forward becomes one hipGraph replay per call (the eager loop is host-bound: 728 launches per frame at ~12 us of host time each); the
+    modules of which several results are alive at once in the reference's loop (feature extractor / shrinker: measurement frames, then the
+    reference frame) return copies."""
     out = []
     for m in modules:
         if m is None:
@@ -387,6 +461,15 @@ def accelerate(*modules, direct_convs=True, bottleneck_convs=True):
             if isinstance(sub, FusedConv2d):
                 sub.direct_conv, sub.bottleneck = bool(direct_convs), bool(bottleneck_convs)
         out.append(fast)
+    if graphs:
+        from dvmvs.fusionnet.model import LSTMFusion
+        wrapped = []
+        for position, m in enumerate(out):
+            if m is None or isinstance(m, LSTMFusion):
+                wrapped.append(m)
+            else:      # the first two modules of the scripts' lists are the feature extractor and the feature shrinker
+                wrapped.append(GraphedModule(m, clone_outputs=position == 1))
+        out = wrapped
     return out
 
 

@@ -1,0 +1,55 @@
+"""The drop-in routes of INTEGRATION.md section A on the GPU: the reference's per-frame loop (fusionnet/run-testing.py:151-204, restated in
+bench.py: ModuleSurfaceLoop) on (a) the plain module surface, (b) ``dvmvs.engine.accelerate`` (BatchNorm folded, fused epilogues, MFMA convolution
+kernels), (c) ``accelerate(graphs=True)`` (each module call one hipGraph replay).  (c) must equal (b) bit for bit -- same kernels on the same
+inputs --, (b) must equal (a) to BatchNorm-folding round-off, over a sequence that exercises the eager / capture / replay calls of every graph, a
+state reset, and measurement features that stay alive across calls of the same module."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")))
+
+
+def _run(loop, frames, dev):
+    fullK = syn.full_K().to(dev)
+    depths = []
+    with torch.no_grad():
+        for item in frames:
+            if item is None:
+                loop.reset()
+                continue
+            r, ms = item
+            d, _ = loop.step(syn.e2e_image(r).to(dev), syn.pose(r).to(dev), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i).to(dev) for i in ms], fullK)
+            depths.append(d.reshape(256, 320).clone())
+    return depths
+
+
+def test_accelerated_and_graphed_module_loops(hip_device):
+    import bench
+    from dvmvs import pose_algebra
+    from dvmvs.engine import GraphedModule, accelerate
+    dev = hip_device
+    frames = list(syn.E2E_FRAMES) + [None] + list(syn.E2E_FRAMES) + [syn.E2E_FRAMES[1]]
+    saved = pose_algebra.MODE
+    pose_algebra.MODE = "auto"      # device-resident poses, as the scripts have them: no synchronisation
+    try:
+        plain = _run(bench.ModuleSurfaceLoop(bench.build_modules(), dev), frames, dev)
+        fast = _run(bench.ModuleSurfaceLoop(accelerate(*[m.to(dev) for m in bench.build_modules()]), dev), frames, dev)
+        graphed_modules = accelerate(*[m.to(dev) for m in bench.build_modules()], graphs=True)
+        assert sum(isinstance(m, GraphedModule) for m in graphed_modules) == 4
+        graphed = _run(bench.ModuleSurfaceLoop(graphed_modules, dev), frames, dev)
+    finally:
+        pose_algebra.MODE = saved
+    assert all(len(m._graphs) >= 1 for m in graphed_modules if isinstance(m, GraphedModule))      # every wrapped module did replay a graph
+    for n, (a, b, c) in enumerate(zip(plain, fast, graphed)):
+        assert torch.equal(b, c), n                                                               # graphs change nothing
+        rel = float(((a - b).abs() / a.abs()).mean())
+        assert rel < 1e-4, (n, rel)                                                               # BatchNorm folding + other convolution kernels
+        assert np.isfinite(float(c.mean()))
