@@ -609,8 +609,11 @@ __global__ __launch_bounds__(64 * Cfg::WPB, Cfg::WAVES) void sweep_mfma_kernel(C
 // Correctness does not depend on where the hardware puts workgroups or waves; the balance does (observed behaviour, ROCm 7.2).
 struct MfmaPersistentPlan {
   unsigned int groups_x_reciprocal;   // g / groups_x == mulhi(g, r) for g < 2^16
+  unsigned int chunks_reciprocal;     // n / chunks likewise
   int rows_per_xcd;                   // 2 ceil(groups_y / 16): local group rows of an XCD (some beyond the image when groups_y is no multiple of 16)
   int d_pad;                          // planes rounded up to whole chunks: the frame stride of the shared K t / depth table
+  // launch constants of the item enumeration (made on the host: six integer divisions per item were ~240 scalar instructions of a wave's ~900)
+  int chunks, lists, g_space, full_rounds, left_items, n_full, n_end;
 };
 
 template <class Cfg, bool NHWC, bool FULL>
@@ -658,13 +661,9 @@ __global__ __launch_bounds__(1024, 4) void sweep_mfma_persistent_kernel(CostVolu
   // that nothing of it is alive across the item, whose registers are the kernel's.)
   for (int handed = -1;;) {
     const int groups_x = (a.W + GW - 1) / GW, groups_y = (a.H + GH - 1) / GH;
-    const int chunks = plan.d_pad / PW;
+    const int chunks = plan.chunks, lists = plan.lists, g_space = plan.g_space, full_rounds = plan.full_rounds, left_items = plan.left_items;
+    const int n_full = plan.n_full, n_end = plan.n_end;
     const int xcd = static_cast<int>(blockIdx.x & 7), wg_in_xcd = static_cast<int>(blockIdx.x >> 3);
-    const int lists = 4 * static_cast<int>(gridDim.x >> 3);                         // per XCD
-    const int g_space = plan.rows_per_xcd * groups_x;
-    const int full_rounds = g_space / lists, left_items = (g_space - full_rounds * lists) * chunks;
-    const int n_full = chunks * full_rounds;
-    const int n_end = n_full + (left_items + lists - 1) / lists;
     const int entries = 4 * (n_end - 4), quartered = Cfg::QUARTER ? min(entries, 4) : 0, whole = entries - quartered;
     int l_, n, quarter = -1;
     if (handed < 0) {
@@ -680,13 +679,16 @@ __global__ __launch_bounds__(1024, 4) void sweep_mfma_persistent_kernel(CostVolu
     int c, v;
     bool valid = true;
     if (n < n_full) {
-      c = n % chunks;
-      v = l_ + (n / chunks) * lists;
+      const int r = chunks == 1 ? n : static_cast<int>(__umulhi(static_cast<unsigned int>(n), plan.chunks_reciprocal));      // n / chunks
+      c = n - r * chunks;
+      v = l_ + r * lists;
     } else {
       const int j = l_ + (n - n_full) * lists;
       valid = j < left_items;
-      c = j % chunks;
-      v = full_rounds * lists + j / chunks;
+      const int jj = valid ? j : 0;
+      const int e = chunks == 1 ? jj : static_cast<int>(__umulhi(static_cast<unsigned int>(jj), plan.chunks_reciprocal));      // j / chunks
+      c = jj - e * chunks;
+      v = full_rounds * lists + e;
     }
     const int gi = !valid ? 0 : ((c & 3) == 0 || (c & 3) == 3) ? v : g_space - 1 - v;
     const int k = static_cast<int>(__umulhi(static_cast<unsigned int>(gi), plan.groups_x_reciprocal));      // gi / groups_x
@@ -851,6 +853,15 @@ int launch_sweep_mfma_persistent(const CostVolumeArgs& a, hipStream_t stream) {
   plan.groups_x_reciprocal = static_cast<unsigned int>(0xffffffffu / static_cast<unsigned int>(groups_x)) + 1u;
   plan.rows_per_xcd = 2 * ((groups_y + 15) / 16);
   plan.d_pad = d_pad;
+  plan.chunks = d_pad / Cfg::PW;
+  plan.chunks_reciprocal = static_cast<unsigned int>(0xffffffffu / static_cast<unsigned int>(plan.chunks)) + 1u;
+  plan.lists = 4 * (n / 8);                                   // per XCD
+  plan.g_space = plan.rows_per_xcd * groups_x;
+  plan.full_rounds = plan.g_space / plan.lists;
+  plan.left_items = (plan.g_space - plan.full_rounds * plan.lists) * plan.chunks;
+  plan.n_full = plan.chunks * plan.full_rounds;
+  plan.n_end = plan.n_full + (plan.left_items + plan.lists - 1) / plan.lists;
+  if (plan.g_space >= 65536 || plan.left_items + plan.lists >= 65536 || plan.n_end >= 65536) return DVMVS_EUNSUPPORTED;      // (the reciprocal divisions are exact below 2^16)
   hipLaunchKernelGGL((sweep_mfma_persistent_kernel<Cfg, NHWC, FULL>), dim3(static_cast<unsigned int>(n)), dim3(1024), lds, stream, a, plan);
   return launch_status();
 }

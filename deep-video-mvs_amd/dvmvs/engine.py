@@ -46,13 +46,11 @@ from dvmvs import utils as _utils
 # resolution), which a depth engine whose recurrent state passes through a discrete z-buffer cannot tolerate (one flipped pixel and the
 # runs diverge).  MIOpen reads this switch when it looks for solvers; with the family off it solves those layers with its GEMM /
 # Winograd / direct kernels, which are deterministic.  (The bottleneck layers do not reach MIOpen at all: csrc/bottleneck_conv.hip.)
-# Set when this module is IMPORTED (MIOpen reads its MIOPEN_DEBUG_* variables once, at its first convolution, and caches them -- set in
-# DepthEngine.__init__, as round 5 had it, the switch was ignored whenever any convolution had already run in the process, and bit-reproducibility
-# became a function of test order).  Training code does not import this module (dvmvs/training.py, dvmvs/train.py) and keeps MIOpen's own choice; a
-# caller that exported its own value keeps it.  DepthEngine.__init__ warns when the variable reads differently from what was set here.
-_DETERMINISTIC_MIOPEN = ("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC", "0")
-_MIOPEN_SWITCH_WAS_PRESET = _DETERMINISTIC_MIOPEN[0] in os.environ
-os.environ.setdefault(*_DETERMINISTIC_MIOPEN)
+# Set when the PACKAGE is imported (dvmvs/__init__.py: MIOpen reads its MIOPEN_DEBUG_* variables once, at its first convolution, and caches them).
+# DepthEngine.__init__ warns when the variable reads differently from what was set there.
+import dvmvs as _package
+_DETERMINISTIC_MIOPEN = _package.DETERMINISTIC_MIOPEN
+_MIOPEN_SWITCH_WAS_PRESET = _package.MIOPEN_SWITCH_WAS_PRESET or os.environ.get("DVMVS_KEEP_MIOPEN_ATOMIC_KERNELS", "0") == "1"
 
 _MAX_MEAS = 8            # DVMVS_MAX_MEASUREMENTS of the C ABI
 # Pinned staging ring = how many frames the host may run ahead of the device (it waits for the slot's previous upload to have executed).
