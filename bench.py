@@ -949,7 +949,8 @@ def main():
                            "worst_us": max(w_per) * 1e6}
             # ... and EVERY keyframe pair of the index (285 lines; fewer repetitions per pair): the figure that does not flatter
             all_lines, all_sets = index_pose_sets(M, 10 ** 6)
-            reps_all = max(2, args.kernel_reps // 3)
+            reps_all = args.kernel_reps      # (round 6: as many back-to-back ops per graph as on the timed lines -- with 3 per graph the gap between two graph
+                                             # replays, ~5 - 10 us on the device, was 1.5 - 2 us of every op's figure)
             a_s, _, a_per, a_var = measure_cost_volume_kernel(engine, M, reps_all, all_sets, rounds=2)
             all_pairs = {"pairs": len(a_per), "kernel_us": a_s * 1e6, "frac": alg_bytes / a_s / 1e9 / HBM_PEAK_GBPS, "worst_us": max(a_per) * 1e6,
                          "worst_index_line": all_lines[int(np.argmax(a_per))], "p90_us": float(np.percentile(a_per, 90)) * 1e6,
