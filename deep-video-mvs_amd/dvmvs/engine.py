@@ -167,6 +167,11 @@ class FusedConv2d(nn.Module):
         self.direct_conv = False         # set by DepthEngine(direct_convs=True)
         self._direct_tiles = {}
         self._direct_packed = {}
+        # 1x1 layers (MnasNet expansion / projection layers, FPN lateral layers): the MFMA GEMM with bias + ReLU + residual in its store path
+        # instead of the library GEMM + epilogue launch (csrc/pointwise_conv.hip); {(input shape, activation, residual mode): taken}
+        self.pointwise_conv = False      # set by DepthEngine(pointwise_convs=True)
+        self._pointwise_taken = {}
+        self._pointwise_packed = None
 
         k = conv.kernel_size
         self.depthwise = (conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1 and k[0] == k[1] and k[0] in (3, 5)
@@ -215,6 +220,10 @@ class FusedConv2d(nn.Module):
                 return _ops.partial_sums_bias_act_into(buffers, splits, dst, self.bias, act, shape)
         if self.direct_conv and residual is None and x.is_contiguous():
             y = self._direct_forward(x, out, act, p0, p1, raw or self.defer_epilogue)
+            if y is not None:
+                return y
+        if self.pointwise_conv and x.is_contiguous() and (residual is None or residual.is_contiguous()):
+            y = self._pointwise_forward(x, out, act, residual, residual_mode if residual is not None else 0, raw or self.defer_epilogue)
             if y is not None:
                 return y
         if (self.plan_epilogue and residual is None and not raw and not self.defer_epilogue and self._plan_eligible(act)
@@ -272,6 +281,29 @@ class FusedConv2d(nn.Module):
             packed = self._direct_packed[tile] = _ops.direct_conv_pack(self.weight.detach(), tile)
         dst = out if out is not None else torch.empty((B, k[0], H // stride, W // stride), device=x.device, dtype=torch.float32)
         return _ops.direct_conv_into(x, packed, tile, bias, dst, k[0], k[2], stride, act, dst_nhwc=out_nhwc)
+
+    def _pointwise_forward(self, x, out, act, residual, residual_mode, raw):
+        """The layer through csrc/pointwise_conv.hip, or None when that kernel does not take the problem (then the library GEMM + epilogue launch
+        as before).  ``raw``: the convolution output without bias and activation (the depthwise consumer applies them)."""
+        k = self.weight.shape
+        if k[2] != 1 or k[3] != 1 or self.groups != 1 or tuple(self.stride) != (1, 1) or tuple(self.padding) != (0, 0):
+            return None
+        if raw:
+            act = _ops.ACTIVATIONS["none"]
+        key = (tuple(x.shape), act, residual_mode)
+        taken = self._pointwise_taken.get(key)
+        if taken is None:
+            B, _, H, W = x.shape
+            taken = self._pointwise_taken[key] = _ops.pointwise_conv_supported(B, k[1], H, W, k[0], act, residual_mode)
+        if not taken or x.data_ptr() % 16 != 0 or (out is not None and out.data_ptr() % 16 != 0):
+            return None
+        if self._pointwise_packed is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None      # (packed at the next eager call: the first frame of every kind runs eagerly)
+            self._pointwise_packed = _ops.pointwise_conv_pack(self.weight.detach())
+        B, _, H, W = x.shape
+        dst = out if out is not None else torch.empty((B, k[0], H, W), device=x.device, dtype=torch.float32)
+        return _ops.pointwise_conv_into(x, self._pointwise_packed, None if raw else self.bias, dst, k[0], act, residual, residual_mode)
 
     def _bottleneck_for(self, x):
         """The partial-sum buffer for this input shape if the bottleneck kernel takes the problem (else None); packs the weights the
@@ -438,12 +470,12 @@ class GraphedModule(nn.Module):
         return type(out)(next(it) if isinstance(t, torch.Tensor) else t for t in out)
 
 
-def accelerate(*modules, direct_convs=True, bottleneck_convs=True, graphs=False):
+def accelerate(*modules, direct_convs=True, bottleneck_convs=True, pointwise_convs=True, graphs=False):
     """Inference copies of the network modules for the reference's OWN per-frame loop (fusionnet/run-testing.py:151-204, pairnet alike) -- one added
     line in the script, ``feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder = accelerate(...)`` after the
     checkpoints are loaded: same call signatures and return values as the modules, with eval-mode BatchNorm folded into the convolutions, bias +
-    activation in the convolution's epilogue, and the dense 3x3 / 5x5 layers and the bottleneck layers on the MFMA kernels of csrc/direct_conv.hip /
-    csrc/bottleneck_conv.hip -- what DepthEngine runs per layer, without its frame-level machinery (no graphs, no feature cache, no look-ahead, no
+    activation in the convolution's epilogue, and the dense 3x3 / 5x5 layers, the bottleneck layers and the 1x1 layers on the MFMA kernels of
+    csrc/direct_conv.hip / csrc/bottleneck_conv.hip / csrc/pointwise_conv.hip -- what DepthEngine runs per layer, without its frame-level machinery (no graphs, no feature cache, no look-ahead, no
     destination passing).  The originals are left untouched; ``None`` entries (pairnet has no LSTM) pass through.  Eval-mode inference only.
     ``graphs=True``: every module except the LSTM fusion (a handful of launches, None-able arguments) is additionally wrapped in a ``GraphedModule``
     -- its forward becomes one hipGraph replay per call (the eager loop is host-bound: 728 launches per frame at ~12 us of host time each); the
@@ -457,7 +489,7 @@ def accelerate(*modules, direct_convs=True, bottleneck_convs=True, graphs=False)
         fast = fuse_epilogues(fold_batchnorm(m))
         for sub in fast.modules():
             if isinstance(sub, FusedConv2d):
-                sub.direct_conv, sub.bottleneck = bool(direct_convs), bool(bottleneck_convs)
+                sub.direct_conv, sub.bottleneck, sub.pointwise_conv = bool(direct_convs), bool(bottleneck_convs), bool(pointwise_convs)
         out.append(fast)
     if graphs:
         from dvmvs.fusionnet.model import LSTMFusion
@@ -488,7 +520,7 @@ class DepthEngine:
     def __init__(self, feature_extractor, feature_shrinker, cost_volume_encoder, lstm_fusion, cost_volume_decoder,
                  device="cuda", min_depth=0.25, max_depth=20.0, n_depth_levels=64, fold_bn=True, cache_features=True,
                  use_graphs=True, cache_size=None, channels_last=False, fuse=True, lstm_channels_last=True, sequences=1,
-                 pose_algebra=None, conv_plans=None, bottleneck_convs=None, direct_convs=None, max_lookahead=None):
+                 pose_algebra=None, conv_plans=None, bottleneck_convs=None, direct_convs=None, max_lookahead=None, pointwise_convs=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DepthEngine runs on an MI355X; there is no CPU execution path in this package")
@@ -530,6 +562,15 @@ class DepthEngine:
             for sub in ([] if m is None else m.modules()):
                 if isinstance(sub, FusedConv2d):
                     sub.direct_conv = self.direct_convs
+        # the 1x1 layers (feature extractor, FPN lateral layers) through the MFMA GEMM with bias + ReLU + residual in its store path
+        # (csrc/pointwise_conv.hip; DVMVS_POINTWISE_CONVS=0: library GEMM + epilogue launch as in rounds 1-5)
+        if pointwise_convs is None:
+            pointwise_convs = os.environ.get("DVMVS_POINTWISE_CONVS", "1") != "0"
+        self.pointwise_convs = bool(pointwise_convs and fuse and not channels_last)
+        for m in mods:
+            for sub in ([] if m is None else m.modules()):
+                if isinstance(sub, FusedConv2d):
+                    sub.pointwise_conv = self.pointwise_convs
         self._lstm_packed, self._lstm_partials, self._lstm_combined = None, None, None
         if lstm_channels_last and self.lstm is not None and not channels_last:
             # the ConvLSTM convolution (1024 -> 2048 channels on an 8x10 map, 75 MB of weights) is weight-bandwidth bound;

@@ -17,7 +17,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVMVS_HIP_LIB", os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libdvmvs_hip.so")))
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_MEASUREMENTS = 8
 MAX_DEPTH_LEVELS = 256
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
@@ -70,6 +70,10 @@ SIGNATURES = {
     "dvmvs_direct_conv_pack": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_direct_conv_fwd": (_c_int, [_c_fp, ctypes.c_longlong, _c_fp, _c_int, _c_fp, _c_fp, ctypes.c_longlong] + [_c_int] * 8 + [_c_stream]),
     "dvmvs_direct_conv_dual_fwd": (_c_int, [_c_fp, ctypes.c_longlong, _c_fp, _c_int, _c_fp, _c_fp, ctypes.c_longlong, _c_fp] + [_c_int] * 8 + [_c_stream]),
+    "dvmvs_pointwise_conv_supported": (_c_int, [_c_int] * 7),
+    "dvmvs_pointwise_conv_packed_bytes": (ctypes.c_size_t, [_c_int] * 2),
+    "dvmvs_pointwise_conv_pack": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_stream]),
+    "dvmvs_pointwise_conv_fwd": (_c_int, [_c_fp, ctypes.c_longlong, _c_fp, _c_fp, _c_fp, ctypes.c_longlong, _c_int, _c_fp, ctypes.c_longlong] + [_c_int] * 7 + [_c_stream]),
     "dvmvs_conv_head_fwd": (_c_int, [_c_fp, ctypes.c_longlong, _c_fp, _c_fp, _c_fp, ctypes.c_longlong] + [_c_int] * 5 + [ctypes.c_float, ctypes.c_float, _c_stream]),
     "dvmvs_partial_sums_bias_act_fwd": (_c_int, [_c_fp, _c_int, _c_fp, ctypes.c_longlong, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_depth_reproject_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int,

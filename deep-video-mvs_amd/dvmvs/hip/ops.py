@@ -825,6 +825,56 @@ def direct_conv_into(x: Tensor, packed: Tensor, n_tile: int, bias, dst: Tensor, 
     return dst
 
 
+# ---- 1x1 convolutions (csrc/pointwise_conv.hip): fp32 MFMA GEMM from the NCHW map, bias + ReLU + residual in its store path ----
+def pointwise_conv_supported(B: int, C_in: int, H: int, W: int, C_out: int, activation: int, residual_mode: int) -> bool:
+    """Whether dvmvs_pointwise_conv_fwd takes the problem (else the caller keeps its library convolution + epilogue launch)."""
+    return bool(_capi.lib().dvmvs_pointwise_conv_supported(int(B), int(C_in), int(H), int(W), int(C_out), int(activation), int(residual_mode)))
+
+
+def pointwise_conv_pack(weight: Tensor) -> Tensor:
+    """[C_out,C_in,1,1] (or [C_out,C_in]) -> the kernel's B-operand order; once per layer (the weights are constants at inference)."""
+    _dev_f32("pointwise_conv_pack", weight)
+    if weight.dim() not in (2, 4) or (weight.dim() == 4 and tuple(weight.shape[2:]) != (1, 1)):
+        raise ValueError(f"dvmvs::pointwise_conv_pack: need a [C_out,C_in,1,1] weight, got {tuple(weight.shape)}")
+    C_out, C_in = int(weight.shape[0]), int(weight.shape[1])
+    nbytes = _capi.lib().dvmvs_pointwise_conv_packed_bytes(C_out, C_in)
+    packed = torch.empty(nbytes // 4, device=weight.device, dtype=torch.float32)
+    with torch.cuda.device(weight.device):
+        rc = _capi.lib().dvmvs_pointwise_conv_pack(_ptr(weight.contiguous()), _ptr(packed), C_out, C_in, _stream(weight))
+    _capi.check(rc, "dvmvs_pointwise_conv_pack")
+    return packed
+
+
+def pointwise_conv_into(x: Tensor, packed: Tensor, bias, dst: Tensor, C_out: int, activation: int, residual=None, residual_mode: int = 0,
+                        splits: int = 0) -> Tensor:
+    """dst = act(conv1x1(x, W) + bias) + residual with ``pointwise_conv_pack``-ed weights; ``dst`` a dense [B,C_out,H,W] tensor or a channel
+    slice of a concatenation buffer; activation "none" or "relu"; ``residual`` / ``residual_mode`` as ``bias_act_into`` (1: same shape,
+    2: half resolution, nearest-up-sampled)."""
+    _dev_f32("pointwise_conv_into", x, packed, dst)
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("dvmvs::pointwise_conv_into: expected a contiguous NCHW input")
+    B, C_in, H, W = x.shape
+    C_out = int(C_out)
+    if packed.numel() * 4 != _capi.lib().dvmvs_pointwise_conv_packed_bytes(C_out, C_in):
+        raise ValueError(f"dvmvs::pointwise_conv_into: the packed weights are not those of a {C_in} -> {C_out} layer")
+    batch_stride = _slice_batch_stride("pointwise_conv_into", dst, B, C_out, H, W)
+    if bias is not None and bias.numel() not in (0, C_out):
+        raise ValueError(f"dvmvs::pointwise_conv_into: bias has {bias.numel()} entries for {C_out} channels")
+    residual_stride = 0
+    if residual_mode:
+        _dev_f32("pointwise_conv_into", residual)
+        shape = (B, C_out, H, W) if residual_mode == 1 else (B, C_out, H // 2, W // 2)
+        if tuple(residual.shape) != shape:
+            raise ValueError(f"dvmvs::pointwise_conv_into: residual of shape {tuple(residual.shape)}, mode {residual_mode} expects {shape}")
+        residual_stride = _slice_batch_stride("pointwise_conv_into", residual, *shape)
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().dvmvs_pointwise_conv_fwd(_ptr(x), 0, _ptr(packed), _ptr(bias) if bias is not None and bias.numel() else None,
+                                                  _ptr(residual) if residual_mode else None, residual_stride, int(residual_mode), _ptr(dst), batch_stride,
+                                                  B, C_in, H, W, C_out, int(activation), int(splits), _stream(x))
+    _capi.check(rc, "dvmvs_pointwise_conv_fwd")
+    return dst
+
+
 def conv_head_into(x: Tensor, weight: Tensor, bias, dst: Tensor, activation: int = 0, p0: float = 0.0, p1: float = 0.0) -> Tensor:
     """3x3, padding 1 convolution with ONE output channel (the decoder's depth heads): dst [B,1,H,W] = act(conv(x, weight) + bias);
     bias None and activation 0: the raw convolution output (the consumer applies bias + activation)."""

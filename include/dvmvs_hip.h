@@ -36,8 +36,10 @@ extern "C" {
  * ABI 7 (round 6) = ABI 6 + dvmvs_direct_conv_dual_fwd (the direct convolution with a second, channels-last copy of its output written in the
  * same epilogue: the frame engine's keyframe features reach the MFMA sweep without a transposing launch); no earlier signature changed.
  * Variant 6 of dvmvs_cost_volume_fwd runs as one persistent 16-wave workgroup per CU where the problem allows (csrc/sweep_mfma.hip): same
- * arguments, bit-identical volumes. */
-#define DVMVS_ABI_VERSION 7
+ * arguments, bit-identical volumes.
+ * ABI 8 (round 6) = ABI 7 + the 1x1 convolution with bias, ReLU and the residual add in its store path (dvmvs_pointwise_conv_*); no earlier
+ * signature changed. */
+#define DVMVS_ABI_VERSION 8
 #define DVMVS_MAX_MEASUREMENTS 8      /* measurement frames fused per launch */
 #define DVMVS_MAX_DEPTH_LEVELS 256    /* sweep planes per launch */
 
@@ -315,6 +317,29 @@ int dvmvs_direct_conv_dual_fwd(const float* x, long long x_batch_stride, const f
                                int activation, dvmvs_stream_t stream);
 int dvmvs_conv_head_fwd(const float* x, long long x_batch_stride, const float* weight, const float* bias, float* dst,
                         long long dst_batch_stride, int B, int C_in, int H, int W, int activation, float p0, float p1, dvmvs_stream_t stream);
+
+/*
+ * (ABI 8) 1x1 convolutions (stride 1, no padding, one group) of a frame as an fp32-MFMA GEMM straight from the NCHW map, with the bias add,
+ * ReLU and the residual add of dvmvs_bias_act_fwd in its store path (csrc/pointwise_conv.hip).  Replace the nn.Conv2d(k = 1) +
+ * BatchNorm(folded) (+ ReLU) (+ residual) of the MnasNet feature extractor's expansion / projection layers and of the feature pyramid's
+ * lateral layers (/root/reference/dvmvs/fusionnet/model.py:20-124; torchvision's _InvertedResidual) at inference: one launch instead of a
+ * library GEMM + an epilogue launch.  No gradient.  Deterministic: input-channel splits are added through LDS in a fixed order.
+ *   dvmvs_pointwise_conv_supported  1 when dvmvs_pointwise_conv_fwd takes the problem (C_in % 4 == 0, H*W % 4 == 0, activation 0 / 1, mode 2 only
+ *                                   for even H and W % 4 == 0), else 0: the caller keeps its library convolution
+ *   dvmvs_pointwise_conv_pack       weight [C_out,C_in] -> packed (dvmvs_pointwise_conv_packed_bytes), once per layer
+ *   dvmvs_pointwise_conv_fwd        x [B,C_in,H,W] (batch item b at x + b*x_batch_stride, 0 = dense) -> dst [B,C_out,H,W] (batch item b at
+ *                                   dst + b*dst_batch_stride, 0 = dense: a channel slice of a concatenation buffer; 16-byte aligned):
+ *                                   dst = act(conv + bias) + residual.  bias may be NULL; activation 0 none, 1 ReLU; residual_mode 0 none,
+ *                                   1 residual [B,C_out,H,W], 2 residual [B,C_out,H/2,W/2] nearest-up-sampled (batch item b at residual +
+ *                                   b*residual_batch_stride, 0 = dense) -- the meaning of dvmvs_bias_act_fwd's arguments;
+ *                                   splits: input-channel splits per output tile, 1 ... 16, 0 = chosen from the problem size
+ */
+int dvmvs_pointwise_conv_supported(int B, int C_in, int H, int W, int C_out, int activation, int residual_mode);
+size_t dvmvs_pointwise_conv_packed_bytes(int C_out, int C_in);
+int dvmvs_pointwise_conv_pack(const float* weight, float* packed, int C_out, int C_in, dvmvs_stream_t stream);
+int dvmvs_pointwise_conv_fwd(const float* x, long long x_batch_stride, const float* packed, const float* bias, const float* residual,
+                             long long residual_batch_stride, int residual_mode, float* dst, long long dst_batch_stride, int B, int C_in,
+                             int H, int W, int C_out, int activation, int splits, dvmvs_stream_t stream);
 
 /*
  * Forward splat (z-buffer, farthest wins) of the previous full-resolution depth into the current view at half
