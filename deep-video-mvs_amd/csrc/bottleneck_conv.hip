@@ -56,11 +56,18 @@ __host__ __device__ inline int bottleneck_splits(int B, int C_out, int C_in, int
 }
 
 // CH: groups of 16 input channels whose weights are requested together; the split's group count is a multiple of it
-template <int H_IN, int W_IN, int STRIDE, int CH>
+template <int H_IN, int W_IN, int STRIDE, int CH, bool WINDOW = false>
 __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(BottleneckConvArgs a) {
-  constexpr int PW = W_IN + 2, PLANE = (H_IN + 2) * PW;
+  // WINDOW (round 6): a workgroup stages only the padded input rows its 80 output pixels read -- (rows - 1) * STRIDE + 3 of them -- instead of
+  // the whole padded map: the stride-2 layer on the 32 x 40 map (9 of 34 rows: 24 KB of LDS per 16 channels instead of 91 KB).  The maps of
+  // rounds 4-5 keep whole-map staging: their kernels are unchanged.
+  constexpr int PW = W_IN + 2;
   constexpr int W_OUT = W_IN / STRIDE, H_OUT = H_IN / STRIDE, P = H_OUT * W_OUT, PG = P / kBcPixels;
+  constexpr int ROWS_OUT = kBcPixels / W_OUT;                                                  // output rows of a pixel group
+  constexpr int STAGED_ROWS = WINDOW ? (ROWS_OUT - 1) * STRIDE + 3 : H_IN + 2;
+  constexpr int PLANE = STAGED_ROWS * PW;
   static_assert(P % kBcPixels == 0, "the map must split into 80-pixel groups");
+  static_assert(!WINDOW || (kBcPixels % W_OUT == 0 && STAGED_ROWS <= H_IN + 2), "a pixel group must be whole output rows");
   extern __shared__ __attribute__((aligned(16))) float xs[];   // [cs][PLANE]: the split's channels with their zero ring
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,13 +82,15 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
   const __amdgpu_buffer_rsrc_t x_resource =
       __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, static_cast<int>(sizeof(float) * static_cast<unsigned int>(a.cs) * (H_IN * W_IN)), 0x00020000);
   const int staged = a.cs * PLANE;
+  const int row0 = WINDOW ? pg * ROWS_OUT * STRIDE : 0;      // first staged row of the padded map
   for (int i0 = tid; i0 < staged; i0 += 8 * kBcWaves * 64) {
     float v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int i = i0 + k * kBcWaves * 64;
       const int c = i / PLANE, r = i - c * PLANE;
-      const int yy = r / PW, xx = r - yy * PW;
+      const int yw = r / PW, xx = r - yw * PW;
+      const int yy = yw + row0;      // (row of the padded map)
       const bool in = i < staged && yy >= 1 && yy <= H_IN && xx >= 1 && xx <= W_IN;
       const unsigned int offset = in ? static_cast<unsigned int>(sizeof(float)) * static_cast<unsigned int>(c * (H_IN * W_IN) + (yy - 1) * W_IN + (xx - 1)) : 0x80000000u;
       v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_resource, static_cast<int>(offset), 0, 0));
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
   for (int pt = 0; pt < kBcPT; ++pt) {
     const int p = pg * kBcPixels + pt * 16 + (lane & 15);
     const int py = p / W_OUT, px = p - py * W_OUT;
-    pix[pt] = (py * STRIDE) * PW + px * STRIDE + (lane >> 4) * PLANE;
+    pix[pt] = (py * STRIDE - row0) * PW + px * STRIDE + (lane >> 4) * PLANE;
   }
   float4v acc[kBcPT];
 #pragma unroll
@@ -228,9 +237,13 @@ __global__ __launch_bounds__(256) void partial_sums_bias_act_kernel(const float*
   }
 }
 
-template <int H_IN, int W_IN, int STRIDE>
+inline constexpr int bottleneck_staged_plane(int H_in, int W_in, int stride, bool window) {
+  return (window ? (kBcPixels / (W_in / stride) - 1) * stride + 3 : H_in + 2) * (W_in + 2);
+}
+
+template <int H_IN, int W_IN, int STRIDE, bool WINDOW = false>
 int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
-  constexpr int P = (H_IN / STRIDE) * (W_IN / STRIDE), PLANE = (H_IN + 2) * (W_IN + 2);
+  constexpr int P = (H_IN / STRIDE) * (W_IN / STRIDE), PLANE = bottleneck_staged_plane(H_IN, W_IN, STRIDE, WINDOW);
   const size_t lds = sizeof(float) * static_cast<size_t>(a.cs) * PLANE;
   if (lds > kBcLdsBytes) return DVMVS_EUNSUPPORTED;
   const dim3 grid((a.n_tiles + kBcWaves - 1) / kBcWaves, a.splits, a.B * (P / kBcPixels)), block(kBcWaves * 64);
@@ -239,10 +252,10 @@ int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
   if (const char* ch = getenv("DVMVS_BC_CH")) {
     const int c = atoi(ch);
     if (c == 0 || c == 1 || groups % c == 0) {
-      if (c == 0) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 0>), grid, block, lds, stream, a);
-      else if (c == 1) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1>), grid, block, lds, stream, a);
-      else if (c == 2) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 2>), grid, block, lds, stream, a);
-      else hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 4>), grid, block, lds, stream, a);
+      if (c == 0) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 0, WINDOW>), grid, block, lds, stream, a);
+      else if (c == 1) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1, WINDOW>), grid, block, lds, stream, a);
+      else if (c == 2) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 2, WINDOW>), grid, block, lds, stream, a);
+      else hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 4, WINDOW>), grid, block, lds, stream, a);
       return launch_status();
     }
   }
@@ -251,15 +264,19 @@ int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
   // 39.8 / 40.8 / 43.7 us at 16 splits, 50-53 us at 8 splits, 43-44 us at 32 -- the kernel is not waiting for its weights (two waves
   // per SIMD cover each other's requests); it runs at ~48 % of the fp32 MFMA rate whatever the burst (PMC: MFMA pipe busy 50 % of the
   // kernel, LDS pipe 25 %, profiles/r04_bottleneck_conv_pmc.txt).
-  hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1>), grid, block, lds, stream, a);
+  hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1, WINDOW>), grid, block, lds, stream, a);
   return launch_status();
 }
 
 inline bool bottleneck_shape_ok(int C_out, int C_in, int H_in, int W_in, int stride) {
   if (C_out <= 0 || C_in <= 0 || C_in % 16 != 0) return false;
-  // the 1/32 and 1/16 maps of a 320x256 frame (80-pixel groups); other sizes stay on MIOpen
-  return (H_in == 8 && W_in == 10 && stride == 1) || (H_in == 16 && W_in == 20 && (stride == 1 || stride == 2));
+  // the 1/32 and 1/16 maps of a 320x256 frame (80-pixel groups), and (round 6) the stride-2 layer that takes the 1/8 map down to the 1/16 one
+  // (encoder_block2's down-convolution: MIOpen ran it as im2col + GEMM + an epilogue launch); other sizes stay on MIOpen
+  return (H_in == 8 && W_in == 10 && stride == 1) || (H_in == 16 && W_in == 20 && (stride == 1 || stride == 2)) || (H_in == 32 && W_in == 40 && stride == 2);
 }
+
+// padded pixels per channel a workgroup stages for a shape bottleneck_shape_ok accepts
+inline int bottleneck_plane(int H_in, int W_in, int stride) { return bottleneck_staged_plane(H_in, W_in, stride, H_in == 32); }
 
 }  // namespace dvmvs
 
@@ -280,7 +297,7 @@ extern "C" int dvmvs_bottleneck_conv_pack(const float* weight, float* packed, in
 
 extern "C" int dvmvs_bottleneck_conv_splits(int B, int C_out, int C_in, int H_in, int W_in, int stride) {
   if (B <= 0 || !dvmvs::bottleneck_shape_ok(C_out, C_in, H_in, W_in, stride)) return DVMVS_EUNSUPPORTED;
-  return dvmvs::bottleneck_splits(B, C_out, C_in, (H_in / stride) * (W_in / stride), (H_in + 2) * (W_in + 2));
+  return dvmvs::bottleneck_splits(B, C_out, C_in, (H_in / stride) * (W_in / stride), dvmvs::bottleneck_plane(H_in, W_in, stride));
 }
 
 extern "C" int dvmvs_bottleneck_conv_fwd(const float* x, const float* packed, float* partials, int B, int C_in, int H_in, int W_in, int C_out,
@@ -292,9 +309,10 @@ extern "C" int dvmvs_bottleneck_conv_fwd(const float* x, const float* packed, fl
   a.x = x; a.packed = packed; a.partials = partials;
   a.B = B; a.C_in = C_in; a.C_out = C_out;
   a.n_tiles = (C_out + kBcRows - 1) / kBcRows;
-  a.splits = bottleneck_splits(B, C_out, C_in, (H_in / stride) * (W_in / stride), (H_in + 2) * (W_in + 2));
+  a.splits = bottleneck_splits(B, C_out, C_in, (H_in / stride) * (W_in / stride), bottleneck_plane(H_in, W_in, stride));
   a.cs = C_in / a.splits;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (H_in == 32) return launch_bottleneck_conv<32, 40, 2, true>(a, s);
   if (H_in == 8 && W_in == 10) return launch_bottleneck_conv<8, 10, 1>(a, s);
   if (stride == 1) return launch_bottleneck_conv<16, 20, 1>(a, s);
   return launch_bottleneck_conv<16, 20, 2>(a, s);

@@ -265,7 +265,8 @@ int dvmvs_depthwise_conv_bwd(const float* grad_out, const float* in, const float
                              float* workspace, int B, int C, int H, int W, int kernel_size, int stride, dvmvs_stream_t stream);
 
 /*
- * 3x3, padding-1 convolutions on the bottleneck maps of a 320x256 frame (8x10, and 16x20 with stride 1 or 2) as a weight-streaming
+ * 3x3, padding-1 convolutions on the bottleneck maps of a 320x256 frame (8x10, 16x20 with stride 1 or 2, and -- ABI 8 -- 32x40 with
+ * stride 2: the layer that takes the 1/8 map down) as a weight-streaming
  * fp32 MFMA GEMM with a DETERMINISTIC split-K (csrc/bottleneck_conv.hip).  Replaces, for those shapes only, the nn.Conv2d of the
  * ConvLSTM cell (/root/reference/dvmvs/convlstm.py:43-44: 1024 -> 2048 channels) and the 256 / 512-channel layers around it
  * (fusionnet/model.py:167-305), which MIOpen solves with split-K kernels that accumulate with float atomics (results vary from
