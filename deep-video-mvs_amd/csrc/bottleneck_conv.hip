@@ -59,8 +59,9 @@ __host__ __device__ inline int bottleneck_splits(int B, int C_out, int C_in, int
 template <int H_IN, int W_IN, int STRIDE, int CH, bool WINDOW = false>
 __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(BottleneckConvArgs a) {
   // WINDOW (round 6): a workgroup stages only the padded input rows its 80 output pixels read -- (rows - 1) * STRIDE + 3 of them -- instead of
-  // the whole padded map: the stride-2 layer on the 32 x 40 map (9 of 34 rows: 24 KB of LDS per 16 channels instead of 91 KB).  The maps of
-  // rounds 4-5 keep whole-map staging: their kernels are unchanged.
+  // the whole padded map: the stride-2 layer on the 32 x 40 map (9 of 34 rows: 24 KB of LDS per 16 channels instead of 91 KB) and the stride-1
+  // layers of the 16 x 20 map (6 of 18 rows).  Same MFMAs on the same operands in the same order: bit-identical partial sums; the split count
+  // of the 16 x 20 layers is still chosen with the whole map's LDS footprint (bottleneck_plane), so their sums are those of rounds 4-5.
   constexpr int PW = W_IN + 2;
   constexpr int W_OUT = W_IN / STRIDE, H_OUT = H_IN / STRIDE, P = H_OUT * W_OUT, PG = P / kBcPixels;
   constexpr int ROWS_OUT = kBcPixels / W_OUT;                                                  // output rows of a pixel group
@@ -275,7 +276,7 @@ inline bool bottleneck_shape_ok(int C_out, int C_in, int H_in, int W_in, int str
   return (H_in == 8 && W_in == 10 && stride == 1) || (H_in == 16 && W_in == 20 && (stride == 1 || stride == 2)) || (H_in == 32 && W_in == 40 && stride == 2);
 }
 
-// padded pixels per channel a workgroup stages for a shape bottleneck_shape_ok accepts
+// padded pixels per channel the split count of a shape is chosen with (what a workgroup stages, except for the 16 x 20 stride-1 layers: see WINDOW)
 inline int bottleneck_plane(int H_in, int W_in, int stride) { return bottleneck_staged_plane(H_in, W_in, stride, H_in == 32); }
 
 }  // namespace dvmvs
@@ -314,7 +315,12 @@ extern "C" int dvmvs_bottleneck_conv_fwd(const float* x, const float* packed, fl
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (H_in == 32) return launch_bottleneck_conv<32, 40, 2, true>(a, s);
   if (H_in == 8 && W_in == 10) return launch_bottleneck_conv<8, 10, 1>(a, s);
-  if (stride == 1) return launch_bottleneck_conv<16, 20, 1>(a, s);
+  if (stride == 1) {
+#ifdef DVMVS_SWEEP_TUNING
+    if (getenv("DVMVS_BC_WHOLE_MAP")) return launch_bottleneck_conv<16, 20, 1>(a, s);      // tools-only build: rounds 4-5's whole-map staging
+#endif
+    return launch_bottleneck_conv<16, 20, 1, true>(a, s);
+  }
   return launch_bottleneck_conv<16, 20, 2>(a, s);
 }
 

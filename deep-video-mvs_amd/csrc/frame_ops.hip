@@ -106,6 +106,45 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
   }
 }
 
+// The same values, four horizontally adjacent outputs per thread (round 6): one plane per blockIdx.y, 32-bit index arithmetic (the kernel above
+// spends three 64-bit divisions per output: 15 us for the decoder's last 32 x 128 x 160 -> 256 x 320 map), one 16-byte store.  Every output
+// is computed by the expression above from the same rounded products, so the two kernels agree bit for bit; taken when the rows allow
+// aligned float4 stores (OW % 4 == 0 always; destination and batch stride 16-byte aligned).
+template <int PRE>
+__global__ __launch_bounds__(256) void upsample2x_quads_kernel(const float* __restrict__ in, float* __restrict__ out, long long out_batch_stride,
+                                                               const float* __restrict__ pre_bias, int C, int H, int W) {
+#pragma clang fp contract(off)
+  typedef float float4v __attribute__((ext_vector_type(4)));
+  const int OH = 2 * H, OW = 2 * W, QW = OW >> 2;
+  const float sh = OH > 1 ? static_cast<float>(H - 1) / static_cast<float>(OH - 1) : 0.0f;
+  const float sw = OW > 1 ? static_cast<float>(W - 1) / static_cast<float>(OW - 1) : 0.0f;
+  const int pl = blockIdx.y, b = pl / C, c = pl - b * C;
+  const float* p = in + static_cast<size_t>(pl) * H * W;
+  const float bv = (PRE != 0 && pre_bias) ? pre_bias[c] : 0.0f;
+  float* dst = out + static_cast<size_t>(b) * out_batch_stride + static_cast<size_t>(c) * OH * OW;
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < OH * QW; q += gridDim.x * 256) {
+    const int oy = q / QW, ox = 4 * (q - oy * QW);
+    const float fy = sh * static_cast<float>(oy);
+    const int y0 = static_cast<int>(fy);
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0);
+    const float h1 = fy - static_cast<float>(y0), h0 = 1.0f - h1;
+    const float* r0 = p + y0 * W;
+    const float* r1 = p + y1 * W;
+    float4v v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float fx = sw * static_cast<float>(ox + e);
+      const int x0 = static_cast<int>(fx);
+      const int x1 = x0 + (x0 < W - 1 ? 1 : 0);
+      const float w1 = fx - static_cast<float>(x0), w0 = 1.0f - w1;
+      const float v00 = PRE ? apply_act<PRE>(r0[x0] + bv) : r0[x0], v01 = PRE ? apply_act<PRE>(r0[x1] + bv) : r0[x1];
+      const float v10 = PRE ? apply_act<PRE>(r1[x0] + bv) : r1[x0], v11 = PRE ? apply_act<PRE>(r1[x1] + bv) : r1[x1];
+      v[e] = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11);
+    }
+    *reinterpret_cast<float4v*>(dst + oy * OW + ox) = v;
+  }
+}
+
 // Depthwise k x k convolution (groups == channels, "same" padding k/2, stride 1 or 2) with the bias add and activation
 // fused.  MIOpen runs these MnasNet layers through its naive reference kernel (naive_conv_ab_nonpacked_fwd_nchw) plus a
 // separate bias/activation launch; a direct kernel is one launch and reads each input element from L1 k*k times.
@@ -250,6 +289,16 @@ extern "C" int dvmvs_upsample2x_fwd(const float* in, float* out, long long out_b
   if (blocks > 256LL * 16) blocks = 256LL * 16;
   const dim3 grid(static_cast<unsigned>(blocks)), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (W % 2 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (out_batch_stride & 3) == 0 && static_cast<long long>(B) * C <= 65535 &&
+      static_cast<long long>(H) * W < (1LL << 27)) {
+    const int quads = 2 * H * (W / 2);
+    const int per_plane = max(1, min((quads + 255) / 256, max(1, 4096 / (B * C))));
+    const dim3 qgrid(static_cast<unsigned>(per_plane), static_cast<unsigned>(B * C));
+    if (pre_activation == 1) hipLaunchKernelGGL(upsample2x_quads_kernel<1>, qgrid, block, 0, s, in, out, out_batch_stride, pre_bias, C, H, W);
+    else if (pre_activation == 2) hipLaunchKernelGGL(upsample2x_quads_kernel<2>, qgrid, block, 0, s, in, out, out_batch_stride, pre_bias, C, H, W);
+    else hipLaunchKernelGGL(upsample2x_quads_kernel<0>, qgrid, block, 0, s, in, out, out_batch_stride, pre_bias, C, H, W);
+    return launch_status();
+  }
   if (pre_activation == 1) hipLaunchKernelGGL(upsample2x_kernel<1>, grid, block, 0, s, in, out, out_batch_stride, pre_bias, B * C, C, H, W);
   else if (pre_activation == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, grid, block, 0, s, in, out, out_batch_stride, pre_bias, B * C, C, H, W);
   else hipLaunchKernelGGL(upsample2x_kernel<0>, grid, block, 0, s, in, out, out_batch_stride, pre_bias, B * C, C, H, W);
