@@ -31,6 +31,10 @@ constexpr int kBcPixels = 80;   // pixels per wave
 constexpr int kBcPT = kBcPixels / 16;
 constexpr int kBcWaves = 4;
 constexpr int kBcTargetWaves = 2048;   // two per SIMD
+#ifndef DVMVS_BC_STAGE
+#define DVMVS_BC_STAGE 8
+#endif
+constexpr int kBcStage = DVMVS_BC_STAGE;   // elements of the staged slice a thread has in flight at a time
 
 struct BottleneckConvArgs {
   const float* x;        // [B, C_in, H_in, W_in]
@@ -84,10 +88,10 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
       __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, static_cast<int>(sizeof(float) * static_cast<unsigned int>(a.cs) * (H_IN * W_IN)), 0x00020000);
   const int staged = a.cs * PLANE;
   const int row0 = WINDOW ? pg * ROWS_OUT * STRIDE : 0;      // first staged row of the padded map
-  for (int i0 = tid; i0 < staged; i0 += 8 * kBcWaves * 64) {
-    float v[8];
+  for (int i0 = tid; i0 < staged; i0 += kBcStage * kBcWaves * 64) {
+    float v[kBcStage];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < kBcStage; ++k) {
       const int i = i0 + k * kBcWaves * 64;
       const int c = i / PLANE, r = i - c * PLANE;
       const int yw = r / PW, xx = r - yw * PW;
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
       v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_resource, static_cast<int>(offset), 0, 0));
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < kBcStage; ++k) {
       const int i = i0 + k * kBcWaves * 64;
       if (i < staged) xs[i] = v[k];
     }

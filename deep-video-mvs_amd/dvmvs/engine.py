@@ -28,6 +28,7 @@ MI355X-specific execution choices (none of them changes results beyond fp32 roun
   with the intrinsics into one pinned staging slot and sent to the device with a single asynchronous copy ahead of the graph
   launch.  ``pose_algebra="exact"`` evaluates them on the device in fp64 inside the captured frame instead.
 """
+import contextlib
 import copy
 import time
 import os
@@ -72,6 +73,7 @@ _STAGING_SLOTS = int(os.environ.get("DVMVS_STAGING_SLOTS", "1"))
 _GRAPH_QUEUE_FILLERS = int(os.environ.get("DVMVS_GRAPH_QUEUE_FILLERS", "1"))
 # experiments: "1" = a frame's sweep runs before the side-stream fork instead of next to the side stream's kernels (see _frame_body_direct)
 _SWEEP_FIRST = os.environ.get("DVMVS_SWEEP_FIRST", "0") == "1"
+_AUX_STREAM = os.environ.get("DVMVS_AUX_STREAM", "0")      # "0" off, "warp" / "heads" one of the two uses, "1" both (see DepthEngine._aux_stream)
 # a step's input copies as one launch (see DepthEngine._copy); "0" = one runtime copy each
 _BATCH_COPIES = os.environ.get("DVMVS_BATCH_COPIES", "1") != "0"
 
@@ -604,6 +606,10 @@ class DepthEngine:
         self.step_clock = None
         self._parity, self._prefetched = 0, None      # buffer set of the next frame; (frame_id, buffer set) whose reference features are ready
         self._side_stream = torch.cuda.Stream(device=self.device)
+        # a third stream for the frame's own independent small kernels (round 6): the re-projection + hidden-state warp next to the sweep and the
+        # encoder, a decoder level's depth head + its up-sampling next to the level's up-convolution -- 3 - 5 us launches that only waited in line
+        # behind kernels they do not depend on; inside the frame graph they are parallel branches (DVMVS_AUX_STREAM=0: in line, as in rounds 3-5)
+        self._aux_stream = torch.cuda.Stream(device=self.device) if _AUX_STREAM != "0" else None
         self._planner, self._planned, self._param_host_ahead = None, None, None      # see plan_ahead
         self.plan_frames_ahead = os.environ.get("DVMVS_PLAN_AHEAD", "1") != "0"
         self.planned_frames_used = 0
@@ -1051,10 +1057,30 @@ class DepthEngine:
         slice has already been written by the encoder's aggregator.  ``depth_head`` (the previous level's depth layer) runs as raw
         convolution and its bias + sigmoid are applied inside the up-sampling kernel."""
         up_channels = block.up_convolution.conv[0].weight.shape[0]
-        block.up_convolution.conv[0](_ops.upsample2x(x), out=cat[:, :up_channels])
         if depth_head is not None:
-            self._upsampled_depth_head(depth_head, depth_input, cat[:, -1:])
+            with self._beside("heads"):      # (reads the previous level's output, writes the last channel of ``cat``: nothing the up-convolution touches)
+                self._upsampled_depth_head(depth_head, depth_input, cat[:, -1:])
+        block.up_convolution.conv[0](_ops.upsample2x(x), out=cat[:, :up_channels])
+        self._join_beside()
         return block.convolution2[0](block.convolution1[0](cat))
+
+    @contextlib.contextmanager
+    def _beside(self, use):
+        """The launches inside run on the auxiliary stream, forked from the current one -- concurrently with what the current stream is given
+        next, until ``_join_beside``.  Without the auxiliary stream (or with it switched on for the other use only): in line."""
+        aux = self._aux_stream if _AUX_STREAM in ("1", use) else None
+        if aux is None:
+            yield
+            return
+        aux.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(aux):
+            yield
+        self._beside_open = True
+
+    def _join_beside(self):
+        if self._aux_stream is not None and getattr(self, "_beside_open", False):
+            torch.cuda.current_stream(self.device).wait_stream(self._aux_stream)
+            self._beside_open = False
 
     @staticmethod
     def _upsampled_depth_head(head, x, dst):
@@ -1090,9 +1116,15 @@ class DepthEngine:
         def own(sweep_done=False):
             if have < 1:
                 self._reference_features_direct(cur)
+            warped = False
             if have < 2:
+                if self.is_fusionnet and self._aux_stream is not None and _AUX_STREAM in ("1", "warp"):
+                    # two 5 us launches that depend on the PREVIOUS frame only: next to this frame's sweep + encoder instead of behind them
+                    with self._beside("warp"):
+                        self._state_warp_direct(cur, has_previous)
+                    warped = True
                 self._sweep_encoder_direct(cur, n_meas, sweep_variant, sweep_done=sweep_done)
-            self._lstm_decoder_direct(cur, has_previous)
+            self._lstm_decoder_direct(cur, has_previous, state_warped=warped)
 
         def ahead():
             if give >= 1:
@@ -1166,25 +1198,35 @@ class DepthEngine:
             else:
                 x = block.standard_convolution.conv2[0](x, out=buffers["lstm_cat"][:, :512])      # (pairnet: the buffer is just the bottleneck's home)
 
-    def _lstm_decoder_direct(self, buffers, has_previous):
+    def _state_warp_direct(self, buffers, has_previous):
+        """Re-projection of the previous depth into the frame's 8x10 estimate and the hidden state warped with it into the ConvLSTM's input
+        (convlstm.py:27-41, utils.py:110-154).  Reads the previous frame's depth and state only -- nothing of this frame's sweep or encoder."""
+        s, d = self._static, self._direct_buffers
+        lstm_cat = buffers["lstm_cat"]
+        if has_previous:
+            exact = self.pose_algebra == "exact"
+            reproject_T = _ops.relative_pose(s["pose"], s["prev_pose"]) if exact else s["reproject_T"]
+            lstm_T = _ops.relative_pose(s["prev_pose"], s["pose"]) if exact else s["lstm_T"]
+            # re-projection of the previous depth straight into this buffer set's 8x10 estimate (one launch: it also zero-fills the
+            # other set's estimate for the next frame), then the hidden-state warp
+            other = d["sets"][1 - buffers["index"]]["estimate"]
+            _ops.depth_reproject_estimate_into(reproject_T, s["prev_depth"], s["full_K"], s["half_K"], buffers["estimate"], other, 16)
+            _ops.hidden_warp_into(s["h"], buffers["estimate"], lstm_T, s["lstm_K"], True, lstm_cat[:, 512:])
+        else:
+            lstm_cat[:, 512:].copy_(s["h"])      # first frame of a sequence: the (zero) state as it is, no warp (convlstm.py:29)
+
+    def _lstm_decoder_direct(self, buffers, has_previous, state_warped=False):
         """Re-projection of the previous depth, ConvLSTM and decoder of the frame whose encoder outputs are in ``buffers``: the part of a
-        frame that carries the recurrent state."""
+        frame that carries the recurrent state.  ``state_warped``: the re-projection + hidden-state warp have been launched already (on the
+        auxiliary stream, next to the sweep and the encoder: ``_frame_body_direct``) and are only waited for here."""
         s, d = self._static, self._direct_buffers
         dec, dec_cat, lstm_cat = self.dec, buffers["dec_cat"], buffers["lstm_cat"]
         bottom = lstm_cat[:, :512]
         if self.is_fusionnet:
             cell = self.lstm.lstm_cell
-            if has_previous:
-                exact = self.pose_algebra == "exact"
-                reproject_T = _ops.relative_pose(s["pose"], s["prev_pose"]) if exact else s["reproject_T"]
-                lstm_T = _ops.relative_pose(s["prev_pose"], s["pose"]) if exact else s["lstm_T"]
-                # re-projection of the previous depth straight into this buffer set's 8x10 estimate (one launch: it also zero-fills the
-                # other set's estimate for the next frame), then the hidden-state warp
-                other = d["sets"][1 - buffers["index"]]["estimate"]
-                _ops.depth_reproject_estimate_into(reproject_T, s["prev_depth"], s["full_K"], s["half_K"], buffers["estimate"], other, 16)
-                _ops.hidden_warp_into(s["h"], buffers["estimate"], lstm_T, s["lstm_K"], True, lstm_cat[:, 512:])
-            else:
-                lstm_cat[:, 512:].copy_(s["h"])      # first frame of a sequence: the (zero) state as it is, no warp (convlstm.py:29)
+            if not state_warped:
+                self._state_warp_direct(buffers, has_previous)
+            self._join_beside()
             if self._lstm_bottleneck(lstm_cat):
                 # the 1024 -> 2048-channel convolution as K-split partial sums (75 MB of weights streamed once through the MFMA
                 # pipe), added up in a fixed order by a chip-wide reduction (the gates kernel can add them itself --
@@ -1208,8 +1250,10 @@ class DepthEngine:
         d3 = self._decoder_block_direct(dec.decoder_block3, d2, dec_cat[2], dec.depth_layer_one_eight, d2)
         d4 = self._decoder_block_direct(dec.decoder_block4, d3, dec_cat[3], dec.depth_layer_quarter, d3)
         full_in = buffers["full_in"]
+        with self._beside("heads"):
+            self._upsampled_depth_head(dec.depth_layer_half, d4, full_in[:, 32:33])
         _ops.upsample2x_into(d4, full_in[:, :32])
-        self._upsampled_depth_head(dec.depth_layer_half, d4, full_in[:, 32:33])
+        self._join_beside()
         refined = dec.refine[1][0](dec.refine[0][0](full_in))
         # last convolution: bias + sigmoid + depth mapping (model.py:231-232) in one epilogue, into the depth / previous-depth buffer
         dec.depth_layer_full[0](refined, out=s["prev_depth"], activation=_ops.ACTIVATION_SIGMOID_TO_DEPTH,
