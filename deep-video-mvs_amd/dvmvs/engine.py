@@ -73,6 +73,7 @@ _STAGING_SLOTS = int(os.environ.get("DVMVS_STAGING_SLOTS", "1"))
 _GRAPH_QUEUE_FILLERS = int(os.environ.get("DVMVS_GRAPH_QUEUE_FILLERS", "1"))
 # experiments: "1" = a frame's sweep runs before the side-stream fork instead of next to the side stream's kernels (see _frame_body_direct)
 _SWEEP_FIRST = os.environ.get("DVMVS_SWEEP_FIRST", "0") == "1"
+_UPLOAD_IN_COPY_BATCH = os.environ.get("DVMVS_UPLOAD_IN_COPY_BATCH", "1") != "0"
 _AUX_STREAM = os.environ.get("DVMVS_AUX_STREAM", "0")      # "0" off, "warp" / "heads" one of the two uses, "1" both (see DepthEngine._aux_stream)
 # a step's input copies as one launch (see DepthEngine._copy); "0" = one runtime copy each
 _BATCH_COPIES = os.environ.get("DVMVS_BATCH_COPIES", "1") != "0"
@@ -869,7 +870,7 @@ class DepthEngine:
         for name, n in sizes:
             offsets[name] = (total, n)
             total += n
-        return offsets, total
+        return offsets, (total + 3) // 4 * 4      # (whole float4: the upload can ride in the frame's copy batch)
 
     def _sweep_views(self, n_meas, index=0):
         """Hm [S,n_meas,9] and kt [S,n_meas,3] views of the parameter buffer (contiguous prefixes of their regions) of buffer set ``index``."""
@@ -885,7 +886,7 @@ class DepthEngine:
         o, n = self._param_offsets["sweep_items1" if index else "sweep_items"]
         return self._static["params"].view(torch.int32)[o:o + n]
 
-    def _upload_frame_parameters(self, n_meas, pose, measurement_poses, full_K, index=0, own_sweep=True, next_frame=None):
+    def _upload_frame_parameters(self, n_meas, pose, measurement_poses, full_K, index=0, own_sweep=True, next_frame=None, pending_copies=None):
         """Evaluates the frame's small matrices on the host (reference mode) and sends them, the intrinsics and the poses to
         the device with ONE asynchronous copy out of a pinned staging slot.  The slot's previous copy (issued _STAGING_SLOTS
         frames ago) must have executed before it is overwritten: its event is waited for, which never blocks in practice.
@@ -897,12 +898,21 @@ class DepthEngine:
         Returns (the host pose that becomes "the previous pose" -- committed by step() only after the frame was launched, so that a
         frame that raises leaves (h, c, previous depth, previous pose) those of one frame --, this frame's sweep configuration or
         None, the next frame's or None)."""
-        planned = self._take_planned(n_meas, pose, measurement_poses, full_K, index, own_sweep, next_frame)
-        if planned is not None:
-            result = planned
-        else:
-            result = self._evaluate_frame_parameters(self._param_host, n_meas, pose, measurement_poses, full_K, self._prev_pose_host,
-                                                     self._no_previous, index, own_sweep, next_frame)
+        try:
+            planned = self._take_planned(n_meas, pose, measurement_poses, full_K, index, own_sweep, next_frame)
+            if planned is not None:
+                result = planned
+            else:
+                result = self._evaluate_frame_parameters(self._param_host, n_meas, pose, measurement_poses, full_K, self._prev_pose_host,
+                                                         self._no_previous, index, own_sweep, next_frame)
+        except BaseException:
+            if pending_copies:      # (they belong to cache entries that are already registered: written before the error leaves)
+                self._copy_queue = pending_copies
+                try:
+                    self._flush_copies()
+                finally:
+                    self._copy_queue = None
+            raise
         mirror = self._param_host
         staging, event = self._ring[self._ring_pos]
         self._ring_pos = (self._ring_pos + 1) % len(self._ring)
@@ -911,7 +921,20 @@ class DepthEngine:
         self.ring_wait_seconds += time.perf_counter() - t_wait
         staging.copy_(mirror)
         with torch.cuda.device(self.device):     # the ring guard must be recorded on the engine's device, whichever is current
-            self._static["params"].copy_(staging, non_blocking=True)
+            params = self._static["params"]
+            if pending_copies and len(pending_copies) < 8 and _UPLOAD_IN_COPY_BATCH:
+                # the block goes up in the SAME launch as the frame's input copies (round 6): the copy kernel reads the pinned staging slot through
+                # its device-visible address -- the runtime's own copy of a pinned buffer is a blit kernel too (__amd_rocclr_copyBuffer), one
+                # launch more per frame
+                _ops.copy_batch(pending_copies + [(params, staging)])
+            else:
+                if pending_copies:
+                    self._copy_queue = pending_copies
+                    try:
+                        self._flush_copies()
+                    finally:
+                        self._copy_queue = None
+                params.copy_(staging, non_blocking=True)
             event.record(torch.cuda.current_stream(self.device))
         return result
 
@@ -1410,11 +1433,11 @@ class DepthEngine:
             finally:
                 self._copy_queue = None
             raise
-        self._flush_copies()
+        pending = self._copy_queue      # (launched together with the parameter block: _upload_frame_parameters)
         self._copy_queue = None
         mark("inputs copied")
         committed_pose, sweep_variant, next_variant = self._upload_frame_parameters(n_meas, reference_pose, measurement_poses, full_K, index=parity,
-                                                                                    own_sweep=have < 2, next_frame=next_frame)
+                                                                                    own_sweep=have < 2, next_frame=next_frame, pending_copies=pending)
         mark("parameters planned + uploaded")
         if self.direct and give < 2 and self.pose_algebra == "reference" and self.plan_frames_ahead and next_reference_pose is not None and \
                 next_measurement_poses is not None and 1 <= len(next_measurement_poses) <= _MAX_MEAS:
