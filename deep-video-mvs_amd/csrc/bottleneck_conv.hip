@@ -60,7 +60,32 @@ __host__ __device__ inline int bottleneck_splits(int B, int C_out, int C_in, int
 }
 
 // CH: groups of 16 input channels whose weights are requested together; the split's group count is a multiple of it
-template <int H_IN, int W_IN, int STRIDE, int CH, bool WINDOW = false>
+// One element of the 2x bilinear up-sampling (align_corners = True) of a [H / 2, W / 2] plane at (oy, ox) of the [H, W] map: dvmvs_upsample2x_fwd's
+// expression (csrc/frame_ops.hip: ATen's op order, no FMA contraction), so a map up-sampled on the fly here holds the bits that kernel writes.
+template <int H, int W>
+__device__ inline void up2x_taps(int oy, int ox, int* o00, int* o01, int* o10, int* o11, float* h0, float* h1, float* w0, float* w1) {
+#pragma clang fp contract(off)
+  constexpr int HS = H / 2, WS = W / 2;
+  const float sh = static_cast<float>(HS - 1) / static_cast<float>(H - 1), sw = static_cast<float>(WS - 1) / static_cast<float>(W - 1);
+  const float fy = sh * static_cast<float>(oy), fx = sw * static_cast<float>(ox);
+  const int y0 = static_cast<int>(fy), x0 = static_cast<int>(fx);
+  const int y1 = y0 + (y0 < HS - 1 ? 1 : 0), x1 = x0 + (x0 < WS - 1 ? 1 : 0);
+  *h1 = fy - static_cast<float>(y0);
+  *h0 = 1.0f - *h1;
+  *w1 = fx - static_cast<float>(x0);
+  *w0 = 1.0f - *w1;
+  *o00 = y0 * WS + x0; *o01 = y0 * WS + x1; *o10 = y1 * WS + x0; *o11 = y1 * WS + x1;
+}
+
+__device__ inline float up2x_blend(float v00, float v01, float v10, float v11, float h0, float h1, float w0, float w1) {
+#pragma clang fp contract(off)
+  return h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11);
+}
+
+// UP2X (round 6): ``x`` is the [B, C_in, H_IN / 2, W_IN / 2] map whose 2x bilinear up-sampling the layer convolves (the decoder's first
+// up-convolution: the ConvLSTM state, 512 x 8 x 10): every staged element is interpolated from its four taps on the way into LDS instead of
+// being read from a map a separate up-sampling launch wrote.
+template <int H_IN, int W_IN, int STRIDE, int CH, bool WINDOW = false, bool UP2X = false>
 __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(BottleneckConvArgs a) {
   // WINDOW (round 6): a workgroup stages only the padded input rows its 80 output pixels read -- (rows - 1) * STRIDE + 3 of them -- instead of
   // the whole padded map: the stride-2 layer on the 32 x 40 map (9 of 34 rows: 24 KB of LDS per 16 channels instead of 91 KB) and the stride-1
@@ -83,11 +108,28 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
 
   // ---- stage x[b, c0 : c0 + cs] into LDS: eight elements per thread in flight at a time, the zero ring through out-of-range
   // offsets of a raw buffer descriptor (a branch per element and one load at a time took a third of the kernel) ----
-  gcfloat_p xg = as_global(a.x) + (static_cast<size_t>(b) * a.C_in + c0) * (H_IN * W_IN);
+  constexpr int SRC_PLANE = UP2X ? (H_IN / 2) * (W_IN / 2) : H_IN * W_IN;
+  gcfloat_p xg = as_global(a.x) + (static_cast<size_t>(b) * a.C_in + c0) * SRC_PLANE;
   const __amdgpu_buffer_rsrc_t x_resource =
-      __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, static_cast<int>(sizeof(float) * static_cast<unsigned int>(a.cs) * (H_IN * W_IN)), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, static_cast<int>(sizeof(float) * static_cast<unsigned int>(a.cs) * SRC_PLANE), 0x00020000);
   const int staged = a.cs * PLANE;
   const int row0 = WINDOW ? pg * ROWS_OUT * STRIDE : 0;      // first staged row of the padded map
+  if constexpr (UP2X) {
+    for (int i = tid; i < staged; i += kBcWaves * 64) {
+      const int c = i / PLANE, r = i - c * PLANE;
+      const int yw = r / PW, xx = r - yw * PW;
+      const int yy = yw + row0;
+      float v = 0.0f;
+      if (yy >= 1 && yy <= H_IN && xx >= 1 && xx <= W_IN) {
+        int o00, o01, o10, o11;
+        float h0, h1, w0, w1;
+        up2x_taps<H_IN, W_IN>(yy - 1, xx - 1, &o00, &o01, &o10, &o11, &h0, &h1, &w0, &w1);
+        gcfloat_p plane = xg + c * SRC_PLANE;
+        v = up2x_blend(plane[o00], plane[o01], plane[o10], plane[o11], h0, h1, w0, w1);
+      }
+      xs[i] = v;
+    }
+  } else
   for (int i0 = tid; i0 < staged; i0 += kBcStage * kBcWaves * 64) {
     float v[kBcStage];
 #pragma unroll
@@ -246,7 +288,7 @@ inline constexpr int bottleneck_staged_plane(int H_in, int W_in, int stride, boo
   return (window ? (kBcPixels / (W_in / stride) - 1) * stride + 3 : H_in + 2) * (W_in + 2);
 }
 
-template <int H_IN, int W_IN, int STRIDE, bool WINDOW = false>
+template <int H_IN, int W_IN, int STRIDE, bool WINDOW = false, bool UP2X = false>
 int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
   constexpr int P = (H_IN / STRIDE) * (W_IN / STRIDE), PLANE = bottleneck_staged_plane(H_IN, W_IN, STRIDE, WINDOW);
   const size_t lds = sizeof(float) * static_cast<size_t>(a.cs) * PLANE;
@@ -257,10 +299,10 @@ int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
   if (const char* ch = getenv("DVMVS_BC_CH")) {
     const int c = atoi(ch);
     if (c == 0 || c == 1 || groups % c == 0) {
-      if (c == 0) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 0, WINDOW>), grid, block, lds, stream, a);
-      else if (c == 1) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1, WINDOW>), grid, block, lds, stream, a);
-      else if (c == 2) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 2, WINDOW>), grid, block, lds, stream, a);
-      else hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 4, WINDOW>), grid, block, lds, stream, a);
+      if (c == 0) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 0, WINDOW, UP2X>), grid, block, lds, stream, a);
+      else if (c == 1) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1, WINDOW, UP2X>), grid, block, lds, stream, a);
+      else if (c == 2) hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 2, WINDOW, UP2X>), grid, block, lds, stream, a);
+      else hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 4, WINDOW, UP2X>), grid, block, lds, stream, a);
       return launch_status();
     }
   }
@@ -269,7 +311,7 @@ int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
   // 39.8 / 40.8 / 43.7 us at 16 splits, 50-53 us at 8 splits, 43-44 us at 32 -- the kernel is not waiting for its weights (two waves
   // per SIMD cover each other's requests); it runs at ~48 % of the fp32 MFMA rate whatever the burst (PMC: MFMA pipe busy 50 % of the
   // kernel, LDS pipe 25 %, profiles/r04_bottleneck_conv_pmc.txt).
-  hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1, WINDOW>), grid, block, lds, stream, a);
+  hipLaunchKernelGGL((bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1, WINDOW, UP2X>), grid, block, lds, stream, a);
   return launch_status();
 }
 
@@ -326,6 +368,20 @@ extern "C" int dvmvs_bottleneck_conv_fwd(const float* x, const float* packed, fl
     return launch_bottleneck_conv<16, 20, 1, true>(a, s);
   }
   return launch_bottleneck_conv<16, 20, 2>(a, s);
+}
+
+extern "C" int dvmvs_bottleneck_conv_up2x_fwd(const float* x, const float* packed, float* partials, int B, int C_in, int H_in, int W_in, int C_out,
+                                              dvmvs_stream_t stream) {
+  using namespace dvmvs;
+  if (!x || !packed || !partials || B <= 0) return DVMVS_EINVAL;
+  if (H_in != 16 || W_in != 20 || !bottleneck_shape_ok(C_out, C_in, H_in, W_in, 1)) return DVMVS_EUNSUPPORTED;
+  BottleneckConvArgs a;
+  a.x = x; a.packed = packed; a.partials = partials;
+  a.B = B; a.C_in = C_in; a.C_out = C_out;
+  a.n_tiles = (C_out + kBcRows - 1) / kBcRows;
+  a.splits = bottleneck_splits(B, C_out, C_in, H_in * W_in, bottleneck_plane(H_in, W_in, 1));      // (the split count of dvmvs_bottleneck_conv_fwd: the same sums)
+  a.cs = C_in / a.splits;
+  return launch_bottleneck_conv<16, 20, 1, true, true>(a, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dvmvs_partial_sums_bias_act_fwd(const float* partials, int n_partials, float* dst, long long dst_batch_stride, const float* bias,

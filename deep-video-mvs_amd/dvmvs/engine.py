@@ -73,6 +73,7 @@ _STAGING_SLOTS = int(os.environ.get("DVMVS_STAGING_SLOTS", "1"))
 _GRAPH_QUEUE_FILLERS = int(os.environ.get("DVMVS_GRAPH_QUEUE_FILLERS", "1"))
 # experiments: "1" = a frame's sweep runs before the side-stream fork instead of next to the side stream's kernels (see _frame_body_direct)
 _SWEEP_FIRST = os.environ.get("DVMVS_SWEEP_FIRST", "0") == "1"
+_UP2X_IN_CONV = os.environ.get("DVMVS_UP2X_IN_CONV", "1") != "0"      # the decoder's first up-sampling inside its convolution's staging
 _UPLOAD_IN_COPY_BATCH = os.environ.get("DVMVS_UPLOAD_IN_COPY_BATCH", "1") != "0"
 _AUX_STREAM = os.environ.get("DVMVS_AUX_STREAM", "0")      # "0" off, "warp" / "heads" one of the two uses, "1" both (see DepthEngine._aux_stream)
 # a step's input copies as one launch (see DepthEngine._copy); "0" = one runtime copy each
@@ -135,6 +136,13 @@ def _graph_microseconds(fn, reps=10, rounds=3):
 
 
 _PLAN_TIMINGS = {}     # (device, input shape, weight shape, stride, padding, activation) -> FusedConv2d._time_plan's tuple
+
+
+class _ShapeOn:
+    """A (shape, device) pair where code written for a tensor only asks for those two."""
+
+    def __init__(self, shape, device):
+        self.shape, self.device = shape, device
 
 
 class FusedConv2d(nn.Module):
@@ -285,6 +293,20 @@ class FusedConv2d(nn.Module):
         dst = out if out is not None else torch.empty((B, k[0], H // stride, W // stride), device=x.device, dtype=torch.float32)
         return _ops.direct_conv_into(x, packed, tile, bias, dst, k[0], k[2], stride, act, dst_nhwc=out_nhwc)
 
+    def forward_upsampled(self, x, out=None):
+        """``self(upsample2x(x), out=out)`` -- the decoder's up-convolutions.  Where the bottleneck kernel takes the layer on the up-sampled map it
+        interpolates while it stages its input (one launch less; the same bits: csrc/bottleneck_conv.hip, UP2X); else the two launches."""
+        if self.bottleneck and _UP2X_IN_CONV and not self.defer_epilogue and x.is_contiguous() and tuple(x.shape[2:]) == (8, 10) and self.stride[0] == 1 \
+                and self.activation in (_ops.ACTIVATIONS["none"], _ops.ACTIVATIONS["relu"]):
+            B, C = x.shape[0], x.shape[1]
+            buffers = self._bottleneck_for(x, shape=(B, C, 16, 20))
+            if buffers is not None:
+                shape = (B, self.weight.shape[0], 16, 20)
+                splits = _ops.bottleneck_conv_into(x, self._bottleneck_packed, shape[1], 1, buffers, upsample=True)
+                dst = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
+                return _ops.partial_sums_bias_act_into(buffers, splits, dst, self.bias, self.activation, shape)
+        return self(_ops.upsample2x(x), out=out)
+
     def _pointwise_forward(self, x, out, act, residual, residual_mode, raw):
         """The layer through csrc/pointwise_conv.hip, or None when that kernel does not take the problem (then the library GEMM + epilogue launch
         as before).  ``raw``: the convolution output without bias and activation (the depthwise consumer applies them)."""
@@ -308,10 +330,13 @@ class FusedConv2d(nn.Module):
         dst = out if out is not None else torch.empty((B, k[0], H, W), device=x.device, dtype=torch.float32)
         return _ops.pointwise_conv_into(x, self._pointwise_packed, None if raw else self.bias, dst, k[0], act, residual, residual_mode)
 
-    def _bottleneck_for(self, x):
+    def _bottleneck_for(self, x, shape=None):
         """The partial-sum buffer for this input shape if the bottleneck kernel takes the problem (else None); packs the weights the
-        first time (outside a stream capture: the first frame of every kind runs eagerly)."""
-        key = tuple(x.shape)
+        first time (outside a stream capture: the first frame of every kind runs eagerly).  ``shape``: the shape of the map the layer convolves
+        when that is not ``x`` itself (``forward_upsampled``)."""
+        key = tuple(x.shape) if shape is None else tuple(shape)
+        if shape is not None:
+            x = _ShapeOn(key, x.device)
         if key not in self._bottleneck_buffers:
             k = self.weight.shape
             ok = (not self.depthwise and self.groups == 1 and k[2] == 3 and k[3] == 3 and tuple(self.padding) == (1, 1) and
@@ -1083,7 +1108,11 @@ class DepthEngine:
         if depth_head is not None:
             with self._beside("heads"):      # (reads the previous level's output, writes the last channel of ``cat``: nothing the up-convolution touches)
                 self._upsampled_depth_head(depth_head, depth_input, cat[:, -1:])
-        block.up_convolution.conv[0](_ops.upsample2x(x), out=cat[:, :up_channels])
+        up_conv = block.up_convolution.conv[0]
+        if isinstance(up_conv, FusedConv2d):
+            up_conv.forward_upsampled(x, out=cat[:, :up_channels])
+        else:
+            up_conv(_ops.upsample2x(x), out=cat[:, :up_channels])
         self._join_beside()
         return block.convolution2[0](block.convolution1[0](cat))
 

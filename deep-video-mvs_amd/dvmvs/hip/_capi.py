@@ -65,6 +65,7 @@ SIGNATURES = {
     "dvmvs_bottleneck_conv_pack": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_stream]),
     "dvmvs_bottleneck_conv_splits": (_c_int, [_c_int] * 6),
     "dvmvs_bottleneck_conv_fwd": (_c_int, [_c_fp, _c_fp, _c_fp] + [_c_int] * 6 + [_c_stream]),
+    "dvmvs_bottleneck_conv_up2x_fwd": (_c_int, [_c_fp, _c_fp, _c_fp] + [_c_int] * 5 + [_c_stream]),
     "dvmvs_direct_conv_tile": (_c_int, [_c_int] * 7),
     "dvmvs_direct_conv_packed_bytes": (ctypes.c_size_t, [_c_int] * 4),
     "dvmvs_direct_conv_pack": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),

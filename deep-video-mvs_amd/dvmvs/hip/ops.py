@@ -750,19 +750,27 @@ def bottleneck_conv_pack(weight: Tensor) -> Tensor:
     return packed
 
 
-def bottleneck_conv_into(x: Tensor, packed: Tensor, C_out: int, stride: int, partials: Tensor) -> int:
+def bottleneck_conv_into(x: Tensor, packed: Tensor, C_out: int, stride: int, partials: Tensor, upsample: bool = False) -> int:
     """3x3, padding 1 convolution of ``x`` [B,C_in,H,W] with ``bottleneck_conv_pack``-ed weights as K-split partial sums into
     ``partials`` (at least splits * B * C_out * H_out * W_out floats, laid out [split][B][C_out][H_out*W_out]).  Returns the number of
-    splits; the consumer adds them in ascending order (``partial_sums_bias_act_into`` / ``lstm_gates_partials_into``)."""
+    splits; the consumer adds them in ascending order (``partial_sums_bias_act_into`` / ``lstm_gates_partials_into``).
+    ``upsample``: the layer convolves the 2x bilinear up-sampling (align_corners=True, ``upsample2x``'s values bit for bit) of ``x``
+    [B,C_in,H/2,W/2], interpolated while the input is staged (dvmvs_bottleneck_conv_up2x_fwd: the 16x20 map, stride 1)."""
     _dev_f32("bottleneck_conv_into", x, packed, partials)
     B, C_in, H, W = x.shape
-    splits = bottleneck_conv_splits(B, C_out, C_in, H, W, stride)
+    if upsample:
+        H, W = 2 * H, 2 * W
+    splits = bottleneck_conv_splits(B, C_out, C_in, H, W, stride) if not upsample or (H, W, stride) == (16, 20, 1) else 0
     if splits == 0:
-        raise ValueError(f"dvmvs::bottleneck_conv_into: problem {tuple(x.shape)} -> {C_out} (stride {stride}) is not one of the bottleneck shapes")
+        raise ValueError(f"dvmvs::bottleneck_conv_into: problem {tuple(x.shape)} -> {C_out} (stride {stride}{', up-sampled' if upsample else ''}) "
+                         f"is not one of the bottleneck shapes")
     if not x.is_contiguous() or partials.numel() < splits * B * C_out * (H // stride) * (W // stride) or not partials.is_contiguous():
         raise ValueError("dvmvs::bottleneck_conv_into: expected a contiguous input and a partial-sum buffer of splits * B * C_out * H_out * W_out floats")
     with torch.cuda.device(x.device):
-        rc = _capi.lib().dvmvs_bottleneck_conv_fwd(_ptr(x), _ptr(packed), _ptr(partials), B, C_in, H, W, int(C_out), int(stride), _stream(x))
+        if upsample:
+            rc = _capi.lib().dvmvs_bottleneck_conv_up2x_fwd(_ptr(x), _ptr(packed), _ptr(partials), B, C_in, H, W, int(C_out), _stream(x))
+        else:
+            rc = _capi.lib().dvmvs_bottleneck_conv_fwd(_ptr(x), _ptr(packed), _ptr(partials), B, C_in, H, W, int(C_out), int(stride), _stream(x))
     _capi.check(rc, "dvmvs_bottleneck_conv_fwd")
     return splits
 

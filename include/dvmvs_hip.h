@@ -284,6 +284,12 @@ int dvmvs_bottleneck_conv_pack(const float* weight, float* packed, int C_out, in
 int dvmvs_bottleneck_conv_splits(int B, int C_out, int C_in, int H_in, int W_in, int stride);
 int dvmvs_bottleneck_conv_fwd(const float* x, const float* packed, float* partials, int B, int C_in, int H_in, int W_in, int C_out,
                               int stride, dvmvs_stream_t stream);
+/* (ABI 8) dvmvs_bottleneck_conv_fwd on the 2x bilinear up-sampling (align_corners = True: dvmvs_upsample2x_fwd's values, bit for bit) of
+ * x [B,C_in,H_in/2,W_in/2], interpolated while the input is staged -- the decoder's first up-convolution without the up-sampling launch in
+ * front of it (/root/reference/dvmvs/fusionnet/model.py UpconvolutionLayer).  H_in x W_in = 16 x 20 (the up-sampled map), stride 1; same
+ * split count and partial-sum layout as dvmvs_bottleneck_conv_fwd for that shape. */
+int dvmvs_bottleneck_conv_up2x_fwd(const float* x, const float* packed, float* partials, int B, int C_in, int H_in, int W_in, int C_out,
+                                   dvmvs_stream_t stream);
 int dvmvs_partial_sums_bias_act_fwd(const float* partials, int n_partials, float* dst, long long dst_batch_stride, const float* bias,
                                     int B, int C, int HW, int activation, dvmvs_stream_t stream);
 int dvmvs_lstm_gates_partials_fwd(const float* conv_partials, int n_partials, const float* c_cur, float* h_next, float* c_next,

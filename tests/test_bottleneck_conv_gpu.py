@@ -29,6 +29,24 @@ def problem(C_in, C_out, H, W, B, seed):
     return x, w, bias
 
 
+@pytest.mark.parametrize("channels", [(512, 256), (64, 40)])
+@pytest.mark.parametrize("B", [1, 2])
+def test_upsampling_inside_the_staging_gives_the_bits_of_the_two_launches(ops, hip_device, channels, B):
+    """dvmvs_bottleneck_conv_up2x_fwd (round 6): the decoder's first up-convolution reads the 8x10 map and interpolates the 16x20 one while it
+    stages its input -- the same partial sums, bit for bit, as dvmvs_upsample2x_fwd followed by dvmvs_bottleneck_conv_fwd."""
+    C_in, C_out = channels
+    x, w, _ = problem(C_in, C_out, 8, 10, B, seed=7 + C_in)
+    x = x.to(hip_device)
+    packed = ops.bottleneck_conv_pack(w.to(hip_device))
+    S = ops.bottleneck_conv_splits(B, C_out, C_in, 16, 20, 1)
+    two, one = (torch.full((S * B * C_out * 320,), float("nan"), device=hip_device) for _ in range(2))
+    assert ops.bottleneck_conv_into(ops.upsample2x(x), packed, C_out, 1, two) == S
+    assert ops.bottleneck_conv_into(x, packed, C_out, 1, one, upsample=True) == S
+    assert not torch.isnan(one).any() and torch.equal(one, two)
+    with pytest.raises(ValueError):
+        ops.bottleneck_conv_into(torch.zeros(B, C_in, 16, 20, device=hip_device), packed, C_out, 1, one, upsample=True)      # only the 8x10 -> 16x20 layer
+
+
 def test_split_count_respects_the_lds_budget(ops):
     """A large batch needs few splits for its wave count, but a split's slice of x must still fit the 64 KB a workgroup stages it in
     (round 4, first form: batch 8 of the ConvLSTM layer asked for 2 splits = 512 channels x 120 padded pixels = 240 KB and the launch
