@@ -14,6 +14,19 @@ extern "C" const char* dvmvs_error_string(int code) {
   return "dvmvs: unknown error";
 }
 
+// Whether a kernel running on the CURRENT device may read host memory at address p as it is: pinned (hipHostMalloc / hipHostRegister) and mapped
+// at the same address.  The frame engine asks this once per staging slot before it lets dvmvs_copy_batch read its parameter block out of
+// pinned memory; anything else (pageable memory, a mapping at another address, an error) answers 0 and the engine keeps the runtime's copy.
+extern "C" int dvmvs_host_pointer_device_visible(const void* p) {
+  if (!p) return 0;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();      // (pageable memory is reported as an error: not one of ours)
+    return 0;
+  }
+  return attr.type == hipMemoryTypeHost && attr.devicePointer == p ? 1 : 0;
+}
+
 // A kernel that does nothing, with a name nothing else in a process has: bench.py --mark-region launches it right before and right
 // after its timed loop so that tools/summarize_trace.py can cut the loop out of a rocprofv3 kernel trace.
 namespace dvmvs {

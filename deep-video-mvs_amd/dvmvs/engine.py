@@ -644,6 +644,7 @@ class DepthEngine:
         self._switch_interval_before = None
         self._filler_buffers, self._filler_graphs = None, []
         self._copy_queue = None      # a list while step() collects its input copies (see _copy)
+        self._staging_seen = {}      # staging slot address -> whether the device may read it in place (see _staging_visible)
         self.warm_captured_graphs = os.environ.get("DVMVS_WARM_GRAPHS", "1") != "0"
         # launches of every newly captured graph on throw-away results: the runtime finishes setting a graph up over its first launches (a
         # 5-6 ms device stall was still seen at a graph's third launch, i.e. a few steps into a short run's timed region, with one)
@@ -947,7 +948,7 @@ class DepthEngine:
         staging.copy_(mirror)
         with torch.cuda.device(self.device):     # the ring guard must be recorded on the engine's device, whichever is current
             params = self._static["params"]
-            if pending_copies and len(pending_copies) < 8 and _UPLOAD_IN_COPY_BATCH:
+            if pending_copies and len(pending_copies) < 8 and _UPLOAD_IN_COPY_BATCH and self._staging_visible(staging):
                 # the block goes up in the SAME launch as the frame's input copies (round 6): the copy kernel reads the pinned staging slot through
                 # its device-visible address -- the runtime's own copy of a pinned buffer is a blit kernel too (__amd_rocclr_copyBuffer), one
                 # launch more per frame
@@ -962,6 +963,15 @@ class DepthEngine:
                 params.copy_(staging, non_blocking=True)
             event.record(torch.cuda.current_stream(self.device))
         return result
+
+    def _staging_visible(self, staging):
+        """Whether kernels on the engine's device may read this pinned staging slot directly (asked once per slot: dvmvs_host_pointer_device_visible)."""
+        key = staging.data_ptr()
+        seen = self._staging_seen.get(key)
+        if seen is None:
+            from dvmvs.hip import _capi
+            seen = self._staging_seen[key] = bool(staging.is_pinned() and key % 16 == 0 and _capi.lib().dvmvs_host_pointer_device_visible(key))
+        return seen
 
     def _evaluate_frame_parameters(self, mirror, n_meas, pose, measurement_poses, full_K, previous_pose, no_previous, index, own_sweep, next_frame):
         """The host half of ``_upload_frame_parameters``: evaluates the matrices, the sweep configuration and the work list and writes

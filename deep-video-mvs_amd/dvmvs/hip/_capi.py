@@ -34,6 +34,7 @@ SIGNATURES = {
     "dvmvs_build_arch": (ctypes.c_char_p, []),
     "dvmvs_error_string": (ctypes.c_char_p, [_c_int]),
     "dvmvs_trace_marker": (_c_int, [_c_stream]),
+    "dvmvs_host_pointer_device_visible": (_c_int, [ctypes.c_void_p]),
     "dvmvs_cost_volume_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "dvmvs_sweep_matrices": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_stream]),
     "dvmvs_cost_volume_fwd": (_c_int, [_c_fp, _c_fpp, _c_fp, _c_fp, _c_fp,

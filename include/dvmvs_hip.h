@@ -38,7 +38,7 @@ extern "C" {
  * Variant 6 of dvmvs_cost_volume_fwd runs as one persistent 16-wave workgroup per CU where the problem allows (csrc/sweep_mfma.hip): same
  * arguments, bit-identical volumes.
  * ABI 8 (round 6) = ABI 7 + the 1x1 convolution with bias, ReLU and the residual add in its store path (dvmvs_pointwise_conv_*); no earlier
- * signature changed. */
+ * signature changed; dvmvs_bottleneck_conv_up2x_fwd and the 32x40 stride-2 shape of dvmvs_bottleneck_conv_fwd; dvmvs_host_pointer_device_visible. */
 #define DVMVS_ABI_VERSION 8
 #define DVMVS_MAX_MEASUREMENTS 8      /* measurement frames fused per launch */
 #define DVMVS_MAX_DEPTH_LEVELS 256    /* sweep planes per launch */
@@ -182,6 +182,9 @@ int dvmvs_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W,
  * ONE launch -- the small copies a frame step makes in front of its graph (features into the feature cache, measurement maps and the next
  * image into the buffers the graph reads).  Ranges must not overlap each other (the copies run concurrently). */
 int dvmvs_copy_batch(const float* const* srcs, float* const* dsts, const long long* n_floats, int n, dvmvs_stream_t stream);
+/* (ABI 8) A source of dvmvs_copy_batch may also be PINNED HOST memory that the device sees at the same address (the frame engine's parameter
+ * block rides up in the frame's copy batch instead of a blit launch of its own): 1 when p is such memory for the current device, else 0. */
+int dvmvs_host_pointer_device_visible(const void* p);
 int dvmvs_sweep_work_list(const float* Hm_host, const float* kt_host, int B, int M, int H, int W, int D,
                           double min_depth, double max_depth, int configuration, unsigned int* work_list_host, size_t work_list_bytes);
 int dvmvs_cost_volume_planned_fwd(const float* image1, const float* const* image2s, const float* Hm, const float* kt,

@@ -151,3 +151,14 @@ def test_nchw_to_nhwc_and_copy_batch(ops, hip_device):
     assert not ops.batchable(torch.zeros(1, 32, 8, 8, device=dev), torch.zeros(1, 32, 8, 8, device=dev).contiguous(memory_format=torch.channels_last))
     with pytest.raises(RuntimeError):
         ops.copy_batch([(torch.zeros(9, device=dev)[1:], torch.zeros(8, device=dev))])
+    # round 6: a source may be pinned host memory the device sees at the same address (the engine's parameter block rides in the frame's batch)
+    from dvmvs.hip import _capi
+    pinned, pageable = torch.randn(1024, generator=g).pin_memory(), torch.randn(1024, generator=g)
+    with torch.cuda.device(dev):
+        assert _capi.lib().dvmvs_host_pointer_device_visible(pinned.data_ptr()) == 1
+        assert _capi.lib().dvmvs_host_pointer_device_visible(pageable.data_ptr()) == 0
+        assert _capi.lib().dvmvs_host_pointer_device_visible(None) == 0
+    up, other = torch.zeros(1024, device=dev), torch.zeros(8, device=dev)
+    ops.copy_batch([(other, torch.ones(8, device=dev)), (up, pinned)])
+    torch.cuda.synchronize()
+    assert torch.equal(up.cpu(), pinned) and float(other.min()) == 1.0
