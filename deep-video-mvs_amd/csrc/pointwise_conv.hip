@@ -4,7 +4,7 @@
 // Which layers (fusionnet/model.py:20-77: the MnasNet feature extractor's expansion / projection layers and the feature-pyramid's lateral
 // layers; pairnet alike): 36 launches of a frame.  They were MIOpen's 1x1 path -- a rocBLAS GEMM of 4.7 - 10.8 us per layer -- followed,
 // for the 22 of them that are not directly consumed by a depthwise layer, by one dvmvs_bias_act_fwd launch (bias, activation, residual:
-// 3.9 - 4.9 us each): 234 + 97 us of kernel time of a 1 207 us frame (profiles/r06_bench_timed_region_lookahead1.csv).
+// 3.9 - 4.9 us each): 234 + 97 us of kernel time of a 1 207 us frame (profiles/r06_first_half_bench_timed_region_lookahead1.csv).
 //
 // The problems are tiny -- out[co, p] = sum_ci W[co, ci] x[ci, p] with 16 ... 1 152 channels on either side and 80 ... 20 480 pixels: 31 MFLOP at
 // most, a fraction of a microsecond of the matrix cores -- so a launch costs what its longest dependent chain of memory round trips costs.
