@@ -1002,7 +1002,7 @@ def main():
         try:     # ... and the count a rocprofv3 kernel trace of THIS command's timed region recorded at the benchmarked look-ahead level
             import glob      # (profiles/, per round: the newest round that has one)
             level = 0 if args.no_feature_cache else args.lookahead
-            region = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_timed_region_lookahead{level}.csv")))[-1]
+            region = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_bench_timed_region_lookahead{level}.csv")))[-1]
             last = open(region).read().strip().splitlines()[-1].split(",")
             launches_per_frame.update(profiled=float(last[5]) / float(last[7]), profiled_source=os.path.relpath(region, ROOT), profiled_lookahead=level)
         except Exception:
