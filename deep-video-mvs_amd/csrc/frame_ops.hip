@@ -111,14 +111,14 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
 // is computed by the expression above from the same rounded products, so the two kernels agree bit for bit; taken when the rows allow
 // aligned float4 stores (OW % 4 == 0 always; destination and batch stride 16-byte aligned).
 template <int PRE>
-__global__ __launch_bounds__(256) void upsample2x_quads_kernel(const float* __restrict__ in, float* __restrict__ out, long long out_batch_stride,
-                                                               const float* __restrict__ pre_bias, int C, int H, int W) {
+__device__ inline void upsample2x_quads_plane(const float* __restrict__ in, float* __restrict__ out, long long out_batch_stride, const float* __restrict__ pre_bias,
+                                              int pl, int C, int H, int W) {
 #pragma clang fp contract(off)
   typedef float float4v __attribute__((ext_vector_type(4)));
   const int OH = 2 * H, OW = 2 * W, QW = OW >> 2;
   const float sh = OH > 1 ? static_cast<float>(H - 1) / static_cast<float>(OH - 1) : 0.0f;
   const float sw = OW > 1 ? static_cast<float>(W - 1) / static_cast<float>(OW - 1) : 0.0f;
-  const int pl = blockIdx.y, b = pl / C, c = pl - b * C;
+  const int b = pl / C, c = pl - b * C;
   const float* p = in + static_cast<size_t>(pl) * H * W;
   const float bv = (PRE != 0 && pre_bias) ? pre_bias[c] : 0.0f;
   float* dst = out + static_cast<size_t>(b) * out_batch_stride + static_cast<size_t>(c) * OH * OW;
@@ -143,6 +143,23 @@ __global__ __launch_bounds__(256) void upsample2x_quads_kernel(const float* __re
     }
     *reinterpret_cast<float4v*>(dst + oy * OW + ox) = v;
   }
+}
+
+template <int PRE>
+__global__ __launch_bounds__(256) void upsample2x_quads_kernel(const float* __restrict__ in, float* __restrict__ out, long long out_batch_stride,
+                                                               const float* __restrict__ pre_bias, int C, int H, int W) {
+  upsample2x_quads_plane<PRE>(in, out, out_batch_stride, pre_bias, blockIdx.y, C, H, W);
+}
+
+// Two up-samplings of maps of the same size in ONE launch (round 6): planes [0, B*C1) are job 1 (no pre-activation), the rest job 2 (PRE2) -- a decoder
+// level's feature map and its one-channel depth head (raw convolution output -> bias + sigmoid on the taps), which the frame launched back to back.
+template <int PRE2>
+__global__ __launch_bounds__(256) void upsample2x_pair_quads_kernel(const float* __restrict__ in1, float* __restrict__ out1, long long out1_batch_stride, int C1,
+                                                                    const float* __restrict__ in2, float* __restrict__ out2, long long out2_batch_stride,
+                                                                    const float* __restrict__ pre_bias2, int C2, int planes1, int H, int W) {
+  const int pl = blockIdx.y;
+  if (pl < planes1) upsample2x_quads_plane<0>(in1, out1, out1_batch_stride, nullptr, pl, C1, H, W);
+  else upsample2x_quads_plane<PRE2>(in2, out2, out2_batch_stride, pre_bias2, pl - planes1, C2, H, W);
 }
 
 // Depthwise k x k convolution (groups == channels, "same" padding k/2, stride 1 or 2) with the bias add and activation
@@ -302,6 +319,32 @@ extern "C" int dvmvs_upsample2x_fwd(const float* in, float* out, long long out_b
   if (pre_activation == 1) hipLaunchKernelGGL(upsample2x_kernel<1>, grid, block, 0, s, in, out, out_batch_stride, pre_bias, B * C, C, H, W);
   else if (pre_activation == 2) hipLaunchKernelGGL(upsample2x_kernel<2>, grid, block, 0, s, in, out, out_batch_stride, pre_bias, B * C, C, H, W);
   else hipLaunchKernelGGL(upsample2x_kernel<0>, grid, block, 0, s, in, out, out_batch_stride, pre_bias, B * C, C, H, W);
+  return launch_status();
+}
+
+extern "C" int dvmvs_upsample2x_pair_fwd(const float* in1, float* out1, long long out1_batch_stride, int C1, const float* in2, float* out2,
+                                         long long out2_batch_stride, const float* pre_bias2, int pre_activation2, int C2, int B, int H, int W,
+                                         dvmvs_stream_t stream) {
+  using namespace dvmvs;
+  if (!in1 || !out1 || !in2 || !out2 || B <= 0 || C1 <= 0 || C2 <= 0 || H <= 0 || W <= 0) return DVMVS_EINVAL;
+  if (pre_activation2 < 0 || pre_activation2 > 2) return DVMVS_EINVAL;
+  if (out1_batch_stride == 0) out1_batch_stride = static_cast<long long>(C1) * H * W * 4;
+  if (out2_batch_stride == 0) out2_batch_stride = static_cast<long long>(C2) * H * W * 4;
+  if (out1_batch_stride < static_cast<long long>(C1) * H * W * 4 || out2_batch_stride < static_cast<long long>(C2) * H * W * 4) return DVMVS_EINVAL;
+  const long long planes = static_cast<long long>(B) * (C1 + C2);
+  const bool quads = W % 2 == 0 && ((reinterpret_cast<uintptr_t>(out1) | reinterpret_cast<uintptr_t>(out2)) & 15) == 0 && ((out1_batch_stride | out2_batch_stride) & 3) == 0 &&
+                     planes <= 65535 && static_cast<long long>(H) * W < (1LL << 27);
+  if (!quads) {      // (destinations that do not allow 16-byte stores: the two launches)
+    const int rc = dvmvs_upsample2x_fwd(in1, out1, out1_batch_stride, nullptr, 0, B, C1, H, W, stream);
+    return rc != 0 ? rc : dvmvs_upsample2x_fwd(in2, out2, out2_batch_stride, pre_bias2, pre_activation2, B, C2, H, W, stream);
+  }
+  const int n_quads = 2 * H * (W / 2);
+  const int per_plane = max(1, min((n_quads + 255) / 256, max(1, 4096 / static_cast<int>(planes))));
+  const dim3 grid(static_cast<unsigned>(per_plane), static_cast<unsigned>(planes)), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define DVMVS_UP2(P) hipLaunchKernelGGL(upsample2x_pair_quads_kernel<P>, grid, block, 0, s, in1, out1, out1_batch_stride, C1, in2, out2, out2_batch_stride, pre_bias2, C2, B * C1, H, W)
+  if (pre_activation2 == 1) DVMVS_UP2(1); else if (pre_activation2 == 2) DVMVS_UP2(2); else DVMVS_UP2(0);
+#undef DVMVS_UP2
   return launch_status();
 }
 

@@ -73,6 +73,7 @@ _STAGING_SLOTS = int(os.environ.get("DVMVS_STAGING_SLOTS", "1"))
 _GRAPH_QUEUE_FILLERS = int(os.environ.get("DVMVS_GRAPH_QUEUE_FILLERS", "1"))
 # experiments: "1" = a frame's sweep runs before the side-stream fork instead of next to the side stream's kernels (see _frame_body_direct)
 _SWEEP_FIRST = os.environ.get("DVMVS_SWEEP_FIRST", "0") == "1"
+_PAIRED_UPSAMPLING = os.environ.get("DVMVS_PAIRED_UPSAMPLING", "1") != "0"      # a decoder level's two up-samplings in one launch
 _UP2X_IN_CONV = os.environ.get("DVMVS_UP2X_IN_CONV", "1") != "0"      # the decoder's first up-sampling inside its convolution's staging
 _UPLOAD_IN_COPY_BATCH = os.environ.get("DVMVS_UPLOAD_IN_COPY_BATCH", "1") != "0"
 _AUX_STREAM = os.environ.get("DVMVS_AUX_STREAM", "0")      # "0" off, "warp" / "heads" one of the two uses, "1" both (see DepthEngine._aux_stream)
@@ -1115,10 +1116,18 @@ class DepthEngine:
         slice has already been written by the encoder's aggregator.  ``depth_head`` (the previous level's depth layer) runs as raw
         convolution and its bias + sigmoid are applied inside the up-sampling kernel."""
         up_channels = block.up_convolution.conv[0].weight.shape[0]
+        up_conv = block.up_convolution.conv[0]
+        if depth_head is not None and _PAIRED_UPSAMPLING and self._aux_stream is None:
+            # the level's two up-samplings -- its feature map for the up-convolution, its depth head (raw convolution, bias + sigmoid on the taps) into the
+            # last channel of ``cat`` -- in ONE launch (round 6; the same bits as the two)
+            B, C, H, W = x.shape
+            up = torch.empty((B, C, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+            _ops.upsample2x_pair_into(x, up, depth_head[0](depth_input, raw=True), cat[:, -1:], depth_head[0].bias, _ops.ACTIVATIONS["sigmoid"])
+            up_conv(up, out=cat[:, :up_channels])
+            return block.convolution2[0](block.convolution1[0](cat))
         if depth_head is not None:
             with self._beside("heads"):      # (reads the previous level's output, writes the last channel of ``cat``: nothing the up-convolution touches)
                 self._upsampled_depth_head(depth_head, depth_input, cat[:, -1:])
-        up_conv = block.up_convolution.conv[0]
         if isinstance(up_conv, FusedConv2d):
             up_conv.forward_upsampled(x, out=cat[:, :up_channels])
         else:
@@ -1312,10 +1321,14 @@ class DepthEngine:
         d3 = self._decoder_block_direct(dec.decoder_block3, d2, dec_cat[2], dec.depth_layer_one_eight, d2)
         d4 = self._decoder_block_direct(dec.decoder_block4, d3, dec_cat[3], dec.depth_layer_quarter, d3)
         full_in = buffers["full_in"]
-        with self._beside("heads"):
-            self._upsampled_depth_head(dec.depth_layer_half, d4, full_in[:, 32:33])
-        _ops.upsample2x_into(d4, full_in[:, :32])
-        self._join_beside()
+        if _PAIRED_UPSAMPLING and self._aux_stream is None:
+            _ops.upsample2x_pair_into(d4, full_in[:, :32], dec.depth_layer_half[0](d4, raw=True), full_in[:, 32:33], dec.depth_layer_half[0].bias,
+                                      _ops.ACTIVATIONS["sigmoid"])
+        else:
+            with self._beside("heads"):
+                self._upsampled_depth_head(dec.depth_layer_half, d4, full_in[:, 32:33])
+            _ops.upsample2x_into(d4, full_in[:, :32])
+            self._join_beside()
         refined = dec.refine[1][0](dec.refine[0][0](full_in))
         # last convolution: bias + sigmoid + depth mapping (model.py:231-232) in one epilogue, into the depth / previous-depth buffer
         dec.depth_layer_full[0](refined, out=s["prev_depth"], activation=_ops.ACTIVATION_SIGMOID_TO_DEPTH,

@@ -85,6 +85,7 @@ SIGNATURES = {
     "dvmvs_bias_act_inplace": (_c_int, [_c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_conv_bias_act_fwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_longlong] + [_c_int] * 9 + [_c_stream]),
     "dvmvs_upsample2x_fwd": (_c_int, [_c_fp, _c_fp, ctypes.c_longlong, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "dvmvs_upsample2x_pair_fwd": (_c_int, [_c_fp, _c_fp, ctypes.c_longlong, _c_int, _c_fp, _c_fp, ctypes.c_longlong, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_upsample2x_bwd": (_c_int, [_c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "dvmvs_depthwise_conv_bwd_workspace_bytes": (ctypes.c_size_t, [_c_int] * 6),
     "dvmvs_depthwise_conv_bwd": (_c_int, [_c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_fp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),

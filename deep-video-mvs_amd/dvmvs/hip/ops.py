@@ -715,6 +715,26 @@ def upsample2x_into(x: Tensor, dst: Tensor, pre_bias=None, pre_activation: int =
     return dst
 
 
+def upsample2x_pair_into(x1: Tensor, dst1: Tensor, x2: Tensor, dst2: Tensor, pre_bias2=None, pre_activation2: int = 0) -> None:
+    """``upsample2x_into(x1, dst1)`` and ``upsample2x_into(x2, dst2, pre_bias2, pre_activation2)`` for two maps of the same size in ONE launch
+    (dvmvs_upsample2x_pair_fwd: a decoder level's feature map and its depth head); the same values bit for bit."""
+    _dev_f32("upsample2x_pair_into", x1, x2)
+    x1, x2 = x1.contiguous(), x2.contiguous()
+    B, C1, H, W = x1.shape
+    C2 = x2.shape[1]
+    if tuple(x2.shape) != (B, C2, H, W):
+        raise ValueError(f"dvmvs::upsample2x_pair_into: the two maps must have the same batch and size, got {tuple(x1.shape)} and {tuple(x2.shape)}")
+    stride1 = _slice_batch_stride("upsample2x_pair_into", dst1, B, C1, 2 * H, 2 * W)
+    stride2 = _slice_batch_stride("upsample2x_pair_into", dst2, B, C2, 2 * H, 2 * W)
+    if pre_bias2 is not None and pre_bias2.numel() not in (0, C2):
+        raise ValueError(f"dvmvs::upsample2x_pair_into: pre_bias2 has {pre_bias2.numel()} entries for {C2} channels")
+    with torch.cuda.device(x1.device):
+        rc = _capi.lib().dvmvs_upsample2x_pair_fwd(_ptr(x1), _ptr(dst1), stride1, C1, _ptr(x2), _ptr(dst2), stride2,
+                                                   _ptr(pre_bias2) if pre_bias2 is not None and pre_bias2.numel() else None, int(pre_activation2), C2, B, H, W,
+                                                   _stream(x1))
+    _capi.check(rc, "dvmvs_upsample2x_pair_fwd")
+
+
 def lstm_gates_into(combined_conv: Tensor, c_state: Tensor, h_state: Tensor) -> None:
     """State update in place: c_state <- c', h_state <- h' (the kernel reads a row of c completely before it writes it)."""
     _dev_f32("lstm_gates_into", combined_conv, c_state, h_state)

@@ -38,7 +38,7 @@ extern "C" {
  * Variant 6 of dvmvs_cost_volume_fwd runs as one persistent 16-wave workgroup per CU where the problem allows (csrc/sweep_mfma.hip): same
  * arguments, bit-identical volumes.
  * ABI 8 (round 6) = ABI 7 + the 1x1 convolution with bias, ReLU and the residual add in its store path (dvmvs_pointwise_conv_*); no earlier
- * signature changed; dvmvs_bottleneck_conv_up2x_fwd and the 32x40 stride-2 shape of dvmvs_bottleneck_conv_fwd; dvmvs_host_pointer_device_visible. */
+ * signature changed; dvmvs_bottleneck_conv_up2x_fwd and the 32x40 stride-2 shape of dvmvs_bottleneck_conv_fwd; dvmvs_host_pointer_device_visible, dvmvs_upsample2x_pair_fwd. */
 #define DVMVS_ABI_VERSION 8
 #define DVMVS_MAX_MEASUREMENTS 8      /* measurement frames fused per launch */
 #define DVMVS_MAX_DEPTH_LEVELS 256    /* sweep planes per launch */
@@ -406,6 +406,12 @@ int dvmvs_bias_act_inplace(float* x, const float* bias, const float* residual, i
                            int activation, dvmvs_stream_t stream);
 int dvmvs_upsample2x_fwd(const float* in, float* out, long long out_batch_stride, const float* pre_bias, int pre_activation,
                          int B, int C, int H, int W, dvmvs_stream_t stream);
+/* (ABI 8) Two dvmvs_upsample2x_fwd of maps of the same size [B,C1,H,W] and [B,C2,H,W] in ONE launch: job 1 without pre-activation, job 2 with
+ * pre_bias2 / pre_activation2 (a decoder level's feature map and its one-channel depth head, /root/reference/dvmvs/fusionnet/model.py:262-296);
+ * the same values bit for bit. */
+int dvmvs_upsample2x_pair_fwd(const float* in1, float* out1, long long out1_batch_stride, int C1, const float* in2, float* out2,
+                              long long out2_batch_stride, const float* pre_bias2, int pre_activation2, int C2, int B, int H, int W,
+                              dvmvs_stream_t stream);
 /*
  *   dvmvs_conv_bias_act_fwd: a dense convolution (square kernel K, zero padding, no dilation, one group) WITH its epilogue, as one
  *                           MIOpen fusion plan (convolution + bias [+ ReLU]): out = act(conv(x, weight) + bias[c]).  The convolution

@@ -646,6 +646,26 @@ def test_upsample2x_matches_aten(ops, dev):
             assert torch.equal(misaligned, got), shape
 
 
+def test_paired_upsampling_gives_the_bits_of_the_two_launches(ops, dev):
+    """dvmvs_upsample2x_pair_fwd (round 6): a decoder level's feature map and its one-channel depth head (raw convolution output, bias + sigmoid on
+    the taps) up-sampled in ONE launch -- channel-slice destinations, batches, and a destination that forces the two-launch fallback."""
+    g = torch.Generator().manual_seed(23)
+    for (B, C, H, W) in ((1, 128, 32, 40), (2, 5, 6, 8), (1, 32, 128, 160), (1, 3, 5, 7)):
+        x, raw, hb = torch.randn(B, C, H, W, generator=g).to(dev), (torch.randn(B, 1, H, W, generator=g) * 2).to(dev), torch.randn(1, generator=g).to(dev)
+        cat_two, cat_one = (torch.full((B, C + 3, 2 * H, 2 * W), 7.0, device=dev) for _ in range(2))
+        up_two, up_one = (torch.full((B, C, 2 * H, 2 * W), float("nan"), device=dev) for _ in range(2))
+        ops.upsample2x_into(x, up_two)
+        ops.upsample2x_into(raw, cat_two[:, -1:], hb, ops.ACTIVATIONS["sigmoid"])
+        ops.upsample2x_pair_into(x, up_one, raw, cat_one[:, -1:], hb, ops.ACTIVATIONS["sigmoid"])
+        assert torch.equal(up_one, up_two) and torch.equal(cat_one, cat_two), (B, C, H, W)
+        misaligned = torch.empty(B * C * 4 * H * W + 1, device=dev)[1:].view(B, C, 2 * H, 2 * W)      # 4-byte aligned: the fallback
+        ops.upsample2x_pair_into(x, misaligned, raw, cat_one[:, -1:], hb, ops.ACTIVATIONS["sigmoid"])
+        assert torch.equal(misaligned, up_two) and torch.equal(cat_one, cat_two)
+    with pytest.raises(ValueError):
+        ops.upsample2x_pair_into(torch.zeros(1, 4, 8, 8, device=dev), torch.zeros(1, 4, 16, 16, device=dev), torch.zeros(1, 1, 4, 4, device=dev),
+                                 torch.zeros(1, 1, 8, 8, device=dev))
+
+
 def test_fused_modules_match_plain_modules(dev):
     """BN folding + epilogue fusion (what the engine runs) against the untouched modules on the GPU."""
     from dvmvs.engine import fold_batchnorm, fuse_epilogues
