@@ -1634,6 +1634,8 @@ class DepthEngine:
                         sub._bottleneck_packed.copy_(_ops.bottleneck_conv_pack(sub.weight.detach()))
                     for tile, packed in sub._direct_packed.items():
                         packed.copy_(_ops.direct_conv_pack(sub.weight.detach(), tile))
+                    if sub._pointwise_packed is not None:
+                        sub._pointwise_packed.copy_(_ops.pointwise_conv_pack(sub.weight.detach()))
         if self._lstm_packed is not None:
             self._lstm_packed.copy_(_ops.bottleneck_conv_pack(self.lstm.lstm_cell.conv.weight.detach()))
 

@@ -488,3 +488,51 @@ def test_planning_a_frame_ahead_is_bit_identical(hip_device):
         assert torch.equal(a, b), n
     print(f"parameter blocks taken from the planning thread: {ahead.planned_frames_used} of {sum(f[0] is not None for f in frames)} frames")
     assert ahead.planned_frames_used >= 6 and inline.planned_frames_used == 0
+
+
+def test_refresh_weights_repacks_every_kernel_copy(hip_device):
+    """The MFMA convolution kernels read re-packed copies of the weights (direct, bottleneck, 1x1 -- round 6 --, ConvLSTM), made at first use and
+    baked into the captured graphs.  After new parameters are loaded into the engine's modules, ``refresh_weights`` re-packs them in place: the
+    engine must then give, bit for bit, what an engine that saw the new parameters from the start gives."""
+    from dvmvs.engine import FusedConv2d
+    dev = hip_device
+    _, used = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
+    _, fresh = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
+    fullK = syn.full_K()
+    frames = list(syn.E2E_FRAMES) + [(12, (11, 9)), (13, (12, 10))]
+
+    def run(engine):
+        engine.reset()
+        out = []
+        for r, ms in frames:
+            out.append(engine.step(syn.e2e_image(r).to(dev), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK,
+                                   frame_id=r, measurement_ids=list(ms)).clone())
+        return out
+
+    def perturb(engine):
+        n = 0
+        for m in (engine.fe, engine.fs, engine.enc, engine.lstm, engine.dec):
+            for sub in m.modules():
+                if isinstance(sub, FusedConv2d):
+                    sub.weight.data.mul_(1.0 + 0.01 * ((n % 5) - 2))
+                    n += 1
+        engine.lstm.lstm_cell.conv.weight.data.mul_(0.99)
+        return n
+
+    before = run(used)                   # packs every kernel copy and captures the graphs with the ORIGINAL weights
+    assert perturb(used) == perturb(fresh) > 50
+    used.refresh_weights()
+    used.clear_feature_cache()
+    after, expected = run(used), run(fresh)
+    kinds = {"direct": 0, "bottleneck": 0, "pointwise": 0}
+    for m in (used.fe, used.fs, used.enc, used.dec):
+        for sub in m.modules():
+            if isinstance(sub, FusedConv2d):
+                kinds["direct"] += bool(sub._direct_packed)
+                kinds["bottleneck"] += sub._bottleneck_packed is not None
+                kinds["pointwise"] += sub._pointwise_packed is not None
+    print(f"layers with packed kernel copies: {kinds}, ConvLSTM: {used._lstm_packed is not None}")
+    assert kinds["pointwise"] >= 30 and kinds["direct"] >= 15 and kinds["bottleneck"] >= 8 and used._lstm_packed is not None
+    for n, (a, b, c) in enumerate(zip(after, expected, before)):
+        assert torch.equal(a, b), n
+        assert not torch.equal(a, c), n      # (the perturbation reaches the depth)
