@@ -72,7 +72,7 @@ _STAGING_SLOTS = int(os.environ.get("DVMVS_STAGING_SLOTS", "1"))
 # instantiated (kept, never launched): all frame graphs end up on the same queue.  DESIGN.md section 5; 0 = the runtime's own order.
 _GRAPH_QUEUE_FILLERS = int(os.environ.get("DVMVS_GRAPH_QUEUE_FILLERS", "1"))
 # experiments: "1" = a frame's sweep runs before the side-stream fork instead of next to the side stream's kernels (see _frame_body_direct)
-_SWEEP_FIRST = os.environ.get("DVMVS_SWEEP_FIRST", "0") == "1"
+_FORK_AFTER = int(os.environ.get("DVMVS_FORK_AFTER", "1"))      # see _frame_body_direct (measured: -1 / 0 / 1 / 2 / 3 / 4 = 1 355 / 1 371 / 1 382 / 1 377 / 1 319 / 1 239 frames/s)
 _PAIRED_UPSAMPLING = os.environ.get("DVMVS_PAIRED_UPSAMPLING", "1") != "0"      # a decoder level's two up-samplings in one launch
 _UP2X_IN_CONV = os.environ.get("DVMVS_UP2X_IN_CONV", "1") != "0"      # the decoder's first up-sampling inside its convolution's staging
 _UPLOAD_IN_COPY_BATCH = os.environ.get("DVMVS_UPLOAD_IN_COPY_BATCH", "1") != "0"
@@ -1184,7 +1184,7 @@ class DepthEngine:
         sets = self._direct_buffers["sets"]
         cur, nxt = sets[parity], sets[1 - parity]
 
-        def own(sweep_done=False):
+        def own(sweep_done=False, after_level=None):
             if have < 1:
                 self._reference_features_direct(cur)
             warped = False
@@ -1194,7 +1194,7 @@ class DepthEngine:
                     with self._beside("warp"):
                         self._state_warp_direct(cur, has_previous)
                     warped = True
-                self._sweep_encoder_direct(cur, n_meas, sweep_variant, sweep_done=sweep_done)
+                self._sweep_encoder_direct(cur, n_meas, sweep_variant, sweep_done=sweep_done, after_level=after_level)
             self._lstm_decoder_direct(cur, has_previous, state_warped=warped)
 
         def ahead():
@@ -1211,15 +1211,25 @@ class DepthEngine:
             ahead()
         else:
             main = torch.cuda.current_stream(self.device)
-            # (DVMVS_SWEEP_FIRST=1: this frame's sweep alone on the chip before the fork.  Measured with the graphs on one hardware queue:
-            # 0.808 ms per frame against 0.798 with the sweep next to the side stream's kernels, for either sweep kernel -- off.)
-            sweep_first = have == 1 and _SWEEP_FIRST
-            if sweep_first:
+
+            def fork():
+                self._side_stream.wait_stream(main)
+                with torch.cuda.stream(self._side_stream):
+                    ahead()
+
+            # WHERE the next frame's work is forked off (DVMVS_FORK_AFTER, round 6).  The frame's first kernels fill the chip on their own -- the persistent
+            # sweep holds every CU's registers and LDS, the 5x5 layers of encoder level 0 run 256 workgroups -- so a side stream started next to them
+            # only delays them (and waits itself); its small kernels belong next to the chain's launch-bound middle (1/8 ... 1/32 maps, ConvLSTM).
+            # -1: at the start (rounds 4-5); 0: behind the sweep; k = 1 ... 4: behind encoder level k - 1.  Same kernels on the same inputs.
+            level = _FORK_AFTER if have == 1 else -1
+            if level < 0:
+                fork()
+                own()
+            else:
                 self._sweep_direct(cur, n_meas, sweep_variant)
-            self._side_stream.wait_stream(main)
-            with torch.cuda.stream(self._side_stream):
-                ahead()
-            own(sweep_done=sweep_first)
+                if level == 0:
+                    fork()
+                own(sweep_done=True, after_level=(level - 1, fork) if level > 0 else None)
             main.wait_stream(self._side_stream)
 
     def _reference_features_direct(self, buffers):
@@ -1245,7 +1255,7 @@ class DepthEngine:
         _ops.cost_volume_into(enc_cat[0][:, :32], buffers["meas_feat"][:n_meas], Hm, kt, self.min_depth, self.max_depth, enc_cat[0][:, 32:], sweep_variant,
                               self._sweep_items(buffers["index"]))
 
-    def _sweep_encoder_direct(self, buffers, n_meas, sweep_variant=0, sweep_done=False):
+    def _sweep_encoder_direct(self, buffers, n_meas, sweep_variant=0, sweep_done=False, after_level=None):
         """Plane sweep + cost-volume encoder of the frame whose features are in ``buffers``: reads that set's measurement features and
         sweep parameters, writes its skip connections (into the decoder's concatenation buffers) and its bottleneck map.  Depends on
         nothing the PREVIOUS frame computes -- no recurrent state, no previous depth -- which is what lets it run a frame ahead."""
@@ -1268,6 +1278,8 @@ class DepthEngine:
                 x = block.standard_convolution.conv2[0](x, out=buffers["lstm_cat"][:, :512])
             else:
                 x = block.standard_convolution.conv2[0](x, out=buffers["lstm_cat"][:, :512])      # (pairnet: the buffer is just the bottleneck's home)
+            if after_level is not None and after_level[0] == level:
+                after_level[1]()      # (the look-ahead fork: _frame_body_direct)
 
     def _state_warp_direct(self, buffers, has_previous):
         """Re-projection of the previous depth into the frame's 8x10 estimate and the hidden state warped with it into the ConvLSTM's input
