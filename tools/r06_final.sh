@@ -11,5 +11,6 @@ DVMVS_HIP_LIB=deep-video-mvs_amd/lib/libdvmvs_hip_tuning.so timeout 100 python t
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.txt" 2>&1
 tools/r06_frame_timeline.sh "$out/ft" > /dev/null 2>&1
 tools/profile_round.sh gpurun_out/prof_r06 > "$out/profile_round.log" 2>&1
+python tools/collect_profiles.py gpurun_out/prof_r06 r06 > /dev/null 2>&1
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver.json" 2> "$out/bench_driver.err"
 for i in $(seq 1 12); do timeout 200 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-rel-l1 --sequences-per-gpu 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); g=d['device_ms_between_step_ends']; print(round(d['value'],1), round(d['ms_per_step'],4), round(d['host_work_ms_per_step'],3), 'max gap', max(g), 'launches', d['launches_per_frame']['profiled'])"; done > "$out/bench_twelve_runs.txt"
