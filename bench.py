@@ -890,16 +890,25 @@ def main():
     level = 0 if args.no_feature_cache else args.lookahead      # the sequence is known in advance (as with a pre-computed keyframe index):
     run_frame_inner = make_frame_runner(engine, images, seq, full_K, M, level, not args.no_feature_cache)   # every step announces the next keyframe
 
+    step_trace_path = os.environ.get("DVMVS_BENCH_STEP_TRACE")      # diagnostic: the host clock at the checkpoints of every timed step, written
+    step_trace = []                                                  # when one of them (or a device gap) exceeds 2 ms: tools/r06_hiccup_hunt.sh
+
     def run_frame(k):
+        if step_trace_path:
+            engine.step_clock = []
         t_host = time.perf_counter()
         try:
             return run_frame_inner(k)
         finally:
-            host_seconds[0] += time.perf_counter() - t_host
+            t_end = time.perf_counter()
+            host_seconds[0] += t_end - t_host
             host_seconds[1] += 1
             if len(step_events) < 64:
                 step_events.append(torch.cuda.Event(enable_timing=True))
                 step_events[-1].record()
+            if step_trace_path:
+                step_trace.append((t_host, t_end, engine.step_clock))
+                engine.step_clock = None
 
     with torch.no_grad():
         # buffer fill: the first M keyframes only contribute features (reference: keyframe-buffer response 0 / short lists)
@@ -929,6 +938,15 @@ def main():
         elapsed = timed_region(lambda i: run_frame(M + i), args.warmup, args.steps, world, device, before=region_start, after=region_end)
         host_ms = 1e3 * host_seconds[0] / max(host_seconds[1], 1)
         host_wait_ms = 1e3 * engine.ring_wait_seconds / max(host_seconds[1], 1)
+        if step_trace_path:
+            timed = step_trace[-args.steps:]
+            gaps = [0.0] + [step_events[i - 1].elapsed_time(step_events[i]) for i in range(1, len(step_events))]
+            slow = [i for i, (a, b, _) in enumerate(timed) if 1e3 * (b - a) > 2.0 or (i < len(gaps) and gaps[i] > 2.0)]
+            if slow:
+                with open(step_trace_path, "w") as f:
+                    json.dump({"slow_steps": slow, "elapsed_ms_per_step": 1e3 * elapsed / args.steps,
+                               "steps": [{"start_ms": 1e3 * (a - timed[0][0]), "host_ms": 1e3 * (b - a), "device_gap_ms": gaps[i] if i < len(gaps) else None,
+                                          "marks_ms": [(name, 1e3 * (t - a)) for name, t in (marks or [])]} for i, (a, b, marks) in enumerate(timed)]}, f, indent=1)
     depth_mean = float(engine._static["depth"].mean())
     assert np.isfinite(depth_mean), "non-finite depth"
 

@@ -4,7 +4,7 @@
 // fusionnet/model.py:308-337) and the 256 / 512-channel 3x3 layers of the encoder's last block and the decoder's first block
 // (fusionnet/model.py:167-305) -- 80 or 320 output pixels against 2 304 ... 9 216-term reductions, i.e. GEMMs with a tiny M whose
 // cost is streaming the weights (75.5 MB for the ConvLSTM: 9.4 us at 8 TB/s) and 3.0 GFLOP of exact-fp32 arithmetic (19 us at the
-// 157 TF fp32 MFMA rate).  Why not MIOpen here (it stays the path of every other convolution): for exactly these problems MIOpen
+// 157 TF fp32 MFMA rate).  Why not MIOpen here (round 4: it was the path of every other convolution then): for exactly these problems MIOpen
 // picks its `igemm_fwd_gtcx35_nhwc_..._gkgs` kernels -- K split over workgroups and accumulated with float ATOMICS -- so the result
 // differs from run to run (measured: tools/conv_determinism_probe.py), which through the discrete depth estimate makes whole depth
 // maps process-dependent; and they cost 50 us + two layout transposes for the ConvLSTM (rocBLAS on an im2col
@@ -318,7 +318,7 @@ int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
 inline bool bottleneck_shape_ok(int C_out, int C_in, int H_in, int W_in, int stride) {
   if (C_out <= 0 || C_in <= 0 || C_in % 16 != 0) return false;
   // the 1/32 and 1/16 maps of a 320x256 frame (80-pixel groups), and (round 6) the stride-2 layer that takes the 1/8 map down to the 1/16 one
-  // (encoder_block2's down-convolution: MIOpen ran it as im2col + GEMM + an epilogue launch); other sizes stay on MIOpen
+  // (encoder_block2's down-convolution: MIOpen ran it as im2col + GEMM + an epilogue launch); other sizes are not this kernel's
   return (H_in == 8 && W_in == 10 && stride == 1) || (H_in == 16 && W_in == 20 && (stride == 1 || stride == 2)) || (H_in == 32 && W_in == 40 && stride == 2);
 }
 

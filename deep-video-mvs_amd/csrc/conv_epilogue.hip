@@ -1,6 +1,7 @@
 // Dense convolution with its bias add and ReLU inside MIOpen's own kernel (fusion plan: convolution + bias [+ activation]).
 //
-// The frame's dense convolutions stay on MIOpen; this entry only changes WHERE their epilogue runs: for the problems MIOpen
+// (Round 3; since round 6 no layer of a default engine takes this path: the dense, bottleneck and 1x1 layers have their own kernels.)
+// A convolution that stays on MIOpen; this entry only changes WHERE its epilogue runs: for the problems MIOpen
 // solves with its fp32 Winograd kernel the fused plan is the same kernel with the epilogue in its store path, i.e. one launch
 // instead of convolution + dvmvs_bias_act_fwd.  For other problems (those MIOpen's search gives to a GEMM or implicit-GEMM
 // solver) the fused plan is slower than the two launches; the caller decides per problem by timing both at warm-up

@@ -574,7 +574,7 @@ class DepthEngine:
                 if isinstance(sub, FusedConv2d):
                     sub.plan_epilogue = self.conv_plans
         # the 3x3 layers on the 8x10 / 16x20 maps and the ConvLSTM convolution through the deterministic MFMA kernel
-        # (csrc/bottleneck_conv.hip; DVMVS_BOTTLENECK_CONVS=0: MIOpen as everywhere else)
+        # (csrc/bottleneck_conv.hip; DVMVS_BOTTLENECK_CONVS=0: MIOpen)
         if bottleneck_convs is None:
             bottleneck_convs = os.environ.get("DVMVS_BOTTLENECK_CONVS", "1") != "0"
         self.bottleneck_convs = bool(bottleneck_convs and fuse and not channels_last)

@@ -273,7 +273,8 @@ int dvmvs_depthwise_conv_bwd(const float* grad_out, const float* in, const float
  * fp32 MFMA GEMM with a DETERMINISTIC split-K (csrc/bottleneck_conv.hip).  Replaces, for those shapes only, the nn.Conv2d of the
  * ConvLSTM cell (/root/reference/dvmvs/convlstm.py:43-44: 1024 -> 2048 channels) and the 256 / 512-channel layers around it
  * (fusionnet/model.py:167-305), which MIOpen solves with split-K kernels that accumulate with float atomics (results vary from
- * run to run).  Inference only (no gradient); every other convolution stays on MIOpen.
+ * run to run).  Inference only (no gradient); the other convolutions of an inference frame have their own entries below (dvmvs_direct_conv_*,
+ * dvmvs_pointwise_conv_*, dvmvs_depthwise_conv_fwd); training convolutions stay on MIOpen.
  *   dvmvs_bottleneck_conv_pack    weight [C_out,C_in,3,3] -> packed (dvmvs_bottleneck_conv_packed_bytes; C_in % 16 == 0), once
  *   dvmvs_bottleneck_conv_splits  number S of partial sums for a problem, DVMVS_EUNSUPPORTED for shapes the kernel does not take
  *   dvmvs_bottleneck_conv_fwd     x [B,C_in,H_in,W_in] -> partials [S][B][C_out][H_out*W_out]: partial s holds the contribution of
