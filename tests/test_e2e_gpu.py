@@ -536,3 +536,31 @@ def test_refresh_weights_repacks_every_kernel_copy(hip_device):
     for n, (a, b, c) in enumerate(zip(after, expected, before)):
         assert torch.equal(a, b), n
         assert not torch.equal(a, c), n      # (the perturbation reaches the depth)
+
+
+@pytest.mark.parametrize("fork_after", [-1, 0, 2, 4])
+def test_every_fork_point_of_the_lookahead_is_bit_identical(hip_device, monkeypatch, fork_after):
+    """DVMVS_FORK_AFTER (round 6): where the frame graph forks the next frame's feature extraction off -- at the start, behind the sweep, behind
+    encoder level k - 1 (default 1, covered by the tests above).  Same kernels on the same inputs: the depth and the recurrent state equal the
+    engine without look-ahead bit for bit, through eager frames and replayed graphs on both buffer sets."""
+    import dvmvs.engine as engine_module
+    monkeypatch.setattr(engine_module, "_FORK_AFTER", fork_after)
+    dev = hip_device
+    _, ahead = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
+    _, plain = build(dev, fusion=True, fold_bn=True, cache_features=True, use_graphs=True)
+    fullK = syn.full_K()
+    lines = syn.keyframe_index_lines(2)[:9]
+    held = {}
+    image = lambda i: held.setdefault(i, syn.e2e_image(i).to(dev))
+    used = 0
+    for n, (r, ms) in enumerate(lines):
+        args = (image(r), syn.pose(r), [syn.e2e_image(i).to(dev) for i in ms], [syn.pose(i) for i in ms], fullK)
+        kw = {}
+        if n + 1 < len(lines):
+            kw = dict(next_reference_image=image(lines[n + 1][0]), next_frame_id=lines[n + 1][0])
+        used += bool(ahead._prefetched and ahead._prefetched["frame_id"] == r)
+        a = ahead.step(*args, frame_id=r, measurement_ids=list(ms), **kw).clone()
+        b = plain.step(*args, frame_id=r, measurement_ids=list(ms)).clone()
+        assert torch.equal(a, b), (fork_after, n)
+        assert torch.equal(ahead._static["h"], plain._static["h"]) and torch.equal(ahead._static["c"], plain._static["c"]), (fork_after, n)
+    assert used >= 6 and any(k[4] == 1 and k[5] == 1 for k in ahead._graphs)
