@@ -36,6 +36,18 @@ constexpr int kBcTargetWaves = 2048;   // two per SIMD
 #endif
 constexpr int kBcStage = DVMVS_BC_STAGE;   // elements of the staged slice a thread has in flight at a time
 
+// ---- optional timeline instrumentation (tools/bottleneck_conv_trace.py; built only by `make trace`): per wave, on the 100 MHz wall clock:
+// [0] start, [1] slice staged (after the barrier), [2] sum over groups of "waiting for the group's weights", [3] of "MFMAs of the group",
+// [4] group loop left, [5] end (partials stored), [6] SIMD-unique id (CU, SIMD), [7] groups ----
+#ifdef DVMVS_SWEEP_TRACE
+constexpr int kBcTraceWords = 8, kBcTraceWaves = 8192;
+__device__ unsigned long long g_bc_trace[kBcTraceWaves * kBcTraceWords];
+#define BC_TRACE(...) __VA_ARGS__
+#define BC_NOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define BC_TRACE(...)
+#endif
+
 struct BottleneckConvArgs {
   const float* x;        // [B, C_in, H_in, W_in]
   const float* packed;   // [n_tiles][C_in / 16][9][64] float4
@@ -103,6 +115,7 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_tile = blockIdx.x * kBcWaves + wave;
   const int split = blockIdx.y;
+  BC_TRACE(const unsigned long long tr_start = BC_NOW(); unsigned long long tr_staged = 0, tr_wait = 0, tr_mfma = 0, tr_loop = 0;)
   const int b = blockIdx.z / PG, pg = blockIdx.z - b * PG;
   const int c0 = split * a.cs;
 
@@ -149,6 +162,7 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
     }
   }
   __syncthreads();
+  BC_TRACE(tr_staged = BC_NOW();)
   if (n_tile >= a.n_tiles) return;
 
   // this lane's B-operand position: input channel (lane >> 4) of a group of four, pixel (lane & 15) of each 16-pixel tile
@@ -218,6 +232,7 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
 #pragma unroll
       for (int t = 0; t < 9; ++t) w[c][t] = wp[(g0 + c) * (9 * 64) + t * 64];
     __builtin_amdgcn_sched_barrier(0);   // the requests stay in front of the MFMAs (the scheduler otherwise sinks each next to its use)
+    BC_TRACE(const unsigned long long tr_a = BC_NOW(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long tr_b = BC_NOW(); tr_wait += tr_b - tr_a;)
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const float* xc = xs + (g0 + c) * 16 * PLANE;
@@ -232,7 +247,9 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
         }
       }
     }
+    BC_TRACE(__builtin_amdgcn_sched_barrier(0); tr_mfma += BC_NOW() - tr_b;)
   }
+  BC_TRACE(tr_loop = BC_NOW();)
 
   // D[row = (lane >> 4) * 4 + r][col = lane & 15] -> partials[split][b][n][p]
   gfloat_p out = as_global(a.partials) + ((static_cast<size_t>(split) * a.B + b) * a.C_out) * P;
@@ -244,6 +261,20 @@ __global__ __launch_bounds__(kBcWaves * 64, 2) void bottleneck_conv_kernel(Bottl
       for (int pt = 0; pt < kBcPT; ++pt) out[static_cast<size_t>(n) * P + pg * kBcPixels + pt * 16 + (lane & 15)] = acc[pt][r];
     }
   }
+  BC_TRACE({
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tr_end = BC_NOW();
+    const size_t wv = (static_cast<size_t>(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * kBcWaves + wave;
+    if (lane == 0 && wv < kBcTraceWaves) {
+      unsigned int hw_id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+      unsigned int xcc_id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+      unsigned long long* t = g_bc_trace + wv * kBcTraceWords;
+      t[0] = tr_start; t[1] = tr_staged; t[2] = tr_wait; t[3] = tr_mfma; t[4] = tr_loop; t[5] = tr_end;
+      t[6] = (static_cast<unsigned long long>(xcc_id & 0xf) << 32) | hw_id; t[7] = static_cast<unsigned long long>(groups);
+    }
+  })
 }
 
 // packed[((tile * G + g) * 9 + tap) * 64 + lane][j] = W[16 tile + (lane & 15)][16 g + 4 j + (lane >> 4)][tap]
@@ -291,10 +322,19 @@ inline constexpr int bottleneck_staged_plane(int H_in, int W_in, int stride, boo
 template <int H_IN, int W_IN, int STRIDE, bool WINDOW = false, bool UP2X = false>
 int launch_bottleneck_conv(const BottleneckConvArgs& a, hipStream_t stream) {
   constexpr int P = (H_IN / STRIDE) * (W_IN / STRIDE), PLANE = bottleneck_staged_plane(H_IN, W_IN, STRIDE, WINDOW);
-  const size_t lds = sizeof(float) * static_cast<size_t>(a.cs) * PLANE;
+  size_t lds = sizeof(float) * static_cast<size_t>(a.cs) * PLANE;
   if (lds > kBcLdsBytes) return DVMVS_EUNSUPPORTED;
   const dim3 grid((a.n_tiles + kBcWaves - 1) / kBcWaves, a.splits, a.B * (P / kBcPixels)), block(kBcWaves * 64);
 #ifdef DVMVS_SWEEP_TUNING
+  if (const char* kb = getenv("DVMVS_BC_LDS_KB")) {      // tools-only build: a larger LDS request caps the workgroups per CU (160 KB / request)
+    const size_t want = static_cast<size_t>(atoi(kb)) * 1024;
+    if (want > lds) {
+      lds = want;
+      if (want > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_conv_kernel<H_IN, W_IN, STRIDE, 1, WINDOW, UP2X>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(want));
+      }
+    }
+  }
   const int groups = a.cs / 16;      // tools-only build: DVMVS_BC_CH=1|2|4 forces the request burst (tools/lstm_conv_probe.py)
   if (const char* ch = getenv("DVMVS_BC_CH")) {
     const int c = atoi(ch);
@@ -383,6 +423,13 @@ extern "C" int dvmvs_bottleneck_conv_up2x_fwd(const float* x, const float* packe
   a.cs = C_in / a.splits;
   return launch_bottleneck_conv<16, 20, 1, true, true>(a, static_cast<hipStream_t>(stream));
 }
+
+#ifdef DVMVS_SWEEP_TRACE
+extern "C" int dvmvs_debug_bottleneck_conv_trace(unsigned long long* host, int waves) {
+  if (waves > dvmvs::kBcTraceWaves) waves = dvmvs::kBcTraceWaves;
+  return static_cast<int>(hipMemcpyFromSymbol(host, HIP_SYMBOL(dvmvs::g_bc_trace), sizeof(unsigned long long) * dvmvs::kBcTraceWords * waves));
+}
+#endif
 
 extern "C" int dvmvs_partial_sums_bias_act_fwd(const float* partials, int n_partials, float* dst, long long dst_batch_stride, const float* bias,
                                                int B, int C, int HW, int activation, dvmvs_stream_t stream) {
